@@ -1,0 +1,215 @@
+/*
+ * medvill.h -- C ABI of the MI355X (gfx950) hot-path library for MedViLL / CXRBERT
+ * cross-modal BERT pretraining (libmedvill_hip.so).
+ *
+ * The reference (reonaledo/Multi-modality-Self-supervision) is pure Python and has no
+ * FFI layer: its boundary is the Python object protocol
+ *     CXRBERT(config, args).forward(cls_tok, input_txt, attn_mask, segment, input_img, sep_tok)
+ *         -> (mlm_logits[B,L,V], itm_logits[B,2])          models/cxrbert_origin.py:132-149
+ *     CXRBERT_Trainer(args, train_dataloader, test_dataloader).train(epoch) / .save(epoch, path)
+ *                                                            models/train_origin.py:19-20,70,254
+ * which `multi-modality-self-supervision_amd/` mirrors in Python.  Underneath that
+ * mirror every piece of arithmetic goes through the entry points below; each one
+ * names the reference code whose work it replaces.  (INTEGRATION.md shows the ctypes
+ * binding a maintainer of the reference would add.)
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; all data pointers are DEVICE pointers owned
+ *     by the caller (torch's allocator); no allocation inside, workspaces are passed in.
+ *   - every call takes the hipStream_t to enqueue on (as void*) and never synchronises.
+ *   - return 0 = ok; negative = invalid argument / unsupported shape (MV_E_*);
+ *     positive = hipError_t of a failed launch.  Nothing throws.
+ *   - re-entrant, no global mutable state except mv_set_impl() (test hook).
+ *   - dtype: MV_F32 = exact fp32 path (plain VALU kernels; parity at 1e-3 and below),
+ *            MV_BF16 = bf16 storage, fp32 accumulate, MFMA kernels (the fast path).
+ *   - matrices are row-major; "ld*" are leading dimensions in ELEMENTS.
+ */
+#ifndef MEDVILL_H_
+#define MEDVILL_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MV_ABI_VERSION 1
+
+enum { MV_F32 = 0, MV_BF16 = 1 };
+
+enum {
+  MV_OK = 0,
+  MV_E_ARG = -1,      /* null pointer / non-positive size */
+  MV_E_SHAPE = -2,    /* shape or alignment the kernels do not support */
+  MV_E_DTYPE = -3,
+  MV_E_WORKSPACE = -4 /* workspace too small */
+};
+
+/* GEMM epilogues (mv_gemm `epi`) */
+enum {
+  MV_EPI_NONE = 0,      /* C = A.B                                                        */
+  MV_EPI_BIAS = 1,      /* C = A.B + bias[n]                                              */
+  MV_EPI_BIAS_GELU = 2, /* Z = A.B + bias -> C2 (pre-activation, kept for backward);
+                           C = gelu_erf(Z)          cxrbert_origin.py:176-181 / HF BertIntermediate */
+  MV_EPI_BIAS_RES = 3,  /* C = A.B + bias[n] + R[m,n]   (HF BertSelfOutput / BertOutput before LayerNorm) */
+  MV_EPI_DGELU = 4,     /* C = (A.B) * gelu_erf'(R[m,n])   (backward of MV_EPI_BIAS_GELU; R = saved Z)  */
+  MV_EPI_RES = 5,       /* C = A.B + R[m,n]             (backward: add the residual-branch gradient)    */
+  MV_EPI_BIAS_TANH = 6  /* C = tanh(A.B + bias)         HF BertPooler, cxrbert_origin.py:130            */
+};
+
+/* implementation selector (test hook): 0 = auto (MFMA for bf16, VALU for f32), 1 = force the
+ * plain VALU kernels for every dtype. */
+int mv_abi_version(void);
+void mv_set_impl(int impl);
+int mv_get_impl(void);
+const char* mv_build_info(void);
+
+/* ---- dense projections --------------------------------------------------------------------
+ * Replaces every nn.Linear on the path and its autograd backward:
+ *   cxrbert_origin.py:16,24 (image projection), HF BertSelfAttention/BertSelfOutput/
+ *   BertIntermediate/BertOutput/BertPooler (call sites cxrbert_origin.py:72-73,126-130),
+ *   cxrbert_origin.py:214,228-237 (MLM transform + tied decoder), :170-173 (ITM).
+ * C[M,N] = epi( opA(A)[M,K] . opB(B)[K,N] ):
+ *   ta = 0: A stored [M,K] (lda >= K);  ta = 1: A stored [K,M] (lda >= M)
+ *   tb = 0: B stored [N,K] (ldb >= K) -- an nn.Linear weight;  tb = 1: B stored [K,N] (ldb >= N)
+ * so  y = x.W^T            is (ta=0, tb=0, A=x,  B=W)
+ *     dx = dy.W            is (ta=0, tb=1, A=dy, B=W)
+ *     dW = dy^T.x          is (ta=1, tb=1, A=dy, B=x)
+ * dtype applies to A and B; c_dtype to C (and C2); r_dtype to R; bias is always f32.
+ * bf16 operands need 16-byte aligned bases and lda, ldb multiples of 8; a contraction length
+ * K that is not a multiple of 8 is allowed only when the k-contiguous operand's rows are
+ * zero-padded up to the next multiple of 8.
+ * splitk > 1: the K range is cut in `splitk` slices whose partial tiles go to `ws`
+ * (>= splitk*M*N floats) and are summed by a second kernel; only with MV_EPI_NONE and an f32 C.
+ * accumulate != 0: C += result (f32 C, MV_EPI_NONE only).                                      */
+int mv_gemm(int dtype, int ta, int tb, int M, int N, int K,
+            const void* A, int lda, const void* B, int ldb,
+            void* C, int ldc, int c_dtype,
+            const float* bias, int epi,
+            const void* R, int ldr, int r_dtype,
+            void* C2, int ldc2,
+            int splitk, float* ws, size_t ws_bytes, int accumulate, void* stream);
+
+/* ---- attention masks ----------------------------------------------------------------------
+ * Replaces CXRBertEncoder.get_extended_attn_mask (cxrbert_origin.py:75-85): instead of an
+ * fp16 additive [B,1,L,L] tensor the int64 0/1 mask the Dataset built
+ * (data/dataset_origin.py:138-176) is packed once per batch into
+ *   bits     uint32 [B, L, W]   W = ceil(L/32); bit (j&31) of word j>>5 = mask[b,i,j]
+ *   tileinfo uint8  [B, TQ, TK] TQ = TK = ceil(L/64); per 64x64 tile: 0 = every entry masked and
+ *                               every query row of the tile sees at least one key somewhere
+ *                               (safe to skip), 1 = every in-range entry visible, 2 = mixed
+ * mask_ndim = 3: mask is [B,L,L];  mask_ndim = 2: mask is [B,L] (the `attn_1d` / retrieval form,
+ * cxrbert_origin.py:76-77), broadcast over query rows.  Masked entries contribute the
+ * reference's additive -10000.0 (not -inf) inside the kernels.                                 */
+int mv_mask_pack(const int64_t* mask, int mask_ndim, int B, int L,
+                 uint32_t* bits, uint8_t* tileinfo, void* stream);
+
+/* ---- fused-mask multi-head attention --------------------------------------------------------
+ * Replaces HF BertSelfAttention's scores/softmax/context (spec:
+ * Downstream_task/report_generation_and_vqa/sc/pytorch_pretrained_bert/model.py:301-320):
+ *   ctx[b,i,h,:] = sum_j softmax_j( q.k/sqrt(dh) + (1-mask)*-10000 ) v
+ * qkv is the fused projection output [B*L, 3H] (q | k | v, heads contiguous inside each).
+ * lse [B, A, L] (f32) = log-sum-exp of each score row, kept for the backward.
+ * dh must be 64 (bf16 MFMA path) or <= 128 (f32 path).                                        */
+int mv_attn_fwd(int dtype, const void* qkv, const uint32_t* bits, const uint8_t* tileinfo,
+                void* ctx, float* lse, int B, int L, int A, int dh, void* stream);
+
+/* dqkv [B*L,3H] from dctx [B*L,H]; `delta` is a [B,A,L] f32 scratch (rowsum(dctx*ctx)). */
+int mv_attn_bwd(int dtype, const void* qkv, const void* ctx, const void* dctx, const float* lse,
+                const uint32_t* bits, const uint8_t* tileinfo,
+                void* dqkv, float* delta, int B, int L, int A, int dh, void* stream);
+
+/* ---- LayerNorm ------------------------------------------------------------------------------
+ * y = (x-mean)/sqrt(var+eps)*gamma+beta over the last dim (HF LayerNorm eps=1e-12 in the
+ * encoder; TF-style BertLayerNorm eps=1e-5 of cxrbert_origin.py:189-202 in the MLM head).
+ * x_dtype: dtype of x (the fused-residual GEMM writes f32); y in `dtype`.
+ * mean, rstd: f32 [M], kept for backward.                                                     */
+int mv_layernorm_fwd(int dtype, const void* x, int x_dtype, const float* gamma, const float* beta,
+                     void* y, float* mean, float* rstd, int M, int H, float eps, void* stream);
+
+/* dx (dtype) = LN backward of dy (dtype) w.r.t. x; dgamma/dbeta (f32 [H]) are ACCUMULATED
+ * (atomically) -- zero them first; colsum (f32 [H], nullable) accumulates sum_m dx[m,:]
+ * (the bias gradient of the projection that produced x).                                      */
+int mv_layernorm_bwd(int dtype, const void* dy, const void* x, int x_dtype, const float* mean,
+                     const float* rstd, const float* gamma, void* dx, float* dgamma, float* dbeta,
+                     float* colsum, int M, int H, void* stream);
+
+/* ---- sequence assembly + embeddings ---------------------------------------------------------
+ * Replaces CXRBertEncoder.forward's else-branch assembly (cxrbert_origin.py:114-125),
+ * ImageBertEmbeddings.forward (:22-35) and the four HF BertEmbeddings calls: writes
+ *   x0[b] = LN( [ E[cls]+Ty[0]+P[0] | imgproj[b,n]+P[img_pos[b,n]]+Ty[0] | E[sep]+Ty[0]+P[0] |
+ *               E[txt[b,t]]+Ty[segment[b,t]]+P[t] ] )         L = N + T + 2
+ * straight into the concatenated [B,L,H] buffer.  imgproj = feats.Wi^T + bi comes from mv_gemm.
+ * Tables E, P, Ty and imgproj are in `dtype`; gamma/beta f32.  `pre` (f32 [B,L,H]) keeps the
+ * pre-LayerNorm sums for the backward.                                                        */
+int mv_embed_fwd(int dtype, const int64_t* cls_tok, const int64_t* txt, const int64_t* segment,
+                 const int64_t* img_pos, const int64_t* sep_tok, const void* imgproj,
+                 const void* E, const void* P, const void* Ty, const float* gamma, const float* beta,
+                 void* x0, float* pre, float* mean, float* rstd,
+                 int B, int N, int T, int H, int V, int maxpos, float eps, void* stream);
+
+/* Backward of the above: LN backward of dx0, scatter-add (f32 atomics) into dE [V,H], dP, dTy,
+ * dgamma, dbeta (all ACCUMULATED) and write d(imgproj) [B,N,H] in `dtype`.                     */
+int mv_embed_bwd(int dtype, const void* dx0, const float* pre, const float* mean, const float* rstd,
+                 const float* gamma, const int64_t* cls_tok, const int64_t* txt, const int64_t* segment,
+                 const int64_t* img_pos, const int64_t* sep_tok,
+                 float* dE, float* dP, float* dTy, float* dgamma, float* dbeta, void* dimgproj,
+                 int B, int N, int T, int H, int V, int maxpos, void* stream);
+
+/* ---- losses + step metrics ------------------------------------------------------------------
+ * Replaces nn.CrossEntropyLoss(ignore_index=-100) on mlm.transpose(1,2) and
+ * nn.CrossEntropyLoss() on the ITM logits (train_origin.py:62-63,120-126) plus the argmax
+ * metrics of train_origin.py:133-146, fused with the loss gradient.
+ * logits [R, ld] (l_dtype f32 or bf16); labels int32 [R] (-100 = ignored row);
+ * out[0] += sum of nll over labelled rows, out[1] += #labelled rows, out[2] += #rows whose
+ * argmax == label (f32 accumulators, zero them first).
+ * dlogits (nullable; d_dtype) = (softmax - onehot) * grad_scale for labelled rows, 0 otherwise;
+ * columns V..ldd-1 are zero-filled (so dlogits can feed mv_gemm with K = V).
+ * grad_scale is read from the device (*grad_scale_dev) when non-null (so 1/n_labelled_global
+ * can be produced by an all-reduce without a host sync), else grad_scale_host.                */
+int mv_ce_fwd_bwd(const void* logits, int l_dtype, int ld, const int32_t* labels, int R, int V,
+                  float* out, void* dlogits, int d_dtype, int ldd,
+                  const float* grad_scale_dev, float grad_scale_host, void* stream);
+
+/* ---- row gather / scatter (labelled-row compaction for the MLM head) ------------------------
+ * dst[i,:] = src[rows[i],:]  /  dst[rows[i],:] (+)= src[i,:]; rows int32 [R].                 */
+int mv_gather_rows(int dtype, const void* src, int lds, const int32_t* rows, int R, int H,
+                   void* dst, int ldd, void* stream);
+int mv_scatter_rows(int dtype, const void* src, int lds, const int32_t* rows, int R, int H,
+                    void* dst, int ldd, int accumulate, void* stream);
+
+/* out[n] (+)= sum_m x[m,n]  (bias gradients). x [M,N] in dtype, out f32.                      */
+int mv_colsum(int dtype, const void* x, int ldx, int M, int N, float* out, int accumulate, void* stream);
+
+/* elementwise c = a + b (dtype), n elements */
+int mv_add(int dtype, const void* a, const void* b, void* c, size_t n, void* stream);
+
+/* out = dy * gelu_erf'(z) (mode 0; backward of the MLM transform's activation,
+ * cxrbert_origin.py:176-181,216) or out = dy * (1 - z*z) (mode 1; tanh backward of the pooler,
+ * z holds the tanh OUTPUT).  n elements, n % 4 == 0. */
+int mv_dact(int dtype, int mode, const void* dy, const void* z, void* out, size_t n, void* stream);
+
+/* 2-D cast: dst[r, 0..cols) = src[r, 0..cols), dst[r, cols..ldd) = 0 (pads a [rows, V] gradient
+ * to a leading dimension the MFMA GEMM accepts). */
+int mv_cast2d(const void* src, int src_dtype, long long lds, void* dst, int dst_dtype, long long ldd,
+              int rows, int cols, void* stream);
+
+/* dst(dst_dtype) = src(src_dtype), n elements */
+int mv_cast(const void* src, int src_dtype, void* dst, int dst_dtype, size_t n, void* stream);
+
+/* ---- optimizer ------------------------------------------------------------------------------
+ * HF transformers.optimization.AdamW (<= 4.x) as called at train_origin.py:60,131:
+ *   m = b1*m+(1-b1)*g; v = b2*v+(1-b2)*g*g; p -= lr*sqrt(1-b2^t)/(1-b1^t) * m/(sqrt(v)+eps);
+ *   p -= lr*wd*p            (eps added BEFORE the bias correction, decoupled decay)
+ * over one flat f32 buffer of n elements (all parameters live in one flat buffer);
+ * g is multiplied by grad_scale first; `shadow` (nullable) receives the bf16 copy of the
+ * updated parameters that the MFMA kernels read.                                              */
+int mv_adamw_step(float* p, const float* g, float* m, float* v, void* shadow_bf16, size_t n,
+                  float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                  int correct_bias, float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MEDVILL_H_ */

@@ -1,0 +1,13 @@
+"""MI355X-native (gfx950) implementation of MedViLL's cross-modal BERT pretraining hot path.
+
+Mirrors the reference's Python interface for that path and nothing else:
+    CXRBERT(config, args).forward(...)            models/cxrbert_origin.py:132-149
+    CXRBERT_Trainer(args, train_dl, test_dl)      models/train_origin.py:19-266
+on top of hand-written HIP kernels reached through the C ABI of include/medvill.h.
+"""
+from .engine import Engine, ModelConfig, param_layout  # noqa: F401
+from .cxrbert import CXRBERT  # noqa: F401
+from .trainer import CXRBERT_Trainer, TrainStep  # noqa: F401
+from . import data  # noqa: F401
+
+__all__ = ["Engine", "ModelConfig", "param_layout", "CXRBERT", "CXRBERT_Trainer", "TrainStep", "data"]

@@ -1,0 +1,109 @@
+"""ctypes binding of libmedvill_hip.so (the C ABI declared in include/medvill.h).
+
+The product path FAILS LOUDLY when the HIP library is missing or a call returns a
+non-zero status: there is no CPU / eager fallback anywhere in this package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libmedvill_hip.so")
+
+MV_F32, MV_BF16 = 0, 1
+EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RES, EPI_DGELU, EPI_RES, EPI_BIAS_TANH = range(7)
+_ERR = {-1: "MV_E_ARG (null pointer / bad size)", -2: "MV_E_SHAPE (unsupported shape or alignment)",
+        -3: "MV_E_DTYPE", -4: "MV_E_WORKSPACE (workspace too small)"}
+
+vp, i32, i64, f32, sz = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_size_t
+
+# name -> argtypes; every function returns int unless listed in _RESTYPE.  This table is also
+# what tests/test_abi.py checks against include/medvill.h.
+PROTOTYPES = {
+    "mv_abi_version": [],
+    "mv_set_impl": [i32],
+    "mv_get_impl": [],
+    "mv_build_info": [],
+    "mv_gemm": [i32, i32, i32, i32, i32, i32, vp, i32, vp, i32, vp, i32, i32, vp, i32, vp, i32, i32, vp, i32, i32, vp, sz,
+                i32, vp],
+    "mv_mask_pack": [vp, i32, i32, i32, vp, vp, vp],
+    "mv_attn_fwd": [i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
+    "mv_attn_bwd": [i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
+    "mv_layernorm_fwd": [i32, vp, i32, vp, vp, vp, vp, vp, i32, i32, f32, vp],
+    "mv_layernorm_bwd": [i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp],
+    "mv_embed_fwd": [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, vp],
+    "mv_embed_bwd": [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
+    "mv_ce_fwd_bwd": [vp, i32, i32, vp, i32, i32, vp, vp, i32, i32, vp, f32, vp],
+    "mv_gather_rows": [i32, vp, i32, vp, i32, i32, vp, i32, vp],
+    "mv_scatter_rows": [i32, vp, i32, vp, i32, i32, vp, i32, i32, vp],
+    "mv_colsum": [i32, vp, i32, i32, i32, vp, i32, vp],
+    "mv_add": [i32, vp, vp, vp, sz, vp],
+    "mv_dact": [i32, i32, vp, vp, vp, sz, vp],
+    "mv_cast2d": [vp, i32, i64, vp, i32, i64, i32, i32, vp],
+    "mv_cast": [vp, i32, vp, i32, sz, vp],
+    "mv_adamw_step": [vp, vp, vp, vp, vp, sz, f32, f32, f32, f32, f32, i32, i32, f32, vp],
+}
+_RESTYPE = {"mv_set_impl": None, "mv_build_info": C.c_char_p}
+
+_lib = None
+
+
+def load(build_if_missing: bool = False):
+    """Load (once) and return the ctypes handle.  Raises if the library is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        if build_if_missing:
+            from ._build import build
+            build()
+        else:
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: the gfx950 HIP extension has not been built. Run "
+                "`python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc). There is no fallback path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, args in PROTOTYPES.items():
+        fn = getattr(lib, name)          # AttributeError if an exported symbol is missing
+        fn.argtypes = args
+        fn.restype = _RESTYPE.get(name, C.c_int)
+    if lib.mv_abi_version() != 1:
+        raise RuntimeError("libmedvill_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc == 0:
+        return
+    if rc < 0:
+        raise RuntimeError(f"{what}: {_ERR.get(rc, rc)}")
+    raise RuntimeError(f"{what}: hipError_t {rc}")
+
+
+def dt_of(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return MV_F32
+    if t.dtype == torch.bfloat16:
+        return MV_BF16
+    raise TypeError(f"unsupported dtype {t.dtype}")
+
+
+def torch_dtype(dt: int):
+    return torch.float32 if dt == MV_F32 else torch.bfloat16
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("medvill HIP kernels need CUDA(ROCm) tensors; there is no CPU fallback")

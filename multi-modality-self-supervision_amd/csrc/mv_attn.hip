@@ -1,0 +1,789 @@
+// Fused-mask multi-head attention for the CXRBERT hot path on gfx950.
+//
+// Replaces HF BertSelfAttention's  softmax(q.k^T/sqrt(dh) + (1-mask)*-10000) . v  and its
+// backward (spec: Downstream_task/report_generation_and_vqa/sc/pytorch_pretrained_bert/
+// model.py:301-320) together with CXRBertEncoder.get_extended_attn_mask
+// (models/cxrbert_origin.py:75-85).  The [B,L,L] int64 mask of data/dataset_origin.py:138-176
+// is packed once per batch into bits + a per-64x64-tile class (mask_pack kernels) and the
+// additive -10000 is applied on the fly; the [B,A,L,L] score tensor never exists in HBM.
+//
+// MFMA kernels (bf16, dh = 64), all on v_mfma_f32_32x32x16_bf16, flash-style:
+//   forward : one wave = 32 queries ON THE LANES (S^T = K.Q^T, O^T = V^T.P^T) so that the
+//             running max / sum / rescale are lane-local; P^T goes from the accumulator
+//             straight into the next MFMA's B operand (no LDS round trip).
+//   dQ      : same orientation (dS^T is lane-local in q, dQ^T = K^T.dS^T).
+//   dK,dV   : one wave = 32 keys on the lanes (S = Q.K^T, dV^T = dO^T.P, dK^T = Q^T.dS).
+// K/V (or Q/dO) tiles of 64 rows x 64 dh live in LDS in ONE image that serves both the
+// row reads (ds_read_b128) and the transposed reads (ds_read_b64_tr_b16), conflict-free for both.
+// The VALU kernels below them are the exact-fp32 path and the on-GPU cross-check.
+#include "mv_common.h"
+
+#define LOG2E 1.4426950408889634f
+#define LN2 0.6931471805599453f
+#define MASK_ADD (-10000.0f)
+
+// =========================================================================================
+// mask packing
+// =========================================================================================
+__global__ void mask_pack_kernel(const int64_t* __restrict__ mask, int ndim, int B, int L, int W, uint32_t* __restrict__ bits) {
+  // one wave per (b, i) row
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (wave >= B * L) return;
+  const int b = wave / L, i = wave - b * L;
+  const int64_t* row = (ndim == 3) ? mask + ((size_t)b * L + i) * L : mask + (size_t)b * L;
+  uint32_t* out = bits + ((size_t)b * L + i) * W;
+  for (int j0 = 0; j0 < L; j0 += 64) {
+    const int j = j0 + lane;
+    const bool v = (j < L) && (row[j] != 0);
+    const unsigned long long bal = __ballot(v);
+    if (lane == 0) {
+      out[j0 >> 5] = (uint32_t)bal;
+      if ((j0 >> 5) + 1 < W) out[(j0 >> 5) + 1] = (uint32_t)(bal >> 32);
+    }
+  }
+}
+
+// one wave per (b, tq): class of every 64x64 tile of that query-tile row
+__global__ void mask_tileinfo_kernel(const uint32_t* __restrict__ bits, int B, int L, int W, int T, uint8_t* __restrict__ info) {
+  const int b = blockIdx.x / T, tq = blockIdx.x - b * T;
+  const int lane = threadIdx.x;
+  const int i = tq * 64 + lane;
+  const bool rv = i < L;
+  const uint32_t* row = bits + ((size_t)b * L + (rv ? i : 0)) * W;
+  bool row_any = false;
+  unsigned long long all0_m = 0, all1_m = 0;  // per-tile flags (T <= 64)
+  for (int tk = 0; tk < T; ++tk) {
+    const int w0 = 2 * tk;
+    unsigned long long w = 0;
+    if (rv) {
+      w = row[w0];
+      if (w0 + 1 < W) w |= ((unsigned long long)row[w0 + 1]) << 32;
+    }
+    const int ncol = min(64, L - tk * 64);
+    const unsigned long long full = (ncol == 64) ? ~0ull : ((1ull << ncol) - 1ull);
+    w &= full;
+    row_any |= (w != 0);
+    const bool a0 = __all(!rv || w == 0);
+    const bool a1 = __all(!rv || w == full);
+    if (a0) all0_m |= (1ull << tk);
+    if (a1) all1_m |= (1ull << tk);
+  }
+  const bool rows_ok = __all(!rv || row_any);
+  if (lane < T) {
+    const int tk = lane;
+    uint8_t c = 2;
+    if ((all1_m >> tk) & 1) c = 1;
+    else if (((all0_m >> tk) & 1) && rows_ok) c = 0;
+    info[((size_t)b * T + tq) * T + tk] = c;
+  }
+}
+
+extern "C" int mv_mask_pack(const int64_t* mask, int mask_ndim, int B, int L, uint32_t* bits, uint8_t* tileinfo, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!mask || !bits || !tileinfo || B <= 0 || L <= 0) return MV_E_ARG;
+  if (mask_ndim != 2 && mask_ndim != 3) return MV_E_SHAPE;   // NotImplementedError in cxrbert_origin.py:80-81
+  const int W = (L + 31) / 32, T = (L + 63) / 64;
+  if (T > 64) return MV_E_SHAPE;
+  const long long waves = (long long)B * L;
+  hipLaunchKernelGGL(mask_pack_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream, mask, mask_ndim, B, L, W, bits);
+  MV_CHECK_LAUNCH();
+  hipLaunchKernelGGL(mask_tileinfo_kernel, dim3(B * T), dim3(64), 0, stream, bits, B, L, W, T, tileinfo);
+  MV_CHECK_LAUNCH();
+  return MV_OK;
+}
+
+// =========================================================================================
+// MFMA kernels (bf16, dh = 64)
+// =========================================================================================
+struct AttnArgs {
+  const bf16_t* qkv; const bf16_t* ctx; const bf16_t* dctx; bf16_t* out; bf16_t* dqkv;
+  const uint32_t* bits; const uint8_t* info; float* lse; const float* lse_in; const float* delta;
+  int B, L, A, H, W, T;
+  float scale;
+  unsigned bytes_qkv, bytes_ctx;
+};
+
+// dual-use LDS image of a [64 rows][64 x bf16] tile: 128-B rows, 16-B chunk index XORed with f(row)
+__device__ __forceinline__ int att_f(int r) { return (((r >> 1) & 1) << 2) | ((r >> 2) & 3); }
+__device__ __forceinline__ int att_off(int r, int ch) { return r * 128 + ((ch ^ att_f(r)) << 4); }
+
+// rows of a 32x32 accumulator: element `reg` of lane-half h is row (reg&3) + 8*(reg>>2) + 4*h
+__device__ __forceinline__ int acc_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
+
+// stage one [64][64] tile (rows row0.. of a [*, ld] bf16 matrix starting at column col0) into regs
+__device__ __forceinline__ void tile_load(u32x4 (&reg)[2], __amdgpu_buffer_rsrc_t rs, unsigned bytes, size_t rowbase,
+                                          int row0, int nrows, int ld, int col0, int tid) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int idx = tid + 256 * i;
+    const int r = idx >> 3, ch = idx & 7;
+    const bool ok = (row0 + r) < nrows;
+    const unsigned off = (unsigned)(((rowbase + row0 + r) * (size_t)ld + col0 + ch * 8) * 2);
+    reg[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? off : bytes, 0, 0);
+  }
+}
+__device__ __forceinline__ void tile_store(const u32x4 (&reg)[2], char* tile, int tid) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int idx = tid + 256 * i;
+    *(u32x4*)(tile + att_off(idx >> 3, idx & 7)) = reg[i];
+  }
+}
+// row-read fragment  X[idx = base + (lane&31)][k = 16*s + 8*h + j]
+__device__ __forceinline__ bf16x8 frag_row(const char* tile, int base, int s, int l31, int h) {
+  return *(const bf16x8*)(tile + att_off(base + l31, 2 * s + h));
+}
+// transposed fragment  A[row = cbase + (lane&31)][k = tile row rb + 8*(j>>2) + 4*h + (j&3)]
+__device__ __forceinline__ bf16x8 frag_tr(const char* tile, int cbase, int rb, int lane) {
+  const int li = lane & 15, g = lane >> 4, h = g >> 1;
+  const int col = cbase + 16 * (g & 1) + 4 * (li & 3);
+  const int r = rb + 4 * h + (li >> 2);
+  const int sub = (li & 1) * 8;
+  bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((MV_LDS bf16x4*)(tile + att_off(r, col >> 3) + sub));
+  bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((MV_LDS bf16x4*)(tile + att_off(r + 8, col >> 3) + sub));
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+__device__ __forceinline__ bf16x8 pack8(const f32x16& v, int s2) {
+  bf16x8 r;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) r[j] = (bf16_t)v[8 * s2 + j];
+  return r;
+}
+__device__ __forceinline__ bf16x8 load_rowfrag_global(__amdgpu_buffer_rsrc_t rs, unsigned bytes, size_t row, bool ok, int ld,
+                                                      int col) {
+  const unsigned off = (unsigned)((row * (size_t)ld + col) * 2);
+  u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? off : bytes, 0, 0);
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+// block-uniform: is K/Q tile `t` needed by the 128-row block starting at row tile `ta` (and ta+1)?
+__device__ __forceinline__ bool tile_needed_q(const uint8_t* info, int b, int T, int ta, int t) {
+  bool need = info[((size_t)b * T + ta) * T + t] != 0;
+  if (ta + 1 < T) need |= info[((size_t)b * T + ta + 1) * T + t] != 0;
+  return need;
+}
+__device__ __forceinline__ bool tile_needed_k(const uint8_t* info, int b, int T, int ka, int t) {
+  bool need = info[((size_t)b * T + t) * T + ka] != 0;
+  if (ka + 1 < T) need |= info[((size_t)b * T + t) * T + ka + 1] != 0;
+  return need;
+}
+
+// ---- forward --------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void attn_fwd_mfma_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 stages x (K 8 KiB + V 8 KiB)
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, h = lane >> 5;
+  const int head = blockIdx.y, b = blockIdx.z;
+  const int L = a.L, H = a.H, ld = 3 * a.H, T = a.T;
+  const int qb0 = blockIdx.x * 128, q0 = qb0 + wid * 32, q = q0 + l31;
+  const bool wave_on = q0 < L, q_ok = q < L;
+  const size_t rowbase = (size_t)b * L;
+  __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.qkv, 0, a.bytes_qkv, 0x00020000);
+
+  bf16x8 qf[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) qf[s] = load_rowfrag_global(rs, a.bytes_qkv, rowbase + q, q_ok, ld, head * 64 + 16 * s + 8 * h);
+
+  const float c2 = a.scale * LOG2E;
+  float m2 = -INFINITY, lsum = 0.f;
+  f32x16 o[2];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { o[0][i] = 0.f; o[1][i] = 0.f; }
+
+  const int nkt = (L + 63) / 64;
+  const int ta = qb0 >> 6;
+  int cur = 0;
+  while (cur < nkt && !tile_needed_q(a.info, b, T, ta, cur)) ++cur;
+  u32x4 rk[2], rv[2];
+  if (cur < nkt) {
+    tile_load(rk, rs, a.bytes_qkv, rowbase, cur * 64, L, ld, H + head * 64, tid);
+    tile_load(rv, rs, a.bytes_qkv, rowbase, cur * 64, L, ld, 2 * H + head * 64, tid);
+    tile_store(rk, smem, tid);
+    tile_store(rv, smem + 8192, tid);
+  }
+  __syncthreads();
+  int buf = 0;
+  const uint32_t* myw = a.bits + (rowbase + (q_ok ? q : 0)) * a.W;
+  while (cur < nkt) {
+    int nxt = cur + 1;
+    while (nxt < nkt && !tile_needed_q(a.info, b, T, ta, nxt)) ++nxt;
+    if (nxt < nkt) {
+      tile_load(rk, rs, a.bytes_qkv, rowbase, nxt * 64, L, ld, H + head * 64, tid);
+      tile_load(rv, rs, a.bytes_qkv, rowbase, nxt * 64, L, ld, 2 * H + head * 64, tid);
+    }
+    const char* tK = smem + buf * 16384;
+    const char* tV = tK + 8192;
+    const int cls = wave_on ? a.info[((size_t)b * T + (q0 >> 6)) * T + cur] : 0;
+    if (wave_on && cls != 0) {
+      const int k0 = cur * 64;
+      f32x16 st[2];
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) st[kk][i] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+          st[kk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(tK, 32 * kk, s, l31, h), qf[s], st[kk], 0, 0, 0);
+      }
+      const bool tail = (k0 + 64 > L);
+      float mx = -INFINITY;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        uint32_t w = 0xffffffffu;
+        if (cls != 1) { const int wi = (k0 >> 5) + kk; w = (q_ok && wi < a.W) ? myw[wi] : 0xffffffffu; }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int kr = acc_row(r, h);
+          float v = st[kk][r] * c2;
+          if (cls != 1) v += ((w >> kr) & 1u) ? 0.f : MASK_ADD * LOG2E;
+          if (tail && (k0 + 32 * kk + kr >= L)) v = -INFINITY;
+          st[kk][r] = v;
+          mx = fmaxf(mx, v);
+        }
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float mn = fmaxf(m2, mx);
+      const float alpha = exp2f(m2 - mn);
+      m2 = mn;
+      float ps = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { const float pv = exp2f(st[kk][r] - mn); st[kk][r] = pv; ps += pv; }
+      lsum = lsum * alpha + ps;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const bf16x8 pf = pack8(st[kk], s2);
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt)
+            o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(tV, 32 * dt, 32 * kk + 16 * s2, lane), pf, o[dt], 0, 0, 0);
+        }
+    }
+    if (nxt < nkt) {
+      tile_store(rk, smem + (buf ^ 1) * 16384, tid);
+      tile_store(rv, smem + (buf ^ 1) * 16384 + 8192, tid);
+    }
+    __syncthreads();
+    buf ^= 1;
+    cur = nxt;
+  }
+  if (!q_ok) return;
+  const float ltot = lsum + __shfl_xor(lsum, 32, 64);
+  const float inv = 1.0f / ltot;
+  bf16_t* orow = a.out + (rowbase + q) * (size_t)H + head * 64;
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      bf16x4 v = {(bf16_t)(o[dt][4 * g] * inv), (bf16_t)(o[dt][4 * g + 1] * inv), (bf16_t)(o[dt][4 * g + 2] * inv),
+                  (bf16_t)(o[dt][4 * g + 3] * inv)};
+      *(bf16x4*)(orow + 32 * dt + 8 * g + 4 * h) = v;
+    }
+  if (h == 0) a.lse[((size_t)b * a.A + head) * L + q] = (m2 + log2f(ltot)) * LN2;
+}
+
+// ---- backward: dQ ----------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_mfma_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, h = lane >> 5;
+  const int head = blockIdx.y, b = blockIdx.z;
+  const int L = a.L, H = a.H, ld = 3 * a.H, T = a.T;
+  const int qb0 = blockIdx.x * 128, q0 = qb0 + wid * 32, q = q0 + l31;
+  const bool wave_on = q0 < L, q_ok = q < L;
+  const size_t rowbase = (size_t)b * L;
+  __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.qkv, 0, a.bytes_qkv, 0x00020000);
+  __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc((void*)a.dctx, 0, a.bytes_ctx, 0x00020000);
+
+  bf16x8 qf[4], dof[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    qf[s] = load_rowfrag_global(rs, a.bytes_qkv, rowbase + q, q_ok, ld, head * 64 + 16 * s + 8 * h);
+    dof[s] = load_rowfrag_global(rsd, a.bytes_ctx, rowbase + q, q_ok, H, head * 64 + 16 * s + 8 * h);
+  }
+  const size_t sidx = ((size_t)b * a.A + head) * L + (q_ok ? q : 0);
+  const float lse2 = q_ok ? a.lse_in[sidx] * LOG2E : INFINITY;
+  const float dlt = q_ok ? a.delta[sidx] : 0.f;
+  const float c2 = a.scale * LOG2E;
+  f32x16 dq[2];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { dq[0][i] = 0.f; dq[1][i] = 0.f; }
+
+  const int nkt = (L + 63) / 64;
+  const int ta = qb0 >> 6;
+  int cur = 0;
+  while (cur < nkt && !tile_needed_q(a.info, b, T, ta, cur)) ++cur;
+  u32x4 rk[2], rv[2];
+  if (cur < nkt) {
+    tile_load(rk, rs, a.bytes_qkv, rowbase, cur * 64, L, ld, H + head * 64, tid);
+    tile_load(rv, rs, a.bytes_qkv, rowbase, cur * 64, L, ld, 2 * H + head * 64, tid);
+    tile_store(rk, smem, tid);
+    tile_store(rv, smem + 8192, tid);
+  }
+  __syncthreads();
+  int buf = 0;
+  const uint32_t* myw = a.bits + (rowbase + (q_ok ? q : 0)) * a.W;
+  while (cur < nkt) {
+    int nxt = cur + 1;
+    while (nxt < nkt && !tile_needed_q(a.info, b, T, ta, nxt)) ++nxt;
+    if (nxt < nkt) {
+      tile_load(rk, rs, a.bytes_qkv, rowbase, nxt * 64, L, ld, H + head * 64, tid);
+      tile_load(rv, rs, a.bytes_qkv, rowbase, nxt * 64, L, ld, 2 * H + head * 64, tid);
+    }
+    const char* tK = smem + buf * 16384;
+    const char* tV = tK + 8192;
+    const int cls = wave_on ? a.info[((size_t)b * T + (q0 >> 6)) * T + cur] : 0;
+    if (wave_on && cls != 0) {
+      const int k0 = cur * 64;
+      const bool tail = (k0 + 64 > L);
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        f32x16 st, dp;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { st[i] = 0.f; dp[i] = 0.f; }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(tK, 32 * kk, s, l31, h), qf[s], st, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(tV, 32 * kk, s, l31, h), dof[s], dp, 0, 0, 0);
+        }
+        uint32_t w = 0xffffffffu;
+        if (cls != 1) { const int wi = (k0 >> 5) + kk; w = (q_ok && wi < a.W) ? myw[wi] : 0xffffffffu; }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int kr = acc_row(r, h);
+          float v = st[r] * c2;
+          if (cls != 1) v += ((w >> kr) & 1u) ? 0.f : MASK_ADD * LOG2E;
+          float pv = exp2f(v - lse2);
+          if (tail && (k0 + 32 * kk + kr >= L)) pv = 0.f;
+          st[r] = pv * (dp[r] - dlt) * a.scale;
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const bf16x8 dsf = pack8(st, s2);
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt)
+            dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(tK, 32 * dt, 32 * kk + 16 * s2, lane), dsf, dq[dt], 0, 0, 0);
+        }
+      }
+    }
+    if (nxt < nkt) {
+      tile_store(rk, smem + (buf ^ 1) * 16384, tid);
+      tile_store(rv, smem + (buf ^ 1) * 16384 + 8192, tid);
+    }
+    __syncthreads();
+    buf ^= 1;
+    cur = nxt;
+  }
+  if (!q_ok) return;
+  bf16_t* orow = a.dqkv + (rowbase + q) * (size_t)ld + head * 64;
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      bf16x4 v = {(bf16_t)dq[dt][4 * g], (bf16_t)dq[dt][4 * g + 1], (bf16_t)dq[dt][4 * g + 2], (bf16_t)dq[dt][4 * g + 3]};
+      *(bf16x4*)(orow + 32 * dt + 8 * g + 4 * h) = v;
+    }
+}
+
+// ---- backward: dK, dV --------------------------------------------------------------------------
+// LDS stage layout: Q tile 8 KiB | dO tile 8 KiB | lse2[64] f32 | delta[64] f32 | words[64][4] u32
+#define KV_STAGE (8192 + 8192 + 256 + 256 + 1024)
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_mfma_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, h = lane >> 5;
+  const int head = blockIdx.y, b = blockIdx.z;
+  const int L = a.L, H = a.H, ld = 3 * a.H, T = a.T;
+  const int kb0 = blockIdx.x * 128, k0w = kb0 + wid * 32, key = k0w + l31;
+  const bool wave_on = k0w < L, k_ok = key < L;
+  const size_t rowbase = (size_t)b * L;
+  __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.qkv, 0, a.bytes_qkv, 0x00020000);
+  __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc((void*)a.dctx, 0, a.bytes_ctx, 0x00020000);
+
+  bf16x8 kf[4], vf[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    kf[s] = load_rowfrag_global(rs, a.bytes_qkv, rowbase + key, k_ok, ld, H + head * 64 + 16 * s + 8 * h);
+    vf[s] = load_rowfrag_global(rs, a.bytes_qkv, rowbase + key, k_ok, ld, 2 * H + head * 64 + 16 * s + 8 * h);
+  }
+  const float c2 = a.scale * LOG2E;
+  f32x16 dk[2], dv[2];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { dk[0][i] = 0.f; dk[1][i] = 0.f; dv[0][i] = 0.f; dv[1][i] = 0.f; }
+
+  const int nqt = (L + 63) / 64;
+  const int ka = kb0 >> 6;
+  const int kw0 = kb0 >> 5;           // first of the block's 4 mask words
+  const size_t sbase = ((size_t)b * a.A + head) * L;
+
+  u32x4 rq[2], rd[2];
+  float r_lse = 0.f, r_dl = 0.f;
+  uint32_t r_w = 0;
+  auto stage_load_all = [&](int t) {
+    tile_load(rq, rs, a.bytes_qkv, rowbase, t * 64, L, ld, head * 64, tid);
+    tile_load(rd, rsd, a.bytes_ctx, rowbase, t * 64, L, H, head * 64, tid);
+    const int qi = t * 64 + (tid & 63);
+    if (tid < 64) r_lse = (qi < L) ? a.lse_in[sbase + qi] * LOG2E : INFINITY;
+    else if (tid < 128) r_dl = (qi < L) ? a.delta[sbase + qi] : 0.f;
+    {
+      const int qq = t * 64 + (tid >> 2), wi = kw0 + (tid & 3);
+      r_w = (qq < L && wi < a.W) ? a.bits[(rowbase + qq) * a.W + wi] : 0u;
+    }
+  };
+  auto stage_store_all = [&](char* st) {
+    tile_store(rq, st, tid);
+    tile_store(rd, st + 8192, tid);
+    if (tid < 64) ((float*)(st + 16384))[tid] = r_lse;
+    else if (tid < 128) ((float*)(st + 16384 + 256))[tid - 64] = r_dl;
+    ((uint32_t*)(st + 16384 + 512))[tid] = r_w;
+  };
+
+  int cur = 0;
+  while (cur < nqt && !tile_needed_k(a.info, b, T, ka, cur)) ++cur;
+  if (cur < nqt) { stage_load_all(cur); stage_store_all(smem); }
+  __syncthreads();
+  int buf = 0;
+  while (cur < nqt) {
+    int nxt = cur + 1;
+    while (nxt < nqt && !tile_needed_k(a.info, b, T, ka, nxt)) ++nxt;
+    if (nxt < nqt) stage_load_all(nxt);
+    const char* st = smem + buf * KV_STAGE;
+    const char* tQ = st;
+    const char* tD = st + 8192;
+    const float* s_lse = (const float*)(st + 16384);
+    const float* s_dl = (const float*)(st + 16384 + 256);
+    const uint32_t* s_w = (const uint32_t*)(st + 16384 + 512);
+    const int cls = wave_on ? a.info[((size_t)b * T + cur) * T + (k0w >> 6)] : 0;
+    if (wave_on && cls != 0) {
+#pragma unroll
+      for (int qq = 0; qq < 2; ++qq) {
+        f32x16 sc, dp;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { sc[i] = 0.f; dp[i] = 0.f; }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(tQ, 32 * qq, s, l31, h), kf[s], sc, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(tD, 32 * qq, s, l31, h), vf[s], dp, 0, 0, 0);
+        }
+        f32x16 pv;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int qr0 = 32 * qq + 8 * g + 4 * h;      // 4 consecutive query rows of this register quad
+          const f32x4 l4 = *(const f32x4*)(s_lse + qr0);
+          const f32x4 d4 = *(const f32x4*)(s_dl + qr0);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int r = 4 * g + e;
+            float v = sc[r] * c2;
+            if (cls != 1) {
+              const uint32_t w = s_w[(qr0 + e) * 4 + wid];
+              v += ((w >> l31) & 1u) ? 0.f : MASK_ADD * LOG2E;
+            }
+            const float p = exp2f(v - l4[e]);     // rows q >= L carry lse = +inf -> p = 0
+            pv[r] = p;
+            sc[r] = p * (dp[r] - d4[e]) * a.scale;
+          }
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const bf16x8 pf = pack8(pv, s2);
+          const bf16x8 dsf = pack8(sc, s2);
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt) {
+            dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(tD, 32 * dt, 32 * qq + 16 * s2, lane), pf, dv[dt], 0, 0, 0);
+            dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(tQ, 32 * dt, 32 * qq + 16 * s2, lane), dsf, dk[dt], 0, 0, 0);
+          }
+        }
+      }
+    }
+    if (nxt < nqt) stage_store_all(smem + (buf ^ 1) * KV_STAGE);
+    __syncthreads();
+    buf ^= 1;
+    cur = nxt;
+  }
+  if (!k_ok) return;
+  bf16_t* krow = a.dqkv + (rowbase + key) * (size_t)ld + H + head * 64;
+  bf16_t* vrow = krow + H;
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      bf16x4 v1 = {(bf16_t)dk[dt][4 * g], (bf16_t)dk[dt][4 * g + 1], (bf16_t)dk[dt][4 * g + 2], (bf16_t)dk[dt][4 * g + 3]};
+      bf16x4 v2 = {(bf16_t)dv[dt][4 * g], (bf16_t)dv[dt][4 * g + 1], (bf16_t)dv[dt][4 * g + 2], (bf16_t)dv[dt][4 * g + 3]};
+      *(bf16x4*)(krow + 32 * dt + 8 * g + 4 * h) = v1;
+      *(bf16x4*)(vrow + 32 * dt + 8 * g + 4 * h) = v2;
+    }
+}
+
+// =========================================================================================
+// plain VALU kernels (any dtype, dh <= 128): exact-fp32 path and cross-check
+// =========================================================================================
+template <typename T>
+struct SArgs {
+  const T* qkv; const T* ctx; const T* dctx; T* out; T* dqkv;
+  const uint32_t* bits; float* lse; const float* lse_in; float* delta;
+  int B, L, A, H, W, dh;
+  float scale;
+};
+
+// delta[b,h,q] = sum_d dctx*ctx   (one wave per (b,q,h))
+template <typename T>
+__global__ void attn_delta_kernel(const T* __restrict__ ctx, const T* __restrict__ dctx, float* __restrict__ delta, int B, int L,
+                                  int A, int H, int dh) {
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (wave >= B * L * A) return;
+  const int hd = wave % A, row = wave / A;   // row = b*L + q
+  const T* c = ctx + (size_t)row * H + hd * dh;
+  const T* d = dctx + (size_t)row * H + hd * dh;
+  float s = 0.f;
+  for (int i = lane; i < dh; i += 64) s += ldf<T>(c + i) * ldf<T>(d + i);
+  s = wave_sum(s);
+  if (lane == 0) {
+    const int b = row / L, q = row - b * L;
+    delta[((size_t)b * A + hd) * L + q] = s;
+  }
+}
+
+// one wave per (b, h, q)
+template <typename T>
+__global__ __launch_bounds__(256) void attn_fwd_simple_kernel(SArgs<T> a) {
+  __shared__ float sq[4][128];
+  __shared__ float sp[4][64];
+  const int lane = threadIdx.x & 63, wl = threadIdx.x >> 6;
+  const long long wave = (long long)blockIdx.x * 4 + wl;
+  if (wave >= (long long)a.B * a.A * a.L) return;
+  const int q = (int)(wave % a.L);
+  const int hd = (int)((wave / a.L) % a.A);
+  const int b = (int)(wave / ((long long)a.L * a.A));
+  const int ld = 3 * a.H, dh = a.dh;
+  const size_t rb = (size_t)b * a.L;
+  const T* qp = a.qkv + (rb + q) * ld + hd * dh;
+  for (int i = lane; i < dh; i += 64) sq[wl][i] = ldf<T>(qp + i);
+  float m = -INFINITY, l = 0.f, o0 = 0.f, o1 = 0.f;
+  const uint32_t* wrow = a.bits + (rb + q) * a.W;
+  for (int k0 = 0; k0 < a.L; k0 += 64) {
+    const int k = k0 + lane;
+    float s = -INFINITY;
+    if (k < a.L) {
+      const T* kp = a.qkv + (rb + k) * ld + a.H + hd * dh;
+      float acc = 0.f;
+      for (int i = 0; i < dh; ++i) acc = fmaf(sq[wl][i], ldf<T>(kp + i), acc);
+      s = acc * a.scale + (((wrow[k >> 5] >> (k & 31)) & 1u) ? 0.f : MASK_ADD);
+    }
+    const float mx = wave_max(s);
+    const float mn = fmaxf(m, mx);
+    const float alpha = expf(m - mn);
+    const float p = (k < a.L) ? expf(s - mn) : 0.f;
+    l = l * alpha + wave_sum(p);
+    m = mn;
+    sp[wl][lane] = p;
+    o0 *= alpha; o1 *= alpha;
+    const int kn = min(64, a.L - k0);
+    for (int j = 0; j < kn; ++j) {
+      const T* vp = a.qkv + (rb + k0 + j) * ld + 2 * a.H + hd * dh;
+      const float pj = sp[wl][j];
+      if (lane < dh) o0 = fmaf(pj, ldf<T>(vp + lane), o0);
+      if (lane + 64 < dh) o1 = fmaf(pj, ldf<T>(vp + lane + 64), o1);
+    }
+  }
+  T* op = a.out + (rb + q) * a.H + hd * dh;
+  if (lane < dh) stf<T>(op + lane, o0 / l);
+  if (lane + 64 < dh) stf<T>(op + lane + 64, o1 / l);
+  if (lane == 0) a.lse[((size_t)b * a.A + hd) * a.L + q] = m + logf(l);
+}
+
+// dQ: one wave per (b,h,q)
+template <typename T>
+__global__ __launch_bounds__(256) void attn_bwd_dq_simple_kernel(SArgs<T> a) {
+  __shared__ float sq[4][128];
+  __shared__ float sdo[4][128];
+  __shared__ float sds[4][64];
+  const int lane = threadIdx.x & 63, wl = threadIdx.x >> 6;
+  const long long wave = (long long)blockIdx.x * 4 + wl;
+  if (wave >= (long long)a.B * a.A * a.L) return;
+  const int q = (int)(wave % a.L);
+  const int hd = (int)((wave / a.L) % a.A);
+  const int b = (int)(wave / ((long long)a.L * a.A));
+  const int ld = 3 * a.H, dh = a.dh;
+  const size_t rb = (size_t)b * a.L;
+  const T* qp = a.qkv + (rb + q) * ld + hd * dh;
+  const T* dop = a.dctx + (rb + q) * a.H + hd * dh;
+  for (int i = lane; i < dh; i += 64) { sq[wl][i] = ldf<T>(qp + i); sdo[wl][i] = ldf<T>(dop + i); }
+  const size_t si = ((size_t)b * a.A + hd) * a.L + q;
+  const float lse = a.lse_in[si], dl = a.delta[si];
+  const uint32_t* wrow = a.bits + (rb + q) * a.W;
+  float g0 = 0.f, g1 = 0.f;
+  for (int k0 = 0; k0 < a.L; k0 += 64) {
+    const int k = k0 + lane;
+    float ds = 0.f;
+    if (k < a.L) {
+      const T* kp = a.qkv + (rb + k) * ld + a.H + hd * dh;
+      const T* vp = kp + a.H;
+      float acc = 0.f, dp = 0.f;
+      for (int i = 0; i < dh; ++i) { acc = fmaf(sq[wl][i], ldf<T>(kp + i), acc); dp = fmaf(sdo[wl][i], ldf<T>(vp + i), dp); }
+      const float s = acc * a.scale + (((wrow[k >> 5] >> (k & 31)) & 1u) ? 0.f : MASK_ADD);
+      ds = expf(s - lse) * (dp - dl) * a.scale;
+    }
+    sds[wl][lane] = ds;
+    const int kn = min(64, a.L - k0);
+    for (int j = 0; j < kn; ++j) {
+      const T* kp = a.qkv + (rb + k0 + j) * ld + a.H + hd * dh;
+      const float dj = sds[wl][j];
+      if (lane < dh) g0 = fmaf(dj, ldf<T>(kp + lane), g0);
+      if (lane + 64 < dh) g1 = fmaf(dj, ldf<T>(kp + lane + 64), g1);
+    }
+  }
+  T* gp = a.dqkv + (rb + q) * ld + hd * dh;
+  if (lane < dh) stf<T>(gp + lane, g0);
+  if (lane + 64 < dh) stf<T>(gp + lane + 64, g1);
+}
+
+// dK, dV: one wave per (b,h,key)
+template <typename T>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_simple_kernel(SArgs<T> a) {
+  __shared__ float sk[4][128];
+  __shared__ float sv[4][128];
+  __shared__ float sds[4][64];
+  __shared__ float spp[4][64];
+  const int lane = threadIdx.x & 63, wl = threadIdx.x >> 6;
+  const long long wave = (long long)blockIdx.x * 4 + wl;
+  if (wave >= (long long)a.B * a.A * a.L) return;
+  const int k = (int)(wave % a.L);
+  const int hd = (int)((wave / a.L) % a.A);
+  const int b = (int)(wave / ((long long)a.L * a.A));
+  const int ld = 3 * a.H, dh = a.dh;
+  const size_t rb = (size_t)b * a.L;
+  const T* kp = a.qkv + (rb + k) * ld + a.H + hd * dh;
+  const T* vp = kp + a.H;
+  for (int i = lane; i < dh; i += 64) { sk[wl][i] = ldf<T>(kp + i); sv[wl][i] = ldf<T>(vp + i); }
+  float gk0 = 0.f, gk1 = 0.f, gv0 = 0.f, gv1 = 0.f;
+  const size_t sb = ((size_t)b * a.A + hd) * a.L;
+  for (int q0 = 0; q0 < a.L; q0 += 64) {
+    const int q = q0 + lane;
+    float ds = 0.f, p = 0.f;
+    if (q < a.L) {
+      const T* qp = a.qkv + (rb + q) * ld + hd * dh;
+      const T* dop = a.dctx + (rb + q) * a.H + hd * dh;
+      float acc = 0.f, dp = 0.f;
+      for (int i = 0; i < dh; ++i) { acc = fmaf(sk[wl][i], ldf<T>(qp + i), acc); dp = fmaf(sv[wl][i], ldf<T>(dop + i), dp); }
+      const uint32_t w = a.bits[(rb + q) * a.W + (k >> 5)];
+      const float s = acc * a.scale + (((w >> (k & 31)) & 1u) ? 0.f : MASK_ADD);
+      p = expf(s - a.lse_in[sb + q]);
+      ds = p * (dp - a.delta[sb + q]) * a.scale;
+    }
+    sds[wl][lane] = ds;
+    spp[wl][lane] = p;
+    const int qn = min(64, a.L - q0);
+    for (int j = 0; j < qn; ++j) {
+      const T* qp = a.qkv + (rb + q0 + j) * ld + hd * dh;
+      const T* dop = a.dctx + (rb + q0 + j) * a.H + hd * dh;
+      const float dj = sds[wl][j], pj = spp[wl][j];
+      if (lane < dh) { gk0 = fmaf(dj, ldf<T>(qp + lane), gk0); gv0 = fmaf(pj, ldf<T>(dop + lane), gv0); }
+      if (lane + 64 < dh) { gk1 = fmaf(dj, ldf<T>(qp + lane + 64), gk1); gv1 = fmaf(pj, ldf<T>(dop + lane + 64), gv1); }
+    }
+  }
+  T* gk = a.dqkv + (rb + k) * ld + a.H + hd * dh;
+  T* gv = gk + a.H;
+  if (lane < dh) { stf<T>(gk + lane, gk0); stf<T>(gv + lane, gv0); }
+  if (lane + 64 < dh) { stf<T>(gk + lane + 64, gk1); stf<T>(gv + lane + 64, gv1); }
+}
+
+// =========================================================================================
+// host
+// =========================================================================================
+template <typename T>
+static int launch_simple_fwd(const void* qkv, const uint32_t* bits, void* ctx, float* lse, int B, int L, int A, int dh,
+                             hipStream_t stream) {
+  SArgs<T> s{};
+  s.qkv = (const T*)qkv; s.out = (T*)ctx; s.bits = bits; s.lse = lse;
+  s.B = B; s.L = L; s.A = A; s.H = A * dh; s.W = (L + 31) / 32; s.dh = dh; s.scale = 1.0f / sqrtf((float)dh);
+  const long long waves = (long long)B * A * L;
+  hipLaunchKernelGGL(attn_fwd_simple_kernel<T>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream, s);
+  MV_CHECK_LAUNCH();
+  return MV_OK;
+}
+
+extern "C" int mv_attn_fwd(int dtype, const void* qkv, const uint32_t* bits, const uint8_t* tileinfo, void* ctx, float* lse,
+                           int B, int L, int A, int dh, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!qkv || !bits || !tileinfo || !ctx || !lse || B <= 0 || L <= 0 || A <= 0 || dh <= 0) return MV_E_ARG;
+  if (dtype != MV_F32 && dtype != MV_BF16) return MV_E_DTYPE;
+  const int H = A * dh;
+  if (dtype == MV_BF16 && g_mv_impl == 0) {
+    if (dh != 64) return MV_E_SHAPE;
+    const size_t bq = (size_t)B * L * 3 * H * 2;
+    if (bq >= 0x7fffffffULL || (((uintptr_t)qkv) & 15) || (((uintptr_t)ctx) & 7)) return MV_E_SHAPE;
+    AttnArgs a{};
+    a.qkv = (const bf16_t*)qkv; a.out = (bf16_t*)ctx; a.bits = bits; a.info = tileinfo; a.lse = lse;
+    a.B = B; a.L = L; a.A = A; a.H = H; a.W = (L + 31) / 32; a.T = (L + 63) / 64;
+    a.scale = 1.0f / sqrtf((float)dh);
+    a.bytes_qkv = (unsigned)bq;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)attn_fwd_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 32768); attr = true; }
+    hipLaunchKernelGGL(attn_fwd_mfma_kernel, dim3((L + 127) / 128, A, B), dim3(256), 32768, stream, a);
+    MV_CHECK_LAUNCH();
+    return MV_OK;
+  }
+  if (dh > 128) return MV_E_SHAPE;
+  return dtype == MV_F32 ? launch_simple_fwd<float>(qkv, bits, ctx, lse, B, L, A, dh, stream)
+                         : launch_simple_fwd<bf16_t>(qkv, bits, ctx, lse, B, L, A, dh, stream);
+}
+
+template <typename T>
+static int launch_simple_bwd(const void* qkv, const void* ctx, const void* dctx, const float* lse, const uint32_t* bits,
+                             void* dqkv, float* delta, int B, int L, int A, int dh, hipStream_t stream) {
+  SArgs<T> s{};
+  s.qkv = (const T*)qkv; s.ctx = (const T*)ctx; s.dctx = (const T*)dctx; s.dqkv = (T*)dqkv; s.bits = bits;
+  s.lse_in = lse; s.delta = delta;
+  s.B = B; s.L = L; s.A = A; s.H = A * dh; s.W = (L + 31) / 32; s.dh = dh; s.scale = 1.0f / sqrtf((float)dh);
+  const long long waves = (long long)B * A * L;
+  const unsigned blocks = (unsigned)((waves + 3) / 4);
+  hipLaunchKernelGGL(attn_delta_kernel<T>, dim3(blocks), dim3(256), 0, stream, s.ctx, s.dctx, delta, B, L, A, s.H, dh);
+  MV_CHECK_LAUNCH();
+  hipLaunchKernelGGL(attn_bwd_dq_simple_kernel<T>, dim3(blocks), dim3(256), 0, stream, s);
+  MV_CHECK_LAUNCH();
+  hipLaunchKernelGGL(attn_bwd_dkv_simple_kernel<T>, dim3(blocks), dim3(256), 0, stream, s);
+  MV_CHECK_LAUNCH();
+  return MV_OK;
+}
+
+extern "C" int mv_attn_bwd(int dtype, const void* qkv, const void* ctx, const void* dctx, const float* lse, const uint32_t* bits,
+                           const uint8_t* tileinfo, void* dqkv, float* delta, int B, int L, int A, int dh, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!qkv || !ctx || !dctx || !lse || !bits || !tileinfo || !dqkv || !delta || B <= 0 || L <= 0 || A <= 0 || dh <= 0)
+    return MV_E_ARG;
+  if (dtype != MV_F32 && dtype != MV_BF16) return MV_E_DTYPE;
+  const int H = A * dh;
+  if (dtype == MV_BF16 && g_mv_impl == 0) {
+    if (dh != 64) return MV_E_SHAPE;
+    const size_t bq = (size_t)B * L * 3 * H * 2, bc = (size_t)B * L * H * 2;
+    if (bq >= 0x7fffffffULL || (((uintptr_t)qkv) & 15) || (((uintptr_t)dctx) & 15) || (((uintptr_t)dqkv) & 7)) return MV_E_SHAPE;
+    const long long waves = (long long)B * A * L;
+    hipLaunchKernelGGL(attn_delta_kernel<bf16_t>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream, (const bf16_t*)ctx,
+                       (const bf16_t*)dctx, delta, B, L, A, H, dh);
+    MV_CHECK_LAUNCH();
+    AttnArgs a{};
+    a.qkv = (const bf16_t*)qkv; a.ctx = (const bf16_t*)ctx; a.dctx = (const bf16_t*)dctx; a.dqkv = (bf16_t*)dqkv;
+    a.bits = bits; a.info = tileinfo; a.lse_in = lse; a.delta = delta;
+    a.B = B; a.L = L; a.A = A; a.H = H; a.W = (L + 31) / 32; a.T = (L + 63) / 64;
+    a.scale = 1.0f / sqrtf((float)dh);
+    a.bytes_qkv = (unsigned)bq; a.bytes_ctx = (unsigned)bc;
+    static bool attr = false;
+    if (!attr) {
+      (void)hipFuncSetAttribute((const void*)attn_bwd_dq_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 32768);
+      (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * KV_STAGE);
+      attr = true;
+    }
+    dim3 grid((L + 127) / 128, A, B);
+    hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel, grid, dim3(256), 32768, stream, a);
+    MV_CHECK_LAUNCH();
+    hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel, grid, dim3(256), 2 * KV_STAGE, stream, a);
+    MV_CHECK_LAUNCH();
+    return MV_OK;
+  }
+  if (dh > 128) return MV_E_SHAPE;
+  return dtype == MV_F32 ? launch_simple_bwd<float>(qkv, ctx, dctx, lse, bits, dqkv, delta, B, L, A, dh, stream)
+                         : launch_simple_bwd<bf16_t>(qkv, ctx, dctx, lse, bits, dqkv, delta, B, L, A, dh, stream);
+}

@@ -1,0 +1,80 @@
+// Shared device helpers for the gfx950 kernels (wave64, MFMA, LDS).  gfx950 only: no
+// portability layers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+#include "../../include/medvill.h"
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+
+#define MV_LDS __attribute__((address_space(3)))
+
+extern int g_mv_impl;
+
+#define MV_CHECK_LAUNCH()                           \
+  do {                                              \
+    hipError_t e__ = hipGetLastError();             \
+    if (e__ != hipSuccess) return (int)e__;         \
+  } while (0)
+
+__device__ __forceinline__ float bf2f(bf16_t x) { return (float)x; }
+__device__ __forceinline__ bf16_t f2bf(float x) { return (bf16_t)x; }
+
+template <typename T> __device__ __forceinline__ float ldf(const T* p);
+template <> __device__ __forceinline__ float ldf<float>(const float* p) { return *p; }
+template <> __device__ __forceinline__ float ldf<bf16_t>(const bf16_t* p) { return (float)*p; }
+template <typename T> __device__ __forceinline__ void stf(T* p, float v);
+template <> __device__ __forceinline__ void stf<float>(float* p, float v) { *p = v; }
+template <> __device__ __forceinline__ void stf<bf16_t>(bf16_t* p, float v) { *p = (bf16_t)v; }
+
+// 4-wide vector access (pointer must be 4-element aligned)
+template <typename T> __device__ __forceinline__ f32x4 ld4(const T* p);
+template <> __device__ __forceinline__ f32x4 ld4<float>(const float* p) { return *(const f32x4*)p; }
+template <> __device__ __forceinline__ f32x4 ld4<bf16_t>(const bf16_t* p) {
+  bf16x4 v = *(const bf16x4*)p;
+  f32x4 r = {(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+  return r;
+}
+template <typename T> __device__ __forceinline__ void st4(T* p, f32x4 v);
+template <> __device__ __forceinline__ void st4<float>(float* p, f32x4 v) { *(f32x4*)p = v; }
+template <> __device__ __forceinline__ void st4<bf16_t>(bf16_t* p, f32x4 v) {
+  bf16x4 r = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+  *(bf16x4*)p = r;
+}
+
+// runtime-typed scalar access (dtype: MV_F32 / MV_BF16)
+__device__ __forceinline__ float ld_any(const void* p, size_t i, int dtype) {
+  return dtype == MV_F32 ? ((const float*)p)[i] : (float)((const bf16_t*)p)[i];
+}
+__device__ __forceinline__ void st_any(void* p, size_t i, int dtype, float v) {
+  if (dtype == MV_F32) ((float*)p)[i] = v; else ((bf16_t*)p)[i] = (bf16_t)v;
+}
+
+__device__ __forceinline__ float gelu_erf(float z) { return z * 0.5f * (1.0f + erff(z * 0.70710678118654752440f)); }
+// d/dz [ z * Phi(z) ] = Phi(z) + z * phi(z)
+__device__ __forceinline__ float dgelu_erf(float z) {
+  const float cdf = 0.5f * (1.0f + erff(z * 0.70710678118654752440f));
+  const float pdf = 0.39894228040143267794f * __expf(-0.5f * z * z);
+  return cdf + z * pdf;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+static inline int mv_dtype_size(int dt) { return dt == MV_F32 ? 4 : 2; }

@@ -1,0 +1,688 @@
+// HBM-bound row kernels of the CXRBERT hot path on gfx950: LayerNorm fwd/bwd, fused
+// sequence-assembly + embedding + LayerNorm fwd/bwd, fused cross-entropy (+argmax, +gradient),
+// row gather/scatter, column sums, casts and the fused HF-AdamW step.
+// All of them are one-wave-per-row (64 lanes x 4-element vectors) streaming kernels: the
+// roofline that bounds them is HBM bandwidth, so every operand is read once, 8/16 bytes per
+// lane, and every reduction stays in registers / DPP shuffles.
+#include "mv_common.h"
+
+// compile-time number of 256-column chunks per row (keeps the per-row register arrays out of scratch)
+#define NC_DISPATCH(H_, CALL)                                  \
+  do {                                                         \
+    if ((H_) <= 256) { CALL(1); }                              \
+    else if ((H_) <= 768) { CALL(3); }                         \
+    else if ((H_) <= 1024) { CALL(4); }                        \
+    else { CALL(8); }                                          \
+  } while (0)
+#define MV_MAX_H 2048
+
+// =========================================================================================
+// LayerNorm
+// =========================================================================================
+// y = (x-mean)*rstd*g+b ; one wave per row, H % 4 == 0, H <= 2048
+template <typename TX, typename TY, int NC>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const TX* __restrict__ x, const float* __restrict__ g,
+                                                     const float* __restrict__ bta, TY* __restrict__ y, float* __restrict__ mean,
+                                                     float* __restrict__ rstd, int M, int H, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const TX* xr = x + (size_t)row * H;
+  f32x4 v[NC];
+  float s = 0.f;
+#pragma unroll
+  for (int n = 0; n < NC; ++n) {
+    const int c = lane * 4 + 256 * n;
+    v[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (c < H) { v[n] = ld4<TX>(xr + c); s += v[n][0] + v[n][1] + v[n][2] + v[n][3]; }
+  }
+  const float mu = wave_sum(s) / (float)H;
+  float q = 0.f;
+#pragma unroll
+  for (int n = 0; n < NC; ++n) {
+    if (lane * 4 + 256 * n < H) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const float d = v[n][e] - mu; q += d * d; }
+    }
+  }
+  const float var = wave_sum(q) / (float)H;
+  const float rs = 1.0f / sqrtf(var + eps);
+  TY* yr = y + (size_t)row * H;
+#pragma unroll
+  for (int n = 0; n < NC; ++n) {
+    const int c = lane * 4 + 256 * n;
+    if (c < H) {
+      const f32x4 gg = *(const f32x4*)(g + c), bb = *(const f32x4*)(bta + c);
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (v[n][e] - mu) * rs * gg[e] + bb[e];
+      st4<TY>(yr + c, o);
+    }
+  }
+  if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+}
+
+// dx = rstd*(g*dy - mean(g*dy) - xhat*mean(g*dy*xhat)); dgamma += dy*xhat; dbeta += dy; colsum += dx
+template <typename TX, typename TD, int NC>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const TD* __restrict__ dy, const TX* __restrict__ x,
+                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                     const float* __restrict__ g, TD* __restrict__ dx, float* __restrict__ dgamma,
+                                                     float* __restrict__ dbeta, float* __restrict__ colsum, int M, int H) {
+  __shared__ float red[3][4][260];
+  const int lane = threadIdx.x & 63, wl = threadIdx.x >> 6;
+  f32x4 ag[NC], ab[NC], ac[NC];
+#pragma unroll
+  for (int i = 0; i < NC; ++i) { ag[i] = (f32x4){0, 0, 0, 0}; ab[i] = ag[i]; ac[i] = ag[i]; }
+  for (int row = blockIdx.x * 4 + wl; row < M; row += gridDim.x * 4) {
+    const TD* dyr = dy + (size_t)row * H;
+    const TX* xr = x + (size_t)row * H;
+    const float mu = mean[row], rs = rstd[row];
+    f32x4 xh[NC], gd[NC];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int n = 0; n < NC; ++n) {
+      const int c = lane * 4 + 256 * n;
+      xh[n] = (f32x4){0, 0, 0, 0}; gd[n] = xh[n];
+      if (c < H) {
+        const f32x4 d = ld4<TD>(dyr + c), xv = ld4<TX>(xr + c), gg = *(const f32x4*)(g + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float h_ = (xv[e] - mu) * rs;
+          const float gde = gg[e] * d[e];
+          xh[n][e] = h_; gd[n][e] = gde;
+          s1 += gde; s2 += gde * h_;
+          ag[n][e] += d[e] * h_;
+          ab[n][e] += d[e];
+        }
+      }
+    }
+    s1 = wave_sum(s1) / (float)H;
+    s2 = wave_sum(s2) / (float)H;
+    TD* dxr = dx + (size_t)row * H;
+#pragma unroll
+    for (int n = 0; n < NC; ++n) {
+      const int c = lane * 4 + 256 * n;
+      if (c < H) {
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { o[e] = rs * (gd[n][e] - s1 - xh[n][e] * s2); ac[n][e] += o[e]; }
+        st4<TD>(dxr + c, o);
+      }
+    }
+  }
+  // cross-wave reduction of the column accumulators, one 256-column chunk at a time
+#pragma unroll
+  for (int n = 0; n < NC; ++n) {
+    const int c0 = 256 * n;
+    if (c0 >= H) break;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { red[0][wl][lane * 4 + e] = ag[n][e]; red[1][wl][lane * 4 + e] = ab[n][e]; red[2][wl][lane * 4 + e] = ac[n][e]; }
+    __syncthreads();
+    const int col = c0 + threadIdx.x;
+    if (col < H) {
+      const int t = threadIdx.x;
+      atomicAdd(dgamma + col, red[0][0][t] + red[0][1][t] + red[0][2][t] + red[0][3][t]);
+      atomicAdd(dbeta + col, red[1][0][t] + red[1][1][t] + red[1][2][t] + red[1][3][t]);
+      if (colsum) atomicAdd(colsum + col, red[2][0][t] + red[2][1][t] + red[2][2][t] + red[2][3][t]);
+    }
+    __syncthreads();
+  }
+}
+
+extern "C" int mv_layernorm_fwd(int dtype, const void* x, int x_dtype, const float* gamma, const float* beta, void* y, float* mean,
+                                float* rstd, int M, int H, float eps, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!x || !gamma || !beta || !y || !mean || !rstd || M <= 0 || H <= 0) return MV_E_ARG;
+  if ((H & 3) || H > MV_MAX_H) return MV_E_SHAPE;
+  dim3 grid((M + 3) / 4), block(256);
+#define LNF(NC_) hipLaunchKernelGGL((ln_fwd_kernel<TX_, TY_, NC_>), grid, block, 0, stream, (const TX_*)x, gamma, beta, (TY_*)y, mean, rstd, M, H, eps)
+  if (dtype == MV_F32 && x_dtype == MV_F32) { typedef float TX_; typedef float TY_; NC_DISPATCH(H, LNF); }
+  else if (dtype == MV_BF16 && x_dtype == MV_F32) { typedef float TX_; typedef bf16_t TY_; NC_DISPATCH(H, LNF); }
+  else if (dtype == MV_BF16 && x_dtype == MV_BF16) { typedef bf16_t TX_; typedef bf16_t TY_; NC_DISPATCH(H, LNF); }
+  else return MV_E_DTYPE;
+#undef LNF
+  MV_CHECK_LAUNCH();
+  return MV_OK;
+}
+
+extern "C" int mv_layernorm_bwd(int dtype, const void* dy, const void* x, int x_dtype, const float* mean, const float* rstd,
+                                const float* gamma, void* dx, float* dgamma, float* dbeta, float* colsum, int M, int H,
+                                void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!dy || !x || !mean || !rstd || !gamma || !dx || !dgamma || !dbeta || M <= 0 || H <= 0) return MV_E_ARG;
+  if ((H & 3) || H > MV_MAX_H) return MV_E_SHAPE;
+  int blocks = (M + 3) / 4;
+  if (blocks > 1024) blocks = 1024;
+  dim3 grid(blocks), block(256);
+#define LNB(NC_) hipLaunchKernelGGL((ln_bwd_kernel<TX_, TD_, NC_>), grid, block, 0, stream, (const TD_*)dy, (const TX_*)x, mean, rstd, gamma, (TD_*)dx, dgamma, dbeta, colsum, M, H)
+  if (dtype == MV_F32 && x_dtype == MV_F32) { typedef float TX_; typedef float TD_; NC_DISPATCH(H, LNB); }
+  else if (dtype == MV_BF16 && x_dtype == MV_F32) { typedef float TX_; typedef bf16_t TD_; NC_DISPATCH(H, LNB); }
+  else if (dtype == MV_BF16 && x_dtype == MV_BF16) { typedef bf16_t TX_; typedef bf16_t TD_; NC_DISPATCH(H, LNB); }
+  else return MV_E_DTYPE;
+#undef LNB
+  MV_CHECK_LAUNCH();
+  return MV_OK;
+}
+
+// =========================================================================================
+// sequence assembly + embeddings + LayerNorm  (cxrbert_origin.py:114-125, :22-35)
+// =========================================================================================
+struct EmbArgs {
+  const int64_t* cls_tok; const int64_t* txt; const int64_t* segment; const int64_t* img_pos; const int64_t* sep_tok;
+  int B, N, T, H, V, maxpos, L;
+};
+// position l of sample b -> (token id or -1 for an image region, position id, type id, region index)
+__device__ __forceinline__ void emb_decode(const EmbArgs& a, int b, int l, int& tok, int& pos, int& typ, int& reg) {
+  reg = -1;
+  if (l == 0) { tok = (int)a.cls_tok[b]; pos = 0; typ = 0; }
+  else if (l <= a.N) { tok = -1; reg = l - 1; pos = (int)a.img_pos[(size_t)b * a.N + reg]; typ = 0; }
+  else if (l == a.N + 1) { tok = (int)a.sep_tok[b]; pos = 0; typ = 0; }
+  else { const int t = l - a.N - 2; tok = (int)a.txt[(size_t)b * a.T + t]; pos = t; typ = (int)a.segment[(size_t)b * a.T + t]; }
+  // clamp so that a bad id can never fault (HF would raise an index error on the host)
+  if (tok >= a.V) tok = a.V - 1;
+  if (tok < -1) tok = 0;
+  pos = pos < 0 ? 0 : (pos >= a.maxpos ? a.maxpos - 1 : pos);
+  typ = typ < 0 ? 0 : (typ > 1 ? 1 : typ);
+}
+
+template <typename T, int NC>
+__global__ __launch_bounds__(256) void embed_fwd_kernel(EmbArgs a, const T* __restrict__ imgproj, const T* __restrict__ E,
+                                                        const T* __restrict__ P, const T* __restrict__ Ty,
+                                                        const float* __restrict__ g, const float* __restrict__ bta,
+                                                        T* __restrict__ x0, float* __restrict__ pre, float* __restrict__ mean,
+                                                        float* __restrict__ rstd, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= a.B * a.L) return;
+  const int b = row / a.L, l = row - b * a.L, H = a.H;
+  int tok, pos, typ, reg;
+  emb_decode(a, b, l, tok, pos, typ, reg);
+  const T* src = (tok >= 0) ? E + (size_t)tok * H : imgproj + ((size_t)b * a.N + reg) * H;
+  const T* pr = P + (size_t)pos * H;
+  const T* tr = Ty + (size_t)typ * H;
+  f32x4 v[NC];
+  float s = 0.f;
+#pragma unroll
+  for (int n = 0; n < NC; ++n) {
+    const int c = lane * 4 + 256 * n;
+    v[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (c < H) {
+      const f32x4 e = ld4<T>(src + c), p = ld4<T>(pr + c), t = ld4<T>(tr + c);
+      // summation order of the reference: (word|img) + position + type  (cxrbert_origin.py:29)
+      v[n] = e + p + t;
+      s += v[n][0] + v[n][1] + v[n][2] + v[n][3];
+    }
+  }
+  const float mu = wave_sum(s) / (float)H;
+  float q = 0.f;
+#pragma unroll
+  for (int n = 0; n < NC; ++n) {
+    if (lane * 4 + 256 * n < H) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const float d = v[n][e] - mu; q += d * d; }
+    }
+  }
+  const float rs = 1.0f / sqrtf(wave_sum(q) / (float)H + eps);
+#pragma unroll
+  for (int n = 0; n < NC; ++n) {
+    const int c = lane * 4 + 256 * n;
+    if (c < H) {
+      const f32x4 gg = *(const f32x4*)(g + c), bb = *(const f32x4*)(bta + c);
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (v[n][e] - mu) * rs * gg[e] + bb[e];
+      st4<T>(x0 + (size_t)row * H + c, o);
+      *(f32x4*)(pre + (size_t)row * H + c) = v[n];
+    }
+  }
+  if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+}
+
+template <typename T, int NC>
+__global__ __launch_bounds__(256) void embed_bwd_kernel(EmbArgs a, const T* __restrict__ dx0, const float* __restrict__ pre,
+                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                        const float* __restrict__ g, float* __restrict__ dE, float* __restrict__ dP,
+                                                        float* __restrict__ dTy, float* __restrict__ dgamma,
+                                                        float* __restrict__ dbeta, T* __restrict__ dimg) {
+  __shared__ float red[4][4][260];
+  const int lane = threadIdx.x & 63, wl = threadIdx.x >> 6, H = a.H;
+  f32x4 ag[NC], ab[NC], at0[NC], at1[NC];
+#pragma unroll
+  for (int i = 0; i < NC; ++i) { ag[i] = (f32x4){0, 0, 0, 0}; ab[i] = ag[i]; at0[i] = ag[i]; at1[i] = ag[i]; }
+  const int M = a.B * a.L;
+  for (int row = blockIdx.x * 4 + wl; row < M; row += gridDim.x * 4) {
+    const int b = row / a.L, l = row - b * a.L;
+    int tok, pos, typ, reg;
+    emb_decode(a, b, l, tok, pos, typ, reg);
+    const float mu = mean[row], rs = rstd[row];
+    f32x4 xh[NC], gd[NC];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int n = 0; n < NC; ++n) {
+      const int c = lane * 4 + 256 * n;
+      xh[n] = (f32x4){0, 0, 0, 0}; gd[n] = xh[n];
+      if (c < H) {
+        const f32x4 d = ld4<T>(dx0 + (size_t)row * H + c), xv = *(const f32x4*)(pre + (size_t)row * H + c), gg = *(const f32x4*)(g + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float h_ = (xv[e] - mu) * rs, gde = gg[e] * d[e];
+          xh[n][e] = h_; gd[n][e] = gde; s1 += gde; s2 += gde * h_;
+          ag[n][e] += d[e] * h_; ab[n][e] += d[e];
+        }
+      }
+    }
+    s1 = wave_sum(s1) / (float)H;
+    s2 = wave_sum(s2) / (float)H;
+#pragma unroll
+    for (int n = 0; n < NC; ++n) {
+      const int c = lane * 4 + 256 * n;
+      if (c < H) {
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = rs * (gd[n][e] - s1 - xh[n][e] * s2);
+        if (typ == 0) at0[n] += o; else at1[n] += o;
+        float* pp = dP + (size_t)pos * H + c;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) atomicAdd(pp + e, o[e]);
+        if (tok >= 0) {
+          float* ep = dE + (size_t)tok * H + c;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) atomicAdd(ep + e, o[e]);
+        } else {
+          st4<T>(dimg + ((size_t)b * a.N + reg) * H + c, o);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int n = 0; n < NC; ++n) {
+    const int c0 = 256 * n;
+    if (c0 >= H) break;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      red[0][wl][lane * 4 + e] = ag[n][e]; red[1][wl][lane * 4 + e] = ab[n][e];
+      red[2][wl][lane * 4 + e] = at0[n][e]; red[3][wl][lane * 4 + e] = at1[n][e];
+    }
+    __syncthreads();
+    const int col = c0 + threadIdx.x, t = threadIdx.x;
+    if (col < H) {
+      atomicAdd(dgamma + col, red[0][0][t] + red[0][1][t] + red[0][2][t] + red[0][3][t]);
+      atomicAdd(dbeta + col, red[1][0][t] + red[1][1][t] + red[1][2][t] + red[1][3][t]);
+      atomicAdd(dTy + col, red[2][0][t] + red[2][1][t] + red[2][2][t] + red[2][3][t]);
+      atomicAdd(dTy + H + col, red[3][0][t] + red[3][1][t] + red[3][2][t] + red[3][3][t]);
+    }
+    __syncthreads();
+  }
+}
+
+static int emb_check(int B, int N, int T, int H, int V, int maxpos) {
+  if (B <= 0 || N < 0 || T <= 0 || H <= 0 || V <= 0 || maxpos <= 0) return MV_E_ARG;
+  if ((H & 3) || H > MV_MAX_H) return MV_E_SHAPE;
+  return MV_OK;
+}
+
+extern "C" int mv_embed_fwd(int dtype, const int64_t* cls_tok, const int64_t* txt, const int64_t* segment, const int64_t* img_pos,
+                            const int64_t* sep_tok, const void* imgproj, const void* E, const void* P, const void* Ty,
+                            const float* gamma, const float* beta, void* x0, float* pre, float* mean, float* rstd, int B, int N,
+                            int T, int H, int V, int maxpos, float eps, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!cls_tok || !txt || !segment || !sep_tok || !E || !P || !Ty || !gamma || !beta || !x0 || !pre || !mean || !rstd) return MV_E_ARG;
+  if (N > 0 && (!img_pos || !imgproj)) return MV_E_ARG;
+  int rc = emb_check(B, N, T, H, V, maxpos);
+  if (rc) return rc;
+  if (T > maxpos) return MV_E_SHAPE;   // text positions 0..T-1 must exist
+  EmbArgs a{cls_tok, txt, segment, img_pos, sep_tok, B, N, T, H, V, maxpos, N + T + 2};
+  dim3 grid((B * a.L + 3) / 4), block(256);
+#define EMF(NC_) hipLaunchKernelGGL((embed_fwd_kernel<T_, NC_>), grid, block, 0, stream, a, (const T_*)imgproj, (const T_*)E, (const T_*)P, (const T_*)Ty, gamma, beta, (T_*)x0, pre, mean, rstd, eps)
+  if (dtype == MV_F32) { typedef float T_; NC_DISPATCH(H, EMF); }
+  else if (dtype == MV_BF16) { typedef bf16_t T_; NC_DISPATCH(H, EMF); }
+  else return MV_E_DTYPE;
+#undef EMF
+  MV_CHECK_LAUNCH();
+  return MV_OK;
+}
+
+extern "C" int mv_embed_bwd(int dtype, const void* dx0, const float* pre, const float* mean, const float* rstd, const float* gamma,
+                            const int64_t* cls_tok, const int64_t* txt, const int64_t* segment, const int64_t* img_pos,
+                            const int64_t* sep_tok, float* dE, float* dP, float* dTy, float* dgamma, float* dbeta, void* dimgproj,
+                            int B, int N, int T, int H, int V, int maxpos, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!dx0 || !pre || !mean || !rstd || !gamma || !cls_tok || !txt || !segment || !sep_tok || !dE || !dP || !dTy || !dgamma || !dbeta)
+    return MV_E_ARG;
+  if (N > 0 && (!img_pos || !dimgproj)) return MV_E_ARG;
+  int rc = emb_check(B, N, T, H, V, maxpos);
+  if (rc) return rc;
+  EmbArgs a{cls_tok, txt, segment, img_pos, sep_tok, B, N, T, H, V, maxpos, N + T + 2};
+  int blocks = (B * a.L + 3) / 4;
+  if (blocks > 1024) blocks = 1024;
+  dim3 grid(blocks), block(256);
+#define EMB(NC_) hipLaunchKernelGGL((embed_bwd_kernel<T_, NC_>), grid, block, 0, stream, a, (const T_*)dx0, pre, mean, rstd, gamma, dE, dP, dTy, dgamma, dbeta, (T_*)dimgproj)
+  if (dtype == MV_F32) { typedef float T_; NC_DISPATCH(H, EMB); }
+  else if (dtype == MV_BF16) { typedef bf16_t T_; NC_DISPATCH(H, EMB); }
+  else return MV_E_DTYPE;
+#undef EMB
+  MV_CHECK_LAUNCH();
+  return MV_OK;
+}
+
+// =========================================================================================
+// fused cross-entropy + argmax + gradient  (train_origin.py:62-63,120-126,133-146)
+// =========================================================================================
+// one block (256 threads) per row; the row is read once into registers (V <= 256*128).
+#define CE_MAXPER 128
+template <typename TL, typename TD, int MAXPER>
+__global__ __launch_bounds__(256) void ce_kernel(const TL* __restrict__ logits, int ld, const int32_t* __restrict__ labels, int R,
+                                                 int V, float* __restrict__ out, TD* __restrict__ dlogits, int ldd,
+                                                 const float* __restrict__ gs_dev, float gs_host) {
+  __shared__ float smax[4];
+  __shared__ int sarg[4];
+  __shared__ float ssum[4];
+  const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wl = tid >> 6;
+  const int label = labels[row];
+  TD* drow = dlogits ? dlogits + (size_t)row * ldd : nullptr;
+  if (label < 0 || label >= V) {   // ignore_index (-100): no loss, zero gradient
+    if (drow) for (int c = tid; c < ldd; c += 256) stf<TD>(drow + c, 0.f);
+    return;
+  }
+  const TL* lr = logits + (size_t)row * ld;
+  float v[MAXPER];
+  float mx = -INFINITY;
+  int am = 0x7fffffff;
+#pragma unroll
+  for (int n = 0; n < MAXPER; ++n) {
+    const int c = tid + 256 * n;
+    v[n] = -INFINITY;
+    if (c < V) {
+      const float x = ldf<TL>(lr + c);
+      v[n] = x;
+      if (x > mx) { mx = x; am = c; }     // first maximum wins (torch.argmax tie rule)
+    }
+  }
+  // wave + block argmax (smallest index among equal maxima)
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float om = __shfl_xor(mx, o, 64);
+    const int oa = __shfl_xor(am, o, 64);
+    if (om > mx || (om == mx && oa < am)) { mx = om; am = oa; }
+  }
+  if (lane == 0) { smax[wl] = mx; sarg[wl] = am; }
+  __syncthreads();
+  mx = smax[0]; am = sarg[0];
+  for (int w = 1; w < 4; ++w) if (smax[w] > mx || (smax[w] == mx && sarg[w] < am)) { mx = smax[w]; am = sarg[w]; }
+  float s = 0.f;
+#pragma unroll
+  for (int n = 0; n < MAXPER; ++n) { v[n] = expf(v[n] - mx); s += v[n]; }   // padding: exp(-inf) = 0
+  s = wave_sum(s);
+  if (lane == 0) ssum[wl] = s;
+  __syncthreads();
+  s = ssum[0] + ssum[1] + ssum[2] + ssum[3];
+  if (tid == 0) {
+    const float xl = ldf<TL>(lr + label);
+    atomicAdd(out + 0, (mx + logf(s)) - xl);
+    atomicAdd(out + 1, 1.0f);
+    if (am == label) atomicAdd(out + 2, 1.0f);
+  }
+  if (drow) {
+    const float gs = gs_dev ? *gs_dev : gs_host;
+    const float inv = gs / s;
+#pragma unroll
+    for (int n = 0; n < MAXPER; ++n) {
+      const int c = tid + 256 * n;
+      if (c < V) stf<TD>(drow + c, v[n] * inv - (c == label ? gs : 0.f));
+    }
+    for (int c = V + tid; c < ldd; c += 256) stf<TD>(drow + c, 0.f);
+  }
+}
+
+extern "C" int mv_ce_fwd_bwd(const void* logits, int l_dtype, int ld, const int32_t* labels, int R, int V, float* out, void* dlogits,
+                             int d_dtype, int ldd, const float* grad_scale_dev, float grad_scale_host, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!logits || !labels || !out || R <= 0 || V <= 0 || ld < V) return MV_E_ARG;
+  if (V > 256 * CE_MAXPER) return MV_E_SHAPE;
+  if (dlogits && ldd < V) return MV_E_SHAPE;
+  dim3 grid(R), block(256);
+#define CE_LAUNCH(TL, TD)                                                                                              \
+  do {                                                                                                                 \
+    if (V <= 256 * 8) hipLaunchKernelGGL((ce_kernel<TL, TD, 8>), grid, block, 0, stream, (const TL*)logits, ld, labels, R, V, out, (TD*)dlogits, ldd, grad_scale_dev, grad_scale_host); \
+    else hipLaunchKernelGGL((ce_kernel<TL, TD, CE_MAXPER>), grid, block, 0, stream, (const TL*)logits, ld, labels, R, V, out, (TD*)dlogits, ldd, grad_scale_dev, grad_scale_host); \
+  } while (0)
+  if (l_dtype == MV_F32 && d_dtype == MV_F32) CE_LAUNCH(float, float);
+  else if (l_dtype == MV_F32 && d_dtype == MV_BF16) CE_LAUNCH(float, bf16_t);
+  else if (l_dtype == MV_BF16 && d_dtype == MV_BF16) CE_LAUNCH(bf16_t, bf16_t);
+  else if (l_dtype == MV_BF16 && d_dtype == MV_F32) CE_LAUNCH(bf16_t, float);
+  else return MV_E_DTYPE;
+#undef CE_LAUNCH
+  MV_CHECK_LAUNCH();
+  return MV_OK;
+}
+
+// =========================================================================================
+// gather / scatter rows, column sums, add, cast
+// =========================================================================================
+template <typename T>
+__global__ void gather_rows_kernel(const T* __restrict__ src, int lds_, const int32_t* __restrict__ rows, int R, int H,
+                                   T* __restrict__ dst, int ldd) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= R) return;
+  const T* s = src + (size_t)rows[r] * lds_;
+  T* d = dst + (size_t)r * ldd;
+  for (int c = lane * 4; c < H; c += 256) st4<T>(d + c, ld4<T>(s + c));
+}
+template <typename T>
+__global__ void scatter_rows_kernel(const T* __restrict__ src, int lds_, const int32_t* __restrict__ rows, int R, int H,
+                                    T* __restrict__ dst, int ldd, int accumulate) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= R) return;
+  const T* s = src + (size_t)r * lds_;
+  T* d = dst + (size_t)rows[r] * ldd;
+  for (int c = lane * 4; c < H; c += 256) {
+    f32x4 v = ld4<T>(s + c);
+    if (accumulate) v += ld4<T>(d + c);
+    st4<T>(d + c, v);
+  }
+}
+
+extern "C" int mv_gather_rows(int dtype, const void* src, int lds_, const int32_t* rows, int R, int H, void* dst, int ldd, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!src || !rows || !dst || R <= 0 || H <= 0) return MV_E_ARG;
+  if ((H & 3) || (lds_ & 3) || (ldd & 3)) return MV_E_SHAPE;
+  dim3 grid((R + 3) / 4), block(256);
+  if (dtype == MV_F32) hipLaunchKernelGGL(gather_rows_kernel<float>, grid, block, 0, stream, (const float*)src, lds_, rows, R, H, (float*)dst, ldd);
+  else if (dtype == MV_BF16) hipLaunchKernelGGL(gather_rows_kernel<bf16_t>, grid, block, 0, stream, (const bf16_t*)src, lds_, rows, R, H, (bf16_t*)dst, ldd);
+  else return MV_E_DTYPE;
+  MV_CHECK_LAUNCH();
+  return MV_OK;
+}
+extern "C" int mv_scatter_rows(int dtype, const void* src, int lds_, const int32_t* rows, int R, int H, void* dst, int ldd,
+                               int accumulate, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!src || !rows || !dst || R <= 0 || H <= 0) return MV_E_ARG;
+  if ((H & 3) || (lds_ & 3) || (ldd & 3)) return MV_E_SHAPE;
+  dim3 grid((R + 3) / 4), block(256);
+  if (dtype == MV_F32) hipLaunchKernelGGL(scatter_rows_kernel<float>, grid, block, 0, stream, (const float*)src, lds_, rows, R, H, (float*)dst, ldd, accumulate);
+  else if (dtype == MV_BF16) hipLaunchKernelGGL(scatter_rows_kernel<bf16_t>, grid, block, 0, stream, (const bf16_t*)src, lds_, rows, R, H, (bf16_t*)dst, ldd, accumulate);
+  else return MV_E_DTYPE;
+  MV_CHECK_LAUNCH();
+  return MV_OK;
+}
+
+// out[n] += sum_m x[m,n]: block = 64 columns x 4 row-lanes... each thread owns one column of a
+// 256-column strip and walks a slice of the rows (coalesced across the strip).
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, int ldx, int M, int N, float* __restrict__ out) {
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  if (col >= N) return;
+  const int rows_per = (M + gridDim.y - 1) / gridDim.y;
+  const int r0 = blockIdx.y * rows_per, r1 = min(M, r0 + rows_per);
+  float s = 0.f;
+  for (int r = r0; r < r1; ++r) s += ldf<T>(x + (size_t)r * ldx + col);
+  atomicAdd(out + col, s);
+}
+__global__ void zero_f32_kernel(float* p, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = 0.f;
+}
+
+extern "C" int mv_colsum(int dtype, const void* x, int ldx, int M, int N, float* out, int accumulate, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!x || !out || M <= 0 || N <= 0 || ldx < N) return MV_E_ARG;
+  if (!accumulate) {
+    hipLaunchKernelGGL(zero_f32_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, out, (size_t)N);
+    MV_CHECK_LAUNCH();
+  }
+  int ysplit = (M + 127) / 128;
+  if (ysplit > 256) ysplit = 256;
+  dim3 grid((N + 255) / 256, ysplit), block(256);
+  if (dtype == MV_F32) hipLaunchKernelGGL(colsum_kernel<float>, grid, block, 0, stream, (const float*)x, ldx, M, N, out);
+  else if (dtype == MV_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, block, 0, stream, (const bf16_t*)x, ldx, M, N, out);
+  else return MV_E_DTYPE;
+  MV_CHECK_LAUNCH();
+  return MV_OK;
+}
+
+template <typename T>
+__global__ void add_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ c, size_t n4) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x)
+    st4<T>(c + 4 * i, ld4<T>(a + 4 * i) + ld4<T>(b + 4 * i));
+}
+extern "C" int mv_add(int dtype, const void* a, const void* b, void* c, size_t n, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!a || !b || !c || n == 0) return MV_E_ARG;
+  if (n & 3) return MV_E_SHAPE;
+  const size_t n4 = n / 4;
+  int blocks = (int)((n4 + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  if (dtype == MV_F32) hipLaunchKernelGGL(add_kernel<float>, dim3(blocks), dim3(256), 0, stream, (const float*)a, (const float*)b, (float*)c, n4);
+  else if (dtype == MV_BF16) hipLaunchKernelGGL(add_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)c, n4);
+  else return MV_E_DTYPE;
+  MV_CHECK_LAUNCH();
+  return MV_OK;
+}
+
+// out = dy * gelu'(z)   (mode 0)   |   out = dy * (1 - y*y)   (mode 1: tanh backward, z holds y)
+template <typename T>
+__global__ void dact_kernel(const T* __restrict__ dy, const T* __restrict__ z, T* __restrict__ out, size_t n4, int mode) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const f32x4 d = ld4<T>(dy + 4 * i), zz = ld4<T>(z + 4 * i);
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = mode == 0 ? d[e] * dgelu_erf(zz[e]) : d[e] * (1.0f - zz[e] * zz[e]);
+    st4<T>(out + 4 * i, o);
+  }
+}
+extern "C" int mv_dact(int dtype, int mode, const void* dy, const void* z, void* out, size_t n, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!dy || !z || !out || n == 0) return MV_E_ARG;
+  if ((n & 3) || (mode != 0 && mode != 1)) return MV_E_SHAPE;
+  const size_t n4 = n / 4;
+  int blocks = (int)((n4 + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  if (dtype == MV_F32) hipLaunchKernelGGL(dact_kernel<float>, dim3(blocks), dim3(256), 0, stream, (const float*)dy, (const float*)z, (float*)out, n4, mode);
+  else if (dtype == MV_BF16) hipLaunchKernelGGL(dact_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream, (const bf16_t*)dy, (const bf16_t*)z, (bf16_t*)out, n4, mode);
+  else return MV_E_DTYPE;
+  MV_CHECK_LAUNCH();
+  return MV_OK;
+}
+
+// 2-D cast with leading dimensions; columns cols..ldd-1 of dst are zero-filled
+template <typename TS, typename TDs>
+__global__ void cast2d_kernel(const TS* __restrict__ s, long long lds_, TDs* __restrict__ d, long long ldd, int rows, int cols) {
+  const int r = blockIdx.y;
+  const TS* sr = s + (size_t)r * lds_;
+  TDs* dr = d + (size_t)r * ldd;
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < ldd; c += gridDim.x * blockDim.x)
+    stf<TDs>(dr + c, c < cols ? ldf<TS>(sr + c) : 0.f);
+}
+extern "C" int mv_cast2d(const void* src, int src_dtype, long long lds_, void* dst, int dst_dtype, long long ldd, int rows, int cols,
+                         void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!src || !dst || rows <= 0 || cols <= 0 || lds_ < cols || ldd < cols) return MV_E_ARG;
+  if (rows > 65535 * 16) return MV_E_SHAPE;
+  int bx = (int)((ldd + 255) / 256);
+  if (bx > 32) bx = 32;
+  for (int r0 = 0; r0 < rows; r0 += 65535) {
+    const int nr = rows - r0 < 65535 ? rows - r0 : 65535;
+    dim3 grid(bx, nr), block(256);
+    const char* sp = (const char*)src + (size_t)r0 * lds_ * mv_dtype_size(src_dtype);
+    char* dp = (char*)dst + (size_t)r0 * ldd * mv_dtype_size(dst_dtype);
+    if (src_dtype == MV_F32 && dst_dtype == MV_BF16) hipLaunchKernelGGL((cast2d_kernel<float, bf16_t>), grid, block, 0, stream, (const float*)sp, lds_, (bf16_t*)dp, ldd, nr, cols);
+    else if (src_dtype == MV_BF16 && dst_dtype == MV_F32) hipLaunchKernelGGL((cast2d_kernel<bf16_t, float>), grid, block, 0, stream, (const bf16_t*)sp, lds_, (float*)dp, ldd, nr, cols);
+    else if (src_dtype == MV_F32 && dst_dtype == MV_F32) hipLaunchKernelGGL((cast2d_kernel<float, float>), grid, block, 0, stream, (const float*)sp, lds_, (float*)dp, ldd, nr, cols);
+    else if (src_dtype == MV_BF16 && dst_dtype == MV_BF16) hipLaunchKernelGGL((cast2d_kernel<bf16_t, bf16_t>), grid, block, 0, stream, (const bf16_t*)sp, lds_, (bf16_t*)dp, ldd, nr, cols);
+    else return MV_E_DTYPE;
+    MV_CHECK_LAUNCH();
+  }
+  return MV_OK;
+}
+
+template <typename TS, typename TDs>
+__global__ void cast_kernel(const TS* __restrict__ s, TDs* __restrict__ d, size_t n) {
+  const size_t n4 = n / 4;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x)
+    st4<TDs>(d + 4 * i, ld4<TS>(s + 4 * i));
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) stf<TDs>(d + n4 * 4 + threadIdx.x, ldf<TS>(s + n4 * 4 + threadIdx.x));
+}
+extern "C" int mv_cast(const void* src, int src_dtype, void* dst, int dst_dtype, size_t n, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!src || !dst || n == 0) return MV_E_ARG;
+  int blocks = (int)((n / 4 + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  if (src_dtype == MV_F32 && dst_dtype == MV_BF16) hipLaunchKernelGGL((cast_kernel<float, bf16_t>), dim3(blocks), dim3(256), 0, stream, (const float*)src, (bf16_t*)dst, n);
+  else if (src_dtype == MV_BF16 && dst_dtype == MV_F32) hipLaunchKernelGGL((cast_kernel<bf16_t, float>), dim3(blocks), dim3(256), 0, stream, (const bf16_t*)src, (float*)dst, n);
+  else if (src_dtype == MV_F32 && dst_dtype == MV_F32) hipLaunchKernelGGL((cast_kernel<float, float>), dim3(blocks), dim3(256), 0, stream, (const float*)src, (float*)dst, n);
+  else if (src_dtype == MV_BF16 && dst_dtype == MV_BF16) hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), dim3(blocks), dim3(256), 0, stream, (const bf16_t*)src, (bf16_t*)dst, n);
+  else return MV_E_DTYPE;
+  MV_CHECK_LAUNCH();
+  return MV_OK;
+}
+
+// =========================================================================================
+// fused HF AdamW over the flat parameter buffer  (train_origin.py:60,131)
+// =========================================================================================
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, bf16_t* __restrict__ shadow, size_t n, float step_size,
+                                                    float b1, float b2, float eps, float lr_wd, float gscale) {
+  const size_t n4 = n / 4;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    f32x4 pp = *(const f32x4*)(p + 4 * i), gg = *(const f32x4*)(g + 4 * i), mm = *(const f32x4*)(m + 4 * i), vv = *(const f32x4*)(v + 4 * i);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float ge = gg[e] * gscale;
+      mm[e] = b1 * mm[e] + (1.0f - b1) * ge;
+      vv[e] = b2 * vv[e] + (1.0f - b2) * ge * ge;
+      float x = pp[e] - step_size * (mm[e] / (sqrtf(vv[e]) + eps));
+      x -= lr_wd * x;
+      pp[e] = x;
+    }
+    *(f32x4*)(p + 4 * i) = pp; *(f32x4*)(m + 4 * i) = mm; *(f32x4*)(v + 4 * i) = vv;
+    if (shadow) st4<bf16_t>(shadow + 4 * i, pp);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const size_t i = n4 * 4 + threadIdx.x;
+    const float ge = g[i] * gscale;
+    const float mm = b1 * m[i] + (1.0f - b1) * ge, vv = b2 * v[i] + (1.0f - b2) * ge * ge;
+    float x = p[i] - step_size * (mm / (sqrtf(vv) + eps));
+    x -= lr_wd * x;
+    p[i] = x; m[i] = mm; v[i] = vv;
+    if (shadow) shadow[i] = (bf16_t)x;
+  }
+}
+
+extern "C" int mv_adamw_step(float* p, const float* g, float* m, float* v, void* shadow_bf16, size_t n, float lr, float beta1,
+                             float beta2, float eps, float weight_decay, int step, int correct_bias, float grad_scale, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!p || !g || !m || !v || n == 0 || step < 1) return MV_E_ARG;
+  if ((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) return MV_E_SHAPE;
+  if (shadow_bf16 && (((uintptr_t)shadow_bf16) & 7)) return MV_E_SHAPE;
+  double ss = lr;
+  if (correct_bias) ss = ss * sqrt(1.0 - pow((double)beta2, step)) / (1.0 - pow((double)beta1, step));
+  int blocks = (int)((n / 4 + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(256), 0, stream, p, g, m, v, (bf16_t*)shadow_bf16, n, (float)ss, beta1, beta2, eps,
+                     lr * weight_decay, grad_scale);
+  MV_CHECK_LAUNCH();
+  return MV_OK;
+}

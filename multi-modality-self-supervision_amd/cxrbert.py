@@ -1,0 +1,232 @@
+"""Drop-in mirror of the reference's model interface (models/cxrbert_origin.py).
+
+    CXRBERT(config, args).forward(cls_tok, input_txt, attn_mask, segment, input_img, sep_tok)
+        -> (mlm_logits [B,L,V], itm_logits [B,2])                 cxrbert_origin.py:132-149
+    .enc(...) -> (last_hidden [B,L,H], pooled [B,H], None)         cxrbert_origin.py:130
+    .mlm / .itm sub-modules, .state_dict() with the reference key names (incl. aliases),
+    .save_pretrained(dir) / CXRBERT.from_pretrained(dir, state_dict=, config=, args=)
+                                                                   train_origin.py:31-32,254-266
+
+Same names, argument meaning and error behaviour as the reference; the arithmetic runs on the
+HIP engine (engine.py) -- there is no eager / CPU path.  ``input_img`` is either the tuple
+``(region_feats [B,N,2048], region_pos [B,N])`` (what the reference's ``img_encoder`` returns,
+models/image.py:54-69 -- the CNN itself is out of scope) or a tensor that a
+user-supplied ``img_encoder`` callable maps to that tuple.
+"""
+from __future__ import annotations
+
+import json
+import os
+from collections import OrderedDict
+from types import SimpleNamespace
+
+import torch
+import torch.nn as nn
+
+from .engine import ALIASES, Engine, ModelConfig
+
+
+def model_config_from(config) -> ModelConfig:
+    """Accepts a ModelConfig, a HF-BertConfig-like object or a dict (config.json contents)."""
+    if isinstance(config, ModelConfig):
+        return config
+    get = (lambda k, d=None: config.get(k, d)) if isinstance(config, dict) else (lambda k, d=None: getattr(config, k, d))
+    return ModelConfig(vocab_size=get("vocab_size", 30522), hidden=get("hidden_size", 768), layers=get("num_hidden_layers", 12),
+                       heads=get("num_attention_heads", 12), intermediate=get("intermediate_size", 3072),
+                       max_pos=get("max_position_embeddings", 512), type_vocab=get("type_vocab_size", 2),
+                       img_hidden=get("img_hidden_sz", 2048), ln_eps=get("layer_norm_eps", 1e-12))
+
+
+class _CXRBertFn(torch.autograd.Function):
+    """Whole-network autograd node: forward = the engine's kernel schedule, backward = the
+    engine's explicit backward schedule.  Gradients come back as (clones of) views of the flat
+    gradient buffer, one per Parameter, so `loss.backward(); optimizer.step()` of the reference
+    trainer (train_origin.py:129-131) works unchanged."""
+
+    @staticmethod
+    def forward(ctx, model, want_heads, cls_tok, input_txt, attn_mask, segment, feats, pos, sep_tok, *params):
+        eng = model.engine
+        eng.shadow_dirty = True                 # parameters may have been stepped by an external optimizer
+        hidden, pooled = eng.encoder_forward(cls_tok, input_txt, attn_mask, segment, feats, pos, sep_tok)
+        ctx.model, ctx.want_heads = model, want_heads
+        if want_heads:
+            mlm, itm = eng.heads_full()
+            return mlm, itm
+        return hidden.clone(), pooled.clone()
+
+    @staticmethod
+    def backward(ctx, g0, g1):
+        model = ctx.model
+        eng = model.engine
+        eng.zero_grad()
+        if ctx.want_heads:
+            eng.heads_full_backward(g0, g1)
+        else:
+            S, H = eng.S, eng.cfg.hidden
+            dh = S["dhidden"] = eng._buf("dhidden", (S["M"], H), eng.adt)
+            dh.copy_(g0.reshape(S["M"], H)) if g0 is not None else dh.zero_()
+            if g1 is not None:
+                # pooled = tanh(hidden[:,0].Wp^T + bp)
+                from . import hip_ops as ops
+                B, Lq = S["B"], S["L"]
+                dpre = eng._buf("dpoolpre", (B, H), eng.adt)
+                ops.dact(1, g1.to(eng.adt).contiguous(), S["pooled"], dpre, B * H)
+                ops.colsum(dpre, H, B, H, eng.g["enc.pooler.dense.bias"], accumulate=True)
+                eng._dW(dpre, S["hidden"], eng.g["enc.pooler.dense.weight"], H, H, B, lda=H, ldb=Lq * H)
+                dh0 = eng._buf("dh0", (B, H), eng.adt)
+                ops.gemm(dpre, eng.w["enc.pooler.dense.weight"], dh0, tb=True, M=B, N=H, K=H)
+                rows0 = (torch.arange(B, device=eng.device, dtype=torch.int32) * Lq)
+                ops.scatter_rows(dh0, H, rows0, B, H, dh, H, accumulate=True)
+        eng.encoder_backward()
+        grads = tuple(eng.g[n].clone() for n in model._param_names)
+        return (None,) * 9 + grads
+
+
+class _Sub(nn.Module):
+    """Namespace module so that parameters appear under the reference's dotted names."""
+
+
+class CXRBERT(nn.Module):
+    """Multimodal BERT: Masked Language Model + Image Text Matching (cxrbert_origin.py:132-149)."""
+
+    def __init__(self, config, args=None, dtype=torch.bfloat16, device=None, img_encoder=None):
+        super().__init__()
+        self.cfg = model_config_from(config)
+        self.config = config
+        self.args = args if args is not None else SimpleNamespace()
+        if getattr(self.args, "disturbing_mask", False):
+            # the reference's disturbing_mask branch is shape-inconsistent and cannot run
+            raise NotImplementedError("disturbing_mask model branch: use the non-cross MASK pattern with the standard branch")
+        dev = torch.device(device) if device is not None else torch.device("cuda" if torch.cuda.is_available() else "cpu")
+        self.engine = Engine(self.cfg, dtype=dtype, device=dev)
+        self.img_encoder = img_encoder
+        self._param_names = list(self.engine.layout.keys())
+        self._register()
+        self.reset_parameters()
+
+    # parameters are views of the engine's flat fp32 buffer, registered under the reference names
+    def _register(self):
+        for name in self._param_names:
+            mod = self
+            parts = name.split(".")
+            for p_ in parts[:-1]:
+                if p_ not in mod._modules:
+                    mod.add_module(p_, _Sub())
+                mod = mod._modules[p_]
+            par = nn.Parameter(self.engine.p[name], requires_grad=True)
+            mod._parameters[parts[-1]] = par
+        self.enc.forward = self._enc_forward
+
+    def _rebind(self):
+        for name in self._param_names:
+            mod = self
+            parts = name.split(".")
+            for p_ in parts[:-1]:
+                mod = mod._modules[p_]
+            mod._parameters[parts[-1]].data = self.engine.p[name]
+
+    def _apply(self, fn, *a, **k):
+        # .to(device) / .cuda(): move the flat buffers, then re-point the Parameter views
+        probe = fn(torch.empty(0, device=self.engine.device))
+        if probe.dtype != torch.float32 and probe.dtype != torch.empty(0).dtype:
+            raise RuntimeError("parameters stay fp32 master weights; choose the compute dtype with CXRBERT(dtype=...)")
+        self.engine.to(probe.device)
+        self._rebind()
+        return self
+
+    @torch.no_grad()
+    def reset_parameters(self, seed: int | None = None):
+        """BertModel(config) self-init N(0, 0.02), LayerNorm (1, 0), zero biases; the heads keep
+        torch's default Linear init because CXRBERT.__init__ never calls init_weights
+        (cxrbert_origin.py:137-142)."""
+        gen = torch.Generator(device="cpu")
+        gen.manual_seed(torch.initial_seed() if seed is None else seed)
+        H = self.cfg.hidden
+        flat = torch.zeros(self.engine.n_flat, dtype=torch.float32)
+        for name, (off, shape) in self.engine.layout.items():
+            n = 1
+            for s in shape:
+                n *= s
+            v = flat[off:off + n].view(shape)
+            head_lin = name.startswith(("mlm.predictions.transform.dense", "itm.linear", "enc.img_embeddings.img_embeddings"))
+            if name.endswith("LayerNorm.weight"):
+                v.fill_(1.0)
+            elif head_lin:
+                fan_in = shape[-1] if len(shape) == 2 else {"mlm.predictions.transform.dense.bias": H, "itm.linear.bias": H,
+                                                           "enc.img_embeddings.img_embeddings.bias": self.cfg.img_hidden}[name]
+                bound = 1.0 / (fan_in ** 0.5)
+                v.copy_((torch.rand(shape, generator=gen) * 2 - 1) * bound)
+            elif name.endswith("bias"):
+                v.zero_()
+            else:
+                v.copy_(torch.randn(shape, generator=gen) * 0.02)
+        self.engine.flat_p.copy_(flat.to(self.engine.device))
+        self.engine.shadow_dirty = True
+
+    # ------------------------------------------------------------------ forward
+    def _regions(self, input_img):
+        if isinstance(input_img, (tuple, list)) and len(input_img) == 2:
+            return input_img
+        if self.img_encoder is not None:
+            return self.img_encoder(input_img)
+        raise TypeError("input_img must be (region_feats[B,N,2048], region_pos[B,N]) or an img_encoder must be supplied "
+                        "(the ResNet-50 trunk of models/image.py is outside this library's scope)")
+
+    def _run(self, want_heads, cls_tok, input_txt, attn_mask, segment, input_img, sep_tok):
+        if attn_mask.dim() not in (2, 3):
+            raise NotImplementedError            # cxrbert_origin.py:80-81
+        feats, pos = self._regions(input_img)
+        params = [self.get_parameter(n) for n in self._param_names]
+        return _CXRBertFn.apply(self, want_heads, cls_tok, input_txt, attn_mask, segment, feats, pos, sep_tok, *params)
+
+    def _enc_forward(self, cls_tok, input_txt, attn_mask, segment, input_img, sep_tok):
+        hidden, pooled = self._run(False, cls_tok, input_txt, attn_mask, segment, input_img, sep_tok)
+        return hidden, pooled, None
+
+    def forward(self, cls_tok, input_txt, attn_mask, segment, input_img, sep_tok):
+        return self._run(True, cls_tok, input_txt, attn_mask, segment, input_img, sep_tok)
+
+    # ------------------------------------------------------------------ state dict (reference key names)
+    def state_dict(self, *a, **k):
+        sd = OrderedDict((n, self.engine.p[n].detach().clone()) for n in self._param_names)
+        for alias, canon in ALIASES.items():
+            sd[alias] = sd[canon]
+        return sd
+
+    def load_state_dict(self, sd, strict=True):
+        missing = []
+        with torch.no_grad():
+            for n in self._param_names:
+                if n in sd:
+                    self.engine.p[n].copy_(sd[n].to(self.engine.device, torch.float32))
+                else:
+                    missing.append(n)
+        unexpected = [k_ for k_ in sd if k_ not in self.engine.layout and k_ not in ALIASES
+                      and "position_ids" not in k_ and not k_.startswith("enc.img_encoder.")]
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"load_state_dict: missing {missing[:5]} unexpected {unexpected[:5]}")
+        self.engine.shadow_dirty = True
+        return SimpleNamespace(missing_keys=missing, unexpected_keys=unexpected)
+
+    def save_pretrained(self, save_directory):
+        """HF layout: config.json + pytorch_model.bin (train_origin.py:254-266)."""
+        os.makedirs(save_directory, exist_ok=True)
+        c = self.cfg
+        cj = dict(architectures=["CXRBERT"], model_type="bert", vocab_size=c.vocab_size, hidden_size=c.hidden,
+                  num_hidden_layers=c.layers, num_attention_heads=c.heads, intermediate_size=c.intermediate,
+                  max_position_embeddings=c.max_pos, type_vocab_size=c.type_vocab, layer_norm_eps=c.ln_eps,
+                  hidden_act="gelu", hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1)
+        with open(os.path.join(save_directory, "config.json"), "w") as f:
+            json.dump(cj, f, indent=2)
+        torch.save({k_: v.cpu() for k_, v in self.state_dict().items()}, os.path.join(save_directory, "pytorch_model.bin"))
+
+    @classmethod
+    def from_pretrained(cls, path, state_dict=None, config=None, args=None, **kw):
+        if config is None:
+            with open(os.path.join(path, "config.json")) as f:
+                config = json.load(f)
+        if state_dict is None:
+            state_dict = torch.load(os.path.join(path, "pytorch_model.bin"), map_location="cpu")
+        m = cls(config, args, **kw)
+        m.load_state_dict(state_dict, strict=False)
+        return m

@@ -1,0 +1,113 @@
+"""Batch-side contract of the pretraining path: attention-mask families, label layout and a
+synthetic batch generator that produces the reference Dataset's 9-tuple contents directly on
+the device (no PIL / tokenizer / DataLoader workers on the benchmark path).
+
+Mirrors (paths relative to the upstream repo):
+  mask families ............. data/dataset_origin.py:138-176  (closed forms: SURVEY Appendix B)
+  label / pad / segment ..... data/dataset_origin.py:105-135
+  MLM corruption ............ data/dataset_origin.py:183-209 (15 % / 80-10-10, >= 1 label)
+  region sampling ........... models/image.py:63-68 (sorted sample of M positions, shared by the batch)
+"""
+from __future__ import annotations
+
+import torch
+
+PAD, UNK, CLS, SEP, MASK = 0, 100, 101, 102, 103
+FAMILIES = ("full", "s2s", "bar", "noncross", "1d")
+
+
+def build_mask(family: str, N: int, S: int, n_ids, device="cpu") -> torch.Tensor:
+    """int64 [B,L,L] (or [B,L] for '1d') for per-sample text lengths n_ids (incl. the text [SEP])."""
+    n_ids = torch.as_tensor(n_ids, device=device, dtype=torch.int64).view(-1)
+    B = n_ids.numel()
+    L = S + N + 3
+    n2 = N + 2
+    vl = (n2 + n_ids).view(B, 1, 1)
+    i = torch.arange(L, device=device).view(1, L, 1)
+    j = torch.arange(L, device=device).view(1, 1, L)
+    if family == "full":
+        m = (j < vl).expand(B, L, L)
+    elif family == "s2s":
+        m = ((j < n2) | ((i >= n2) & (j >= n2) & (j <= i))).expand(B, L, L)
+    elif family == "bar":
+        m = ((i < n2) | (j < n2) | (j <= i)).expand(B, L, L)
+    elif family == "noncross":
+        m = ((i < n2) == (j < n2)).expand(B, L, L)
+    elif family == "1d":
+        return (torch.arange(L, device=device).view(1, L) < vl.view(B, 1)).to(torch.int64)
+    else:
+        raise ValueError(family)
+    return m.to(torch.int64).contiguous()
+
+
+def mixed_mask(N: int, S: int, n_ids, choose_s2s, device="cpu"):
+    """`Mixed` (dataset_origin.py:152-155): per-sample choice between full and s2s."""
+    full = build_mask("full", N, S, n_ids, device)
+    s2s = build_mask("s2s", N, S, n_ids, device)
+    sel = torch.as_tensor(choose_s2s, device=device, dtype=torch.bool).view(-1, 1, 1)
+    return torch.where(sel, s2s, full)
+
+
+def corrupt_tokens(ids: torch.Tensor, lengths: torch.Tensor, vocab: int, gen: torch.Generator):
+    """Vectorised random_word: ids [B,S] (valid for t < lengths[b]).  Returns (ids', labels) with
+    labels = original id where selected else -100; guarantees >= 1 label per sample."""
+    B, S = ids.shape
+    dev = ids.device
+    t = torch.arange(S, device=dev).view(1, S)
+    valid = t < lengths.view(B, 1)
+    u = torch.rand((B, S), generator=gen, device=dev)
+    sel = (u < 0.15) & valid
+    none = ~sel.any(dim=1)
+    sel[none, 0] = True                       # "at least one mask": position 0 becomes [MASK]
+    u2 = u / 0.15
+    rnd = torch.randint(0, vocab, (B, S), generator=gen, device=dev)
+    out = ids.clone()
+    to_mask = sel & ((u2 < 0.8) | none.view(B, 1))
+    to_rand = sel & (u2 >= 0.8) & (u2 < 0.9) & ~none.view(B, 1)
+    out[to_mask] = MASK
+    out[to_rand] = rnd[to_rand]
+    labels = torch.where(sel, ids, torch.full_like(ids, -100))
+    return out, labels
+
+
+def synthetic_batch(vocab: int, B: int, N: int, S: int, family: str, seed: int, device="cuda", img_hidden: int = 2048,
+                    M_regions: int = 256, feat_dtype=torch.float32) -> dict:
+    """One mini-batch in the reference's batch protocol (dataset_origin.py:181) plus the
+    labelled-row index the fused MLM head consumes.  family: full|s2s|bar|noncross|1d|mixed."""
+    dev = torch.device(device)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed)
+    T, L = S + 1, S + N + 3
+    lo = 1000 if vocab > 2000 else 200
+    lengths = torch.randint((S + 1) // 2, S + 1, (B,), generator=gen, device=dev)
+    ids = torch.randint(lo, vocab, (B, S), generator=gen, device=dev)
+    ids_c, lab = corrupt_tokens(ids, lengths, vocab, gen)
+    t = torch.arange(T, device=dev).view(1, T)
+    n_ids = lengths + 1
+    txt = torch.zeros((B, T), dtype=torch.int64, device=dev)
+    txt[:, :S] = torch.where(t[:, :S] < lengths.view(B, 1), ids_c, torch.zeros_like(ids_c))
+    txt[torch.arange(B, device=dev), lengths] = SEP
+    labels = torch.full((B, L), -100, dtype=torch.int64, device=dev)
+    labels[:, N + 2:N + 2 + S] = torch.where(t[:, :S] < lengths.view(B, 1), lab, torch.full_like(lab, -100))
+    segment = torch.ones((B, T), dtype=torch.int64, device=dev)
+    perm = torch.randperm(M_regions, generator=gen, device=dev)[:N]
+    pos = torch.sort(perm)[0].view(1, N).expand(B, N).contiguous()
+    feats = torch.randn((B, N, img_hidden), generator=gen, device=dev, dtype=torch.float32).to(feat_dtype)
+    is_aligned = (torch.rand((B,), generator=gen, device=dev) > 0.5).to(torch.int64)
+    if family == "mixed":
+        choose = torch.rand((B,), generator=gen, device=dev) < 0.75
+        mask = mixed_mask(N, S, n_ids, choose, dev)
+    else:
+        mask = build_mask(family, N, S, n_ids, dev)
+    flat = labels.view(-1)
+    rows = torch.nonzero(flat != -100).view(-1)
+    return dict(cls_tok=torch.full((B, 1), CLS, dtype=torch.int64, device=dev), input_txt=txt, attn_mask=mask, segment=segment,
+                img_feats=feats, img_pos=pos, sep_tok=torch.full((B, 1), SEP, dtype=torch.int64, device=dev), txt_labels=labels,
+                is_aligned=is_aligned, n_ids=n_ids, label_rows=rows.to(torch.int32), label_ids=flat[rows].to(torch.int32))
+
+
+def label_index(txt_labels: torch.Tensor):
+    """(rows int32 [R], ids int32 [R]) of the positions with a label (!= -100), row-major."""
+    flat = txt_labels.reshape(-1)
+    rows = torch.nonzero(flat != -100).view(-1)
+    return rows.to(torch.int32), flat[rows].to(torch.int32)

@@ -1,0 +1,88 @@
+"""Data-parallel exchange for the pretraining step: one process per GPU, RCCL over xGMI.
+
+Replaces nn.DataParallel of models/train_origin.py:53-55 (per-step parameter broadcast, input
+scatter, [B,L,V] logit gather and gradient reduce to GPU 0) by the only exchange the math
+needs:
+  * one tiny all-reduce of (#labelled tokens, local batch) BEFORE the backward, so that every
+    rank back-propagates  mlm_nll_sum / n_labelled_global + itm_nll_sum / B_global  -- the
+    gradient of the reference's global-batch mean losses;
+  * sum all-reduce of the flat fp32 gradient, cut into contiguous buckets (heads, one per
+    encoder layer, embeddings) that are launched on a side stream as soon as the backward has
+    finished them, so the exchange overlaps the remaining backward kernels.
+Parameters are never broadcast after construction: identical init + identical updates.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+def bucket_ranges(layout, n_flat, layers):
+    """name -> (start, end) element ranges of the flat buffer, in forward (= memory) order."""
+    def off(name):
+        return layout[name][0]
+    r = {}
+    first_layer = off("enc.encoder.layer.0.attention.self.query.weight") if layers > 0 else off("enc.pooler.dense.weight")
+    r["embeddings"] = (0, first_layer)
+    for l in range(layers):
+        s = off(f"enc.encoder.layer.{l}.attention.self.query.weight")
+        e = off(f"enc.encoder.layer.{l + 1}.attention.self.query.weight") if l + 1 < layers else off("enc.pooler.dense.weight")
+        r[f"layer{l}"] = (s, e)
+    r["heads"] = (off("enc.pooler.dense.weight"), n_flat)
+    return r
+
+
+class GradAllReducer:
+    def __init__(self, flat_g: torch.Tensor, layout, n_flat: int, layers: int, group=None, merge_layers: int = 2):
+        self.flat_g = flat_g
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.ranges = bucket_ranges(layout, n_flat, layers)
+        self.merge = max(1, merge_layers)      # layers per bucket: ~2 x 28 MB fp32 at BERT-base
+        self.layers = layers
+        self.cuda = flat_g.is_cuda
+        self.stream = torch.cuda.Stream(device=flat_g.device) if self.cuda else None
+        self.works = []
+        self._pending_hi = None
+
+    def global_counts(self, n_labelled: int, batch: int, device):
+        """-> f32[2] device tensor (n_labelled_global, B_global); one small all-reduce."""
+        t = torch.tensor([float(n_labelled), float(batch)], dtype=torch.float32, device=device)
+        if self.world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t
+
+    def _launch(self, s, e):
+        if self.world == 1 or e <= s:
+            return
+        view = self.flat_g[s:e]
+        if self.cuda:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            with torch.cuda.stream(self.stream):
+                self.stream.wait_event(ev)
+                self.works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        else:
+            self.works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def hook(self, name: str):
+        """Called by Engine.encoder_backward when the gradients of bucket `name` are final."""
+        if name == "heads":
+            # mlm.predictions.* / pooler / itm are final; the tied E gradient is NOT (embedding scatter comes last)
+            self._launch(*self.ranges["heads"])
+        elif name.startswith("layer"):
+            l = int(name[5:])
+            if self._pending_hi is None:
+                self._pending_hi = self.ranges[name][1]
+            if l % self.merge == 0 or l == 0:
+                self._launch(self.ranges[name][0], self._pending_hi)
+                self._pending_hi = None
+        elif name == "embeddings":
+            self._launch(*self.ranges["embeddings"])
+
+    def finish(self):
+        """Make the current stream wait for every outstanding bucket."""
+        for w in self.works:
+            w.wait()
+        self.works.clear()
+        self._pending_hi = None

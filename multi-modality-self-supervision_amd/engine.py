@@ -1,0 +1,502 @@
+"""Execution engine of the CXRBERT pretraining hot path on MI355X.
+
+One flat fp32 buffer holds every parameter (plus flat grad / Adam-moment buffers and, in bf16
+mode, a flat bf16 shadow that the MFMA kernels read), so the optimizer is ONE fused kernel and
+the data-parallel gradient exchange is a handful of large contiguous RCCL all-reduces.  The
+forward and backward passes are explicit kernel schedules over the C ABI (include/medvill.h):
+no autograd graph, no tracing compiler; activations needed by the backward live in a
+workspace sized once per (B, L) -- 288 GB of HBM3E makes recomputation unnecessary.
+
+Reference semantics implemented here (paths relative to the upstream repo):
+  CXRBertEncoder.forward else-branch ......... models/cxrbert_origin.py:114-130
+  ImageBertEmbeddings ........................ models/cxrbert_origin.py:22-35
+  HF BertLayer x layers, BertPooler .......... call sites cxrbert_origin.py:72-73,126-130
+  BertPreTrainingHeads / ImageTextMatching ... models/cxrbert_origin.py:164-173,205-248
+  losses, metrics, AdamW step ................ models/train_origin.py:62-63,106-146
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+from dataclasses import asdict, dataclass
+
+import torch
+
+from . import hip_ops as ops
+from ._lib import (EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RES, EPI_BIAS_TANH, EPI_DGELU, EPI_NONE, EPI_RES, MV_BF16, MV_F32)
+
+
+@dataclass
+class ModelConfig:
+    vocab_size: int = 30522
+    hidden: int = 768
+    layers: int = 12
+    heads: int = 12
+    intermediate: int = 3072
+    max_pos: int = 512
+    type_vocab: int = 2
+    img_hidden: int = 2048
+    ln_eps: float = 1e-12
+    head_ln_eps: float = 1e-5
+
+    def to_dict(self):
+        return asdict(self)
+
+
+def _align(n: int, a: int = 64) -> int:
+    return (n + a - 1) // a * a
+
+
+def param_layout(cfg: ModelConfig):
+    """name -> (offset, shape) in the flat buffer, reference state-dict names.
+    q/k/v weights (and biases) of a layer are adjacent so the fused [3H,H] projection is a view."""
+    H, I, V = cfg.hidden, cfg.intermediate, cfg.vocab_size
+    if H % 64 or I % 64 or cfg.img_hidden % 8:
+        raise ValueError("hidden and intermediate sizes must be multiples of 64")
+    lay = OrderedDict()
+    off = 0
+
+    def add(name, shape):
+        nonlocal off
+        n = 1
+        for s in shape:
+            n *= s
+        lay[name] = (off, tuple(shape))
+        off = _align(off + n)
+
+    e = "enc.txt_embeddings."
+    add(e + "word_embeddings.weight", (V, H))
+    add(e + "position_embeddings.weight", (cfg.max_pos, H))
+    add(e + "token_type_embeddings.weight", (cfg.type_vocab, H))
+    add(e + "LayerNorm.weight", (H,))
+    add(e + "LayerNorm.bias", (H,))
+    add("enc.img_embeddings.img_embeddings.weight", (H, cfg.img_hidden))
+    add("enc.img_embeddings.img_embeddings.bias", (H,))
+    for l in range(cfg.layers):
+        p = f"enc.encoder.layer.{l}."
+        for n in ("query", "key", "value"):
+            add(p + f"attention.self.{n}.weight", (H, H))
+        for n in ("query", "key", "value"):
+            add(p + f"attention.self.{n}.bias", (H,))
+        add(p + "attention.output.dense.weight", (H, H))
+        add(p + "attention.output.dense.bias", (H,))
+        add(p + "attention.output.LayerNorm.weight", (H,))
+        add(p + "attention.output.LayerNorm.bias", (H,))
+        add(p + "intermediate.dense.weight", (I, H))
+        add(p + "intermediate.dense.bias", (I,))
+        add(p + "output.dense.weight", (H, I))
+        add(p + "output.dense.bias", (H,))
+        add(p + "output.LayerNorm.weight", (H,))
+        add(p + "output.LayerNorm.bias", (H,))
+    add("enc.pooler.dense.weight", (H, H))
+    add("enc.pooler.dense.bias", (H,))
+    add("mlm.predictions.transform.dense.weight", (H, H))
+    add("mlm.predictions.transform.dense.bias", (H,))
+    add("mlm.predictions.transform.LayerNorm.weight", (H,))
+    add("mlm.predictions.transform.LayerNorm.bias", (H,))
+    add("mlm.predictions.bias", (V,))
+    add("itm.linear.weight", (2, H))
+    add("itm.linear.bias", (2,))
+    return lay, off
+
+
+ALIASES = {  # reference state-dict aliases -> canonical tensor (cxrbert_origin.py:17-20,141,231)
+    "enc.img_embeddings.position_embeddings.weight": "enc.txt_embeddings.position_embeddings.weight",
+    "enc.img_embeddings.token_type_embeddings.weight": "enc.txt_embeddings.token_type_embeddings.weight",
+    "enc.img_embeddings.LayerNorm.weight": "enc.txt_embeddings.LayerNorm.weight",
+    "enc.img_embeddings.LayerNorm.bias": "enc.txt_embeddings.LayerNorm.bias",
+    "mlm.predictions.decoder.weight": "enc.txt_embeddings.word_embeddings.weight",
+}
+
+
+class Engine:
+    def __init__(self, cfg: ModelConfig, dtype=torch.bfloat16, device="cuda"):
+        if dtype not in (torch.float32, torch.bfloat16):
+            raise TypeError("compute dtype must be float32 or bfloat16")
+        self.cfg = cfg
+        self.adt = dtype
+        self.dt = MV_F32 if dtype == torch.float32 else MV_BF16
+        self.device = torch.device(device)
+        self.layout, self.n_flat = param_layout(cfg)
+        self.flat_p = torch.zeros(self.n_flat, dtype=torch.float32, device=self.device)
+        self.flat_g = None
+        self.flat_m = None
+        self.flat_v = None
+        self.shadow = torch.zeros(self.n_flat, dtype=torch.bfloat16, device=self.device) if self.dt == MV_BF16 else None
+        self.shadow_dirty = True
+        self._ws = {}
+        self._gemm_ws = None
+        self._bind()
+
+    # ------------------------------------------------------------------ storage
+    def _bind(self):
+        self.p, self.w = {}, {}
+        src_w = self.shadow if self.dt == MV_BF16 else self.flat_p
+        for name, (off, shape) in self.layout.items():
+            n = math.prod(shape)
+            self.p[name] = self.flat_p[off:off + n].view(shape)
+            self.w[name] = src_w[off:off + n].view(shape)
+        self.g = {}
+        if self.flat_g is not None:
+            for name, (off, shape) in self.layout.items():
+                self.g[name] = self.flat_g[off:off + math.prod(shape)].view(shape)
+
+    def ensure_grad(self):
+        if self.flat_g is None:
+            self.flat_g = torch.zeros_like(self.flat_p)
+            self._bind()
+
+    def ensure_opt(self):
+        self.ensure_grad()
+        if self.flat_m is None:
+            self.flat_m = torch.zeros_like(self.flat_p)
+            self.flat_v = torch.zeros_like(self.flat_p)
+
+    def to(self, device):
+        device = torch.device(device)
+        if device == self.device:
+            return self
+        # host storage is allowed (state-dict I/O); every kernel call requires device tensors and raises otherwise
+        for k in ("flat_p", "flat_g", "flat_m", "flat_v", "shadow"):
+            t = getattr(self, k)
+            if t is not None:
+                setattr(self, k, t.to(device))
+        self.device = device
+        self._ws.clear()
+        self._gemm_ws = None
+        self._bind()
+        return self
+
+    def sync_shadow(self):
+        """bf16 mode: refresh the bf16 copy the MFMA kernels read from the fp32 master weights."""
+        if self.dt == MV_BF16:
+            ops.cast(self.flat_p, self.shadow, self.n_flat)
+        self.shadow_dirty = False
+
+    def zero_grad(self):
+        self.ensure_grad()
+        self.flat_g.zero_()
+
+    def qkv_views(self, l):
+        """fused [3H,H] weight (compute dtype), [3H] bias (f32) and their grads for layer l."""
+        H = self.cfg.hidden
+        name = f"enc.encoder.layer.{l}.attention.self.query.weight"
+        bname = f"enc.encoder.layer.{l}.attention.self.query.bias"
+        off, _ = self.layout[name]
+        boff, _ = self.layout[bname]
+        src_w = self.shadow if self.dt == MV_BF16 else self.flat_p
+        W = src_w[off:off + 3 * H * H].view(3 * H, H)
+        b = self.flat_p[boff:boff + 3 * H]
+        gW = gb = None
+        if self.flat_g is not None:
+            gW = self.flat_g[off:off + 3 * H * H].view(3 * H, H)
+            gb = self.flat_g[boff:boff + 3 * H]
+        return W, b, gW, gb
+
+    # ------------------------------------------------------------------ workspaces
+    def _buf(self, key, shape, dtype):
+        t = self._ws.get(key)
+        n = math.prod(shape)
+        if t is None or t.numel() < n or t.dtype != dtype:
+            t = torch.empty(n, dtype=dtype, device=self.device)
+            self._ws[key] = t
+        return t[:n].view(shape)
+
+    def _gemm_workspace(self, nfloat):
+        if self._gemm_ws is None or self._gemm_ws.numel() < nfloat:
+            self._gemm_ws = torch.empty(nfloat, dtype=torch.float32, device=self.device)
+        return self._gemm_ws
+
+    # dW[No,Ko] = dy[Mtok,No]^T . x[Mtok,Ko]  (contraction over tokens; split-K when the tile grid is small)
+    def _dW(self, dy, x, gW, No, Ko, Mtok, lda, ldb, ldc=None):
+        tiles = ((No + 127) // 128) * ((Ko + 127) // 128)
+        splitk = 1
+        if self.dt == MV_BF16 and Mtok >= 2048 and tiles < 512:
+            splitk = max(1, min(16, 768 // tiles, Mtok // 1024))
+        ws = self._gemm_workspace(splitk * No * Ko) if splitk > 1 else None
+        ops.gemm(dy, x, gW, ta=True, tb=True, M=No, N=Ko, K=Mtok, lda=lda, ldb=ldb, ldc=ldc, splitk=splitk, ws=ws)
+
+    # ------------------------------------------------------------------ encoder forward
+    def encoder_forward(self, cls_tok, input_txt, attn_mask, segment, img_feats, img_pos, sep_tok):
+        cfg, dt, adt, dev = self.cfg, self.dt, self.adt, self.device
+        H, A, I, D = cfg.hidden, cfg.heads, cfg.intermediate, cfg.img_hidden
+        dh = H // A
+        B, T = input_txt.shape
+        N = img_feats.shape[1]
+        Lq = N + T + 2
+        M = B * Lq
+        if attn_mask.shape[0] != B or attn_mask.shape[-1] != Lq:
+            raise ValueError(f"attn_mask shape {tuple(attn_mask.shape)} does not match L = N+T+2 = {Lq}")
+        if self.shadow_dirty:
+            self.sync_shadow()
+        f32 = torch.float32
+        S = self.S = dict(B=B, T=T, N=N, L=Lq, M=M)
+        i64 = torch.int64
+        S["cls_tok"] = cls_tok.to(dev, i64).contiguous().view(-1)
+        S["sep_tok"] = sep_tok.to(dev, i64).contiguous().view(-1)
+        S["txt"] = input_txt.to(dev, i64).contiguous()
+        S["segment"] = segment.to(dev, i64).contiguous()
+        S["img_pos"] = img_pos.to(dev, i64).contiguous()
+        # region features -> compute dtype (kept: the image projection's weight gradient needs them)
+        feats_in = img_feats.to(dev).contiguous().view(B * N, D)
+        if feats_in.dtype not in (f32, torch.bfloat16):
+            feats_in = feats_in.float()
+        if feats_in.dtype == adt:
+            feats = feats_in
+        else:
+            feats = self._buf("feats", (B * N, D), adt)
+            ops.cast(feats_in, feats, B * N * D)
+        S["feats"] = feats
+        # packed mask
+        W32, Tt = (Lq + 31) // 32, (Lq + 63) // 64
+        bits = self._buf("bits", (B, Lq, W32), torch.int32)
+        tinfo = self._buf("tinfo", (B, Tt, Tt), torch.uint8)
+        ops.mask_pack(attn_mask.to(dev), bits, tinfo)
+        S["bits"], S["tinfo"] = bits, tinfo
+        # image projection + embeddings
+        e = "enc.txt_embeddings."
+        imgproj = self._buf("imgproj", (B * N, H), adt)
+        ops.gemm(feats, self.w["enc.img_embeddings.img_embeddings.weight"], imgproj, M=B * N, N=H, K=D,
+                 bias=self.p["enc.img_embeddings.img_embeddings.bias"], epi=EPI_BIAS)
+        x = self._buf("x0", (M, H), adt)
+        pre0 = self._buf("pre0", (M, H), f32)
+        mean0, rstd0 = self._buf("mean0", (M,), f32), self._buf("rstd0", (M,), f32)
+        ops.embed_fwd(dt, S["cls_tok"], S["txt"], S["segment"], S["img_pos"], S["sep_tok"], imgproj,
+                      self.w[e + "word_embeddings.weight"], self.w[e + "position_embeddings.weight"],
+                      self.w[e + "token_type_embeddings.weight"], self.p[e + "LayerNorm.weight"], self.p[e + "LayerNorm.bias"],
+                      x, pre0, mean0, rstd0, B, N, T, H, cfg.vocab_size, cfg.max_pos, cfg.ln_eps)
+        S["layers"] = []
+        for l in range(cfg.layers):
+            p = f"enc.encoder.layer.{l}."
+            Wqkv, bqkv, _, _ = self.qkv_views(l)
+            a_ = {}
+            a_["x"] = x
+            qkv = a_["qkv"] = self._buf(f"qkv{l}", (M, 3 * H), adt)
+            ops.gemm(x, Wqkv, qkv, M=M, N=3 * H, K=H, bias=bqkv, epi=EPI_BIAS)
+            ctx = a_["ctx"] = self._buf(f"ctx{l}", (M, H), adt)
+            lse = a_["lse"] = self._buf(f"lse{l}", (B, A, Lq), f32)
+            ops.attn_fwd(qkv, bits, tinfo, ctx, lse, B, Lq, A, dh)
+            pre1 = a_["pre1"] = self._buf(f"pre1_{l}", (M, H), f32)
+            ops.gemm(ctx, self.w[p + "attention.output.dense.weight"], pre1, M=M, N=H, K=H,
+                     bias=self.p[p + "attention.output.dense.bias"], epi=EPI_BIAS_RES, r=x)
+            a1 = a_["a"] = self._buf(f"a{l}", (M, H), adt)
+            a_["mean1"], a_["rstd1"] = self._buf(f"mean1_{l}", (M,), f32), self._buf(f"rstd1_{l}", (M,), f32)
+            ops.layernorm_fwd(pre1, self.p[p + "attention.output.LayerNorm.weight"], self.p[p + "attention.output.LayerNorm.bias"],
+                              a1, a_["mean1"], a_["rstd1"], M, H, cfg.ln_eps)
+            act = a_["i"] = self._buf(f"i{l}", (M, I), adt)
+            z = a_["z"] = self._buf(f"z{l}", (M, I), adt)
+            ops.gemm(a1, self.w[p + "intermediate.dense.weight"], act, M=M, N=I, K=H, bias=self.p[p + "intermediate.dense.bias"],
+                     epi=EPI_BIAS_GELU, c2=z)
+            pre2 = a_["pre2"] = self._buf(f"pre2_{l}", (M, H), f32)
+            ops.gemm(act, self.w[p + "output.dense.weight"], pre2, M=M, N=H, K=I, bias=self.p[p + "output.dense.bias"],
+                     epi=EPI_BIAS_RES, r=a1)
+            x = self._buf(f"x{l + 1}", (M, H), adt)
+            a_["mean2"], a_["rstd2"] = self._buf(f"mean2_{l}", (M,), f32), self._buf(f"rstd2_{l}", (M,), f32)
+            ops.layernorm_fwd(pre2, self.p[p + "output.LayerNorm.weight"], self.p[p + "output.LayerNorm.bias"], x, a_["mean2"],
+                              a_["rstd2"], M, H, cfg.ln_eps)
+            S["layers"].append(a_)
+        S["hidden"] = x
+        pooled = S["pooled"] = self._buf("pooled", (B, H), adt)
+        ops.gemm(x, self.w["enc.pooler.dense.weight"], pooled, M=B, N=H, K=H, lda=Lq * H, bias=self.p["enc.pooler.dense.bias"],
+                 epi=EPI_BIAS_TANH)
+        return x.view(B, Lq, H), pooled
+
+    # ------------------------------------------------------------------ heads (shared pieces)
+    def _itm_forward(self):
+        S, H = self.S, self.cfg.hidden
+        itm = S["itm"] = self._buf("itm", (S["B"], 2), torch.float32)
+        ops.gemm(S["pooled"], self.w["itm.linear.weight"], itm, M=S["B"], N=2, K=H, bias=self.p["itm.linear.bias"], epi=EPI_BIAS)
+        return itm
+
+    def _mlm_forward(self, xr, R, tag, pad=True):
+        """xr [R,H] (compute dtype) -> logits [R, Vp] f32 (Vp = V rounded up to 8 when `pad`; pad columns unspecified)."""
+        cfg, H, V = self.cfg, self.cfg.hidden, self.cfg.vocab_size
+        f32 = torch.float32
+        Vp = (V + 7) // 8 * 8 if pad else V
+        hs = self.S[tag] = {}
+        hs["xr"], hs["R"], hs["Vp"] = xr, R, Vp
+        tact = hs["tact"] = self._buf(tag + "tact", (R, H), f32)
+        tz = hs["tz"] = self._buf(tag + "tz", (R, H), f32)
+        ops.gemm(xr, self.w["mlm.predictions.transform.dense.weight"], tact, M=R, N=H, K=H,
+                 bias=self.p["mlm.predictions.transform.dense.bias"], epi=EPI_BIAS_GELU, c2=tz)
+        t = hs["t"] = self._buf(tag + "t", (R, H), self.adt)
+        hs["mean"], hs["rstd"] = self._buf(tag + "mean", (R,), f32), self._buf(tag + "rstd", (R,), f32)
+        ops.layernorm_fwd(tact, self.p["mlm.predictions.transform.LayerNorm.weight"],
+                          self.p["mlm.predictions.transform.LayerNorm.bias"], t, hs["mean"], hs["rstd"], R, H, cfg.head_ln_eps)
+        logits = hs["logits"] = torch.empty((R, Vp), dtype=f32, device=self.device)
+        ops.gemm(t, self.w["enc.txt_embeddings.word_embeddings.weight"], logits, M=R, N=V, K=H, ldc=Vp,
+                 bias=self.p["mlm.predictions.bias"], epi=EPI_BIAS)
+        return logits
+
+    def _mlm_backward(self, dlogits, tag):
+        """dlogits [R, Vp] compute dtype (pad columns zero) -> grads of decoder/bias/transform; returns d(xr) [R,H]."""
+        cfg, H, V = self.cfg, self.cfg.hidden, self.cfg.vocab_size
+        hs = self.S[tag]
+        R, Vp = hs["R"], hs["Vp"]
+        g = self.g
+        ops.colsum(dlogits, Vp, R, V, g["mlm.predictions.bias"], accumulate=True)
+        # tied decoder: dE = dlogits^T . t  (the embedding scatter-add comes later, in embed_bwd)
+        self._dW(dlogits, hs["t"], g["enc.txt_embeddings.word_embeddings.weight"], V, H, R, lda=Vp, ldb=H)
+        dt_ = self._buf(tag + "dt", (R, H), self.adt)
+        ops.gemm(dlogits, self.w["enc.txt_embeddings.word_embeddings.weight"], dt_, tb=True, M=R, N=H, K=V, lda=Vp, ldb=H)
+        dtact = self._buf(tag + "dtact", (R, H), self.adt)
+        ops.layernorm_bwd(dt_, hs["tact"], hs["mean"], hs["rstd"], self.p["mlm.predictions.transform.LayerNorm.weight"], dtact,
+                          g["mlm.predictions.transform.LayerNorm.weight"], g["mlm.predictions.transform.LayerNorm.bias"], None, R, H)
+        # dtz = dtact * gelu'(tz); tz is f32, dtact compute dtype -> bring tz to compute dtype first
+        if self.dt == MV_BF16:
+            tzc = self._buf(tag + "tzc", (R, H), self.adt)
+            ops.cast(hs["tz"], tzc, R * H)
+        else:
+            tzc = hs["tz"]
+        dtz = self._buf(tag + "dtz", (R, H), self.adt)
+        ops.dact(0, dtact, tzc, dtz, R * H)
+        ops.colsum(dtz, H, R, H, g["mlm.predictions.transform.dense.bias"], accumulate=True)
+        self._dW(dtz, hs["xr"], g["mlm.predictions.transform.dense.weight"], H, H, R, lda=H, ldb=H)
+        dxr = self._buf(tag + "dxr", (R, H), self.adt)
+        ops.gemm(dtz, self.w["mlm.predictions.transform.dense.weight"], dxr, tb=True, M=R, N=H, K=H)
+        return dxr
+
+    def _itm_backward(self, ditm8):
+        """ditm8 [B,8] compute dtype (cols 2..7 zero). Adds the pooler-path gradient into dhidden rows b*L."""
+        S, H = self.S, self.cfg.hidden
+        B, Lq = S["B"], S["L"]
+        g = self.g
+        ops.colsum(ditm8, 8, B, 2, g["itm.linear.bias"], accumulate=True)
+        self._dW(ditm8, S["pooled"], g["itm.linear.weight"], 2, H, B, lda=8, ldb=H)
+        dpool = self._buf("dpool", (B, H), self.adt)
+        ops.gemm(ditm8, self.w["itm.linear.weight"], dpool, tb=True, M=B, N=H, K=2, lda=8, ldb=H)
+        dpre = self._buf("dpoolpre", (B, H), self.adt)
+        ops.dact(1, dpool, S["pooled"], dpre, B * H)
+        ops.colsum(dpre, H, B, H, g["enc.pooler.dense.bias"], accumulate=True)
+        self._dW(dpre, S["hidden"], g["enc.pooler.dense.weight"], H, H, B, lda=H, ldb=Lq * H)
+        dh0 = self._buf("dh0", (B, H), self.adt)
+        ops.gemm(dpre, self.w["enc.pooler.dense.weight"], dh0, tb=True, M=B, N=H, K=H)
+        rows0 = self._buf("rows0", (B,), torch.int32)
+        rows0.copy_(torch.arange(B, device=self.device, dtype=torch.int32) * Lq)
+        ops.scatter_rows(dh0, H, rows0, B, H, S["dhidden"], H, accumulate=True)
+
+    # ------------------------------------------------------------------ drop-in heads: full logits
+    def heads_full(self):
+        """(mlm [B,L,V] f32, itm [B,2] f32) over ALL positions -- the CXRBERT.forward contract."""
+        S, V = self.S, self.cfg.vocab_size
+        logits = self._mlm_forward(S["hidden"], S["M"], "hf_", pad=False)
+        itm = self._itm_forward()
+        return logits.view(S["B"], S["L"], V), itm.clone()
+
+    def heads_full_backward(self, dmlm, ditm):
+        S, H, V = self.S, self.cfg.hidden, self.cfg.vocab_size
+        M, B = S["M"], S["B"]
+        Vp = (V + 7) // 8 * 8
+        self.S["hf_"]["Vp"] = Vp
+        self.ensure_grad()
+        dhid = S["dhidden"] = self._buf("dhidden", (M, H), self.adt)
+        if dmlm is not None:
+            dl = torch.empty((M, Vp), dtype=self.adt, device=self.device)
+            ops.cast2d(dmlm.contiguous().view(M, V).float(), V, dl, Vp, M, V)
+            dxr = self._mlm_backward(dl, "hf_")
+            ops.cast(dxr, dhid, M * H)
+        else:
+            dhid.zero_()
+        if ditm is not None:
+            d8 = self._buf("ditm8", (B, 8), self.adt)
+            ops.cast2d(ditm.contiguous().float(), 2, d8, 8, B, 2)
+            self._itm_backward(d8)
+
+    # ------------------------------------------------------------------ training heads: labelled rows only
+    def heads_train(self, label_rows, label_ids, is_aligned, mlm_scale_dev=None, mlm_scale=None, itm_scale=None,
+                    compute_grad=True, itm_scale_dev=None):
+        """Fused MLM (labelled rows only) + ITM losses, metrics and their gradients into dhidden.
+        label_rows int32 [R]: flat indices b*L+i of positions with a label; label_ids int32 [R].
+        Returns stats f32[6] = [mlm_nll_sum, n_labelled, mlm_correct, itm_nll_sum, B, itm_correct]."""
+        S, H, V = self.S, self.cfg.hidden, self.cfg.vocab_size
+        M, B = S["M"], S["B"]
+        R = int(label_rows.numel())
+        stats = torch.zeros(6, dtype=torch.float32, device=self.device)
+        if compute_grad:
+            self.ensure_grad()
+            dhid = S["dhidden"] = self._buf("dhidden", (M, H), self.adt)
+            dhid.zero_()
+        if R > 0:
+            xr = self._buf("ht_xr", (R, H), self.adt)
+            ops.gather_rows(S["hidden"], H, label_rows, R, H, xr, H)
+            logits = self._mlm_forward(xr, R, "ht_")
+            Vp = logits.shape[1]
+            dl = torch.empty((R, Vp), dtype=self.adt, device=self.device) if compute_grad else None
+            ops.ce_fwd_bwd(logits, Vp, label_ids, R, V, stats[0:3], dl, Vp, grad_scale_dev=mlm_scale_dev,
+                           grad_scale=(mlm_scale if mlm_scale is not None else 1.0 / R))
+            if compute_grad:
+                dxr = self._mlm_backward(dl, "ht_")
+                ops.scatter_rows(dxr, H, label_rows, R, H, dhid, H, accumulate=False)
+        itm = self._itm_forward()
+        d8 = self._buf("ditm8", (B, 8), self.adt) if compute_grad else None
+        ops.ce_fwd_bwd(itm, 2, is_aligned, B, 2, stats[3:6], d8, 8, grad_scale_dev=itm_scale_dev,
+                       grad_scale=(itm_scale if itm_scale is not None else 1.0 / B))
+        if compute_grad:
+            self._itm_backward(d8)
+        return stats
+
+    # ------------------------------------------------------------------ encoder backward
+    def encoder_backward(self, bucket_hook=None):
+        """Consumes S['dhidden'] (grad w.r.t. the last hidden states); fills the flat gradient.
+        bucket_hook(name) is called when the gradients of a contiguous parameter range are final
+        ('heads', 'layer<l>', 'embeddings') so a data-parallel driver can start its all-reduce."""
+        cfg, S = self.cfg, self.S
+        H, A, I, D = cfg.hidden, cfg.heads, cfg.intermediate, cfg.img_hidden
+        dh = H // A
+        B, Lq, M, N, T = S["B"], S["L"], S["M"], S["N"], S["T"]
+        adt, g = self.adt, self.g
+        dy = S["dhidden"]
+        if bucket_hook:
+            bucket_hook("heads")
+        dpre = self._buf("bw_dpre", (M, H), adt)
+        dz = self._buf("bw_dz", (M, I), adt)
+        dctx = self._buf("bw_dctx", (M, H), adt)
+        dqkv = self._buf("bw_dqkv", (M, 3 * H), adt)
+        delta = self._buf("bw_delta", (B, A, Lq), torch.float32)
+        da = self._buf("bw_da", (M, H), adt)
+        dxb = [self._buf("bw_dx0", (M, H), adt), self._buf("bw_dx1", (M, H), adt)]
+        for l in reversed(range(cfg.layers)):
+            p = f"enc.encoder.layer.{l}."
+            a_ = S["layers"][l]
+            Wqkv, _, gWqkv, gbqkv = self.qkv_views(l)
+            # LN2 backward (+ bias grad of output.dense)
+            ops.layernorm_bwd(dy, a_["pre2"], a_["mean2"], a_["rstd2"], self.p[p + "output.LayerNorm.weight"], dpre,
+                              g[p + "output.LayerNorm.weight"], g[p + "output.LayerNorm.bias"], g[p + "output.dense.bias"], M, H)
+            self._dW(dpre, a_["i"], g[p + "output.dense.weight"], H, I, M, lda=H, ldb=I)
+            ops.gemm(dpre, self.w[p + "output.dense.weight"], dz, tb=True, M=M, N=I, K=H, epi=EPI_DGELU, r=a_["z"])
+            ops.colsum(dz, I, M, I, g[p + "intermediate.dense.bias"], accumulate=True)
+            self._dW(dz, a_["a"], g[p + "intermediate.dense.weight"], I, H, M, lda=I, ldb=H)
+            ops.gemm(dz, self.w[p + "intermediate.dense.weight"], da, tb=True, M=M, N=H, K=I, epi=EPI_RES, r=dpre)
+            # LN1 backward (+ bias grad of attention.output.dense)
+            ops.layernorm_bwd(da, a_["pre1"], a_["mean1"], a_["rstd1"], self.p[p + "attention.output.LayerNorm.weight"], dpre,
+                              g[p + "attention.output.LayerNorm.weight"], g[p + "attention.output.LayerNorm.bias"],
+                              g[p + "attention.output.dense.bias"], M, H)
+            self._dW(dpre, a_["ctx"], g[p + "attention.output.dense.weight"], H, H, M, lda=H, ldb=H)
+            ops.gemm(dpre, self.w[p + "attention.output.dense.weight"], dctx, tb=True, M=M, N=H, K=H)
+            ops.attn_bwd(a_["qkv"], a_["ctx"], dctx, a_["lse"], S["bits"], S["tinfo"], dqkv, delta, B, Lq, A, dh)
+            ops.colsum(dqkv, 3 * H, M, 3 * H, gbqkv, accumulate=True)
+            self._dW(dqkv, a_["x"], gWqkv, 3 * H, H, M, lda=3 * H, ldb=H)
+            dx = dxb[l & 1]          # never the buffer dy currently lives in
+            ops.gemm(dqkv, Wqkv, dx, tb=True, M=M, N=H, K=3 * H, epi=EPI_RES, r=dpre)
+            dy = dx
+            if bucket_hook:
+                bucket_hook(f"layer{l}")
+        e = "enc.txt_embeddings."
+        dimg = self._buf("bw_dimg", (B * N, H), adt)
+        ops.embed_bwd(self.dt, dy, self._ws["pre0"][:M * H].view(M, H), self._ws["mean0"][:M], self._ws["rstd0"][:M],
+                      self.p[e + "LayerNorm.weight"], S["cls_tok"], S["txt"], S["segment"], S["img_pos"], S["sep_tok"],
+                      g[e + "word_embeddings.weight"], g[e + "position_embeddings.weight"], g[e + "token_type_embeddings.weight"],
+                      g[e + "LayerNorm.weight"], g[e + "LayerNorm.bias"], dimg, B, N, T, H, cfg.vocab_size, cfg.max_pos)
+        if N > 0:
+            ops.colsum(dimg, H, B * N, H, g["enc.img_embeddings.img_embeddings.bias"], accumulate=True)
+            self._dW(dimg, S["feats"], g["enc.img_embeddings.img_embeddings.weight"], H, D, B * N, lda=H, ldb=D)
+        if bucket_hook:
+            bucket_hook("embeddings")
+
+    # ------------------------------------------------------------------ optimizer
+    def adamw_step(self, step, lr=1e-5, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.0, correct_bias=True, grad_scale=1.0):
+        """HF AdamW over the whole flat buffer in one kernel; also refreshes the bf16 shadow."""
+        self.ensure_opt()
+        ops.adamw_step(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.shadow, self.n_flat, lr, betas[0], betas[1], eps,
+                       weight_decay, step, correct_bias, grad_scale)
+        self.shadow_dirty = False

@@ -1,0 +1,139 @@
+"""Tensor-level wrappers over the C ABI (include/medvill.h).  torch is used for device memory
+and streams only; every wrapper enqueues on torch's current stream and returns immediately."""
+from __future__ import annotations
+
+import torch
+
+from . import _lib as L
+from ._lib import (EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RES, EPI_BIAS_TANH, EPI_DGELU, EPI_NONE, EPI_RES, MV_BF16,  # noqa: F401
+                   MV_F32)
+
+
+def _lib():
+    return L.load()
+
+
+def gemm(a, b, c, *, ta=False, tb=False, M, N, K, lda=None, ldb=None, ldc=None, bias=None, epi=EPI_NONE, r=None, ldr=None,
+         c2=None, ldc2=None, splitk=1, ws=None, accumulate=False):
+    """c[M,N] = epi(op(a)[M,K] . op(b)[K,N]); see mv_gemm in include/medvill.h."""
+    L.require_cuda(a, b, c, bias, r, c2, ws)
+    lda = lda if lda is not None else (M if ta else K)
+    ldb = ldb if ldb is not None else (N if tb else K)
+    ldc = ldc if ldc is not None else N
+    ldr = ldr if ldr is not None else N
+    ldc2 = ldc2 if ldc2 is not None else N
+    if a.dtype != b.dtype:
+        raise TypeError("gemm operands must share a dtype")
+    if bias is not None and bias.dtype != torch.float32:
+        raise TypeError("bias must be f32")
+    rc = _lib().mv_gemm(L.dt_of(a), int(ta), int(tb), M, N, K, L.ptr(a), lda, L.ptr(b), ldb, L.ptr(c), ldc, L.dt_of(c),
+                        L.ptr(bias), epi, L.ptr(r), ldr, L.dt_of(r) if r is not None else 0, L.ptr(c2), ldc2, splitk,
+                        L.ptr(ws), (ws.numel() * 4) if ws is not None else 0, int(accumulate), L.stream_ptr())
+    L.check(rc, f"mv_gemm(M={M},N={N},K={K},ta={ta},tb={tb},epi={epi})")
+    return c
+
+
+def mask_pack(mask, bits, tileinfo):
+    L.require_cuda(mask, bits, tileinfo)
+    if mask.dtype != torch.int64:
+        raise TypeError("attn_mask must be int64 (as built by the reference Dataset)")
+    if mask.dim() not in (2, 3):
+        raise NotImplementedError          # cxrbert_origin.py:80-81
+    B, Lq = mask.shape[0], mask.shape[-1]
+    rc = _lib().mv_mask_pack(L.ptr(mask.contiguous()), mask.dim(), B, Lq, L.ptr(bits), L.ptr(tileinfo), L.stream_ptr())
+    L.check(rc, "mv_mask_pack")
+
+
+def attn_fwd(qkv, bits, tileinfo, ctx, lse, B, Lq, A, dh):
+    rc = _lib().mv_attn_fwd(L.dt_of(qkv), L.ptr(qkv), L.ptr(bits), L.ptr(tileinfo), L.ptr(ctx), L.ptr(lse), B, Lq, A, dh,
+                            L.stream_ptr())
+    L.check(rc, "mv_attn_fwd")
+
+
+def attn_bwd(qkv, ctx, dctx, lse, bits, tileinfo, dqkv, delta, B, Lq, A, dh):
+    rc = _lib().mv_attn_bwd(L.dt_of(qkv), L.ptr(qkv), L.ptr(ctx), L.ptr(dctx), L.ptr(lse), L.ptr(bits), L.ptr(tileinfo),
+                            L.ptr(dqkv), L.ptr(delta), B, Lq, A, dh, L.stream_ptr())
+    L.check(rc, "mv_attn_bwd")
+
+
+def layernorm_fwd(x, gamma, beta, y, mean, rstd, M, H, eps):
+    rc = _lib().mv_layernorm_fwd(L.dt_of(y), L.ptr(x), L.dt_of(x), L.ptr(gamma), L.ptr(beta), L.ptr(y), L.ptr(mean),
+                                 L.ptr(rstd), M, H, float(eps), L.stream_ptr())
+    L.check(rc, "mv_layernorm_fwd")
+
+
+def layernorm_bwd(dy, x, mean, rstd, gamma, dx, dgamma, dbeta, colsum, M, H):
+    rc = _lib().mv_layernorm_bwd(L.dt_of(dy), L.ptr(dy), L.ptr(x), L.dt_of(x), L.ptr(mean), L.ptr(rstd), L.ptr(gamma),
+                                 L.ptr(dx), L.ptr(dgamma), L.ptr(dbeta), L.ptr(colsum), M, H, L.stream_ptr())
+    L.check(rc, "mv_layernorm_bwd")
+
+
+def embed_fwd(dt, cls_tok, txt, segment, img_pos, sep_tok, imgproj, E, P, Ty, gamma, beta, x0, pre, mean, rstd, B, N, T, H, V,
+              maxpos, eps):
+    rc = _lib().mv_embed_fwd(dt, L.ptr(cls_tok), L.ptr(txt), L.ptr(segment), L.ptr(img_pos), L.ptr(sep_tok), L.ptr(imgproj),
+                             L.ptr(E), L.ptr(P), L.ptr(Ty), L.ptr(gamma), L.ptr(beta), L.ptr(x0), L.ptr(pre), L.ptr(mean),
+                             L.ptr(rstd), B, N, T, H, V, maxpos, float(eps), L.stream_ptr())
+    L.check(rc, "mv_embed_fwd")
+
+
+def embed_bwd(dt, dx0, pre, mean, rstd, gamma, cls_tok, txt, segment, img_pos, sep_tok, dE, dP, dTy, dgamma, dbeta, dimgproj, B,
+              N, T, H, V, maxpos):
+    rc = _lib().mv_embed_bwd(dt, L.ptr(dx0), L.ptr(pre), L.ptr(mean), L.ptr(rstd), L.ptr(gamma), L.ptr(cls_tok), L.ptr(txt),
+                             L.ptr(segment), L.ptr(img_pos), L.ptr(sep_tok), L.ptr(dE), L.ptr(dP), L.ptr(dTy), L.ptr(dgamma),
+                             L.ptr(dbeta), L.ptr(dimgproj), B, N, T, H, V, maxpos, L.stream_ptr())
+    L.check(rc, "mv_embed_bwd")
+
+
+def ce_fwd_bwd(logits, ld, labels, R, V, out, dlogits=None, ldd=0, grad_scale_dev=None, grad_scale=1.0):
+    if labels.dtype != torch.int32:
+        raise TypeError("labels must be int32")
+    rc = _lib().mv_ce_fwd_bwd(L.ptr(logits), L.dt_of(logits), ld, L.ptr(labels), R, V, L.ptr(out), L.ptr(dlogits),
+                              L.dt_of(dlogits) if dlogits is not None else 0, ldd, L.ptr(grad_scale_dev), float(grad_scale),
+                              L.stream_ptr())
+    L.check(rc, "mv_ce_fwd_bwd")
+
+
+def gather_rows(src, lds, rows, R, H, dst, ldd):
+    rc = _lib().mv_gather_rows(L.dt_of(src), L.ptr(src), lds, L.ptr(rows), R, H, L.ptr(dst), ldd, L.stream_ptr())
+    L.check(rc, "mv_gather_rows")
+
+
+def scatter_rows(src, lds, rows, R, H, dst, ldd, accumulate=False):
+    rc = _lib().mv_scatter_rows(L.dt_of(src), L.ptr(src), lds, L.ptr(rows), R, H, L.ptr(dst), ldd, int(accumulate),
+                                L.stream_ptr())
+    L.check(rc, "mv_scatter_rows")
+
+
+def colsum(x, ldx, M, N, out, accumulate=True):
+    rc = _lib().mv_colsum(L.dt_of(x), L.ptr(x), ldx, M, N, L.ptr(out), int(accumulate), L.stream_ptr())
+    L.check(rc, "mv_colsum")
+
+
+def add(a, b, c, n):
+    rc = _lib().mv_add(L.dt_of(a), L.ptr(a), L.ptr(b), L.ptr(c), n, L.stream_ptr())
+    L.check(rc, "mv_add")
+
+
+def dact(mode, dy, z, out, n):
+    rc = _lib().mv_dact(L.dt_of(dy), mode, L.ptr(dy), L.ptr(z), L.ptr(out), n, L.stream_ptr())
+    L.check(rc, "mv_dact")
+
+
+def cast(src, dst, n):
+    rc = _lib().mv_cast(L.ptr(src), L.dt_of(src), L.ptr(dst), L.dt_of(dst), n, L.stream_ptr())
+    L.check(rc, "mv_cast")
+
+
+def cast2d(src, lds, dst, ldd, rows, cols):
+    rc = _lib().mv_cast2d(L.ptr(src), L.dt_of(src), lds, L.ptr(dst), L.dt_of(dst), ldd, rows, cols, L.stream_ptr())
+    L.check(rc, "mv_cast2d")
+
+
+def adamw_step(p, g, m, v, shadow, n, lr, b1, b2, eps, wd, step, correct_bias=True, grad_scale=1.0):
+    rc = _lib().mv_adamw_step(L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), L.ptr(shadow), n, float(lr), float(b1), float(b2),
+                              float(eps), float(wd), int(step), int(correct_bias), float(grad_scale), L.stream_ptr())
+    L.check(rc, "mv_adamw_step")
+
+
+def set_impl(impl: int):
+    _lib().mv_set_impl(int(impl))

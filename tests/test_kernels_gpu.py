@@ -1,0 +1,369 @@
+"""GPU parity tests of the individual HIP kernels, called through the C ABI (ctypes), against
+plain fp32/fp64 torch restatements of the same op on the same (already rounded) inputs.
+Tolerances: f32 path 1e-4 relative-to-scale (it is exact fp32 arithmetic in a different order);
+bf16 path: fp32-accumulated results compared at 2e-3 before output rounding, 1e-2 after."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import medvill_amd as mv                                   # noqa: E402
+from medvill_amd import hip_ops as ops                      # noqa: E402
+from medvill_amd import data as D                           # noqa: E402
+from medvill_amd._lib import (EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RES, EPI_BIAS_TANH, EPI_DGELU, EPI_NONE, EPI_RES)  # noqa: E402
+
+DEV = "cuda"
+
+
+def rnd(shape, dtype, seed, scale=1.0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(dtype).to(DEV)
+
+
+def relerr(got, ref):
+    ref = ref.double()
+    return float((got.double() - ref).abs().max() / (ref.abs().max() + 1e-30))
+
+
+def gelu(x):
+    return x * 0.5 * (1.0 + torch.erf(x / math.sqrt(2.0)))
+
+
+def dgelu(z):
+    return 0.5 * (1 + torch.erf(z / math.sqrt(2.0))) + z * torch.exp(-0.5 * z * z) / math.sqrt(2 * math.pi)
+
+
+# ------------------------------------------------------------------------------------------ GEMM
+GEMM_SHAPES = [(256, 256, 256), (130, 70, 200), (1024, 768, 768), (64, 2, 768), (96, 1000, 128), (517, 264, 3072)]
+
+
+@pytest.mark.parametrize("impl", ["mfma", "simple_bf16", "f32"])
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 1), (1, 0)])
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+def test_gemm_layouts(impl, ta, tb, M, N, K):
+    dt = torch.float32 if impl == "f32" else torch.bfloat16
+    ops.set_impl(1 if impl == "simple_bf16" else 0)
+    try:
+        pad = lambda n: (n + 7) // 8 * 8
+        lda = pad(M if ta else K) + 8
+        ldb = pad(N if tb else K) + 16
+        a = rnd((K if ta else M, lda), dt, 1)
+        b = rnd((K if tb else N, ldb), dt, 2)
+        # zero the padding of k-contiguous operands (contract of mv_gemm for K % 8 != 0)
+        if not ta:
+            a[:, K:] = 0
+        if not tb:
+            b[:, K:] = 0
+        c = torch.full((M, N + 3), 7.0, dtype=torch.float32, device=DEV)
+        ops.gemm(a, b, c, ta=bool(ta), tb=bool(tb), M=M, N=N, K=K, lda=lda, ldb=ldb, ldc=N + 3)
+        A = (a[:, :M].t() if ta else a[:, :K]).float()
+        Bm = (b[:, :N] if tb else b[:, :K].t()).float()
+        ref = A.double() @ Bm.double()
+        assert relerr(c[:, :N], ref) < (1e-5 if impl == "f32" else 2e-5) * math.sqrt(K)
+        assert (c[:, N:] == 7.0).all()           # nothing written outside [M,N]
+    finally:
+        ops.set_impl(0)
+
+
+@pytest.mark.parametrize("impl", ["mfma", "f32"])
+@pytest.mark.parametrize("epi", [EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RES, EPI_DGELU, EPI_RES, EPI_BIAS_TANH])
+@pytest.mark.parametrize("M,N,K,cdt", [(256, 384, 128, "bf16"), (200, 130, 72, "f32"), (128, 768, 768, "f32")])
+def test_gemm_epilogues(impl, epi, M, N, K, cdt):
+    dt = torch.float32 if impl == "f32" else torch.bfloat16
+    cd = torch.float32 if (cdt == "f32" or impl == "f32") else torch.bfloat16
+    a, b = rnd((M, K), dt, 3, 0.5), rnd((N, K), dt, 4, 0.5)
+    bias = rnd((N,), torch.float32, 5)
+    r = rnd((M, N), dt, 6)
+    c = torch.zeros((M, N), dtype=cd, device=DEV)
+    c2 = torch.zeros((M, N), dtype=cd, device=DEV)
+    ops.gemm(a, b, c, M=M, N=N, K=K, bias=bias, epi=epi, r=r, c2=c2)
+    y = a.double() @ b.double().t()
+    rr = r.double()
+    if epi == EPI_BIAS:
+        ref = y + bias
+    elif epi == EPI_BIAS_GELU:
+        z = y + bias
+        ref = gelu(z)
+        assert relerr(c2, z) < (1e-5 if cd == torch.float32 else 1e-2)
+    elif epi == EPI_BIAS_RES:
+        ref = y + bias + rr
+    elif epi == EPI_DGELU:
+        ref = y * dgelu(rr)
+    elif epi == EPI_RES:
+        ref = y + rr
+    else:
+        ref = torch.tanh(y + bias)
+    assert relerr(c, ref) < (2e-5 if cd == torch.float32 else 1e-2)
+
+
+@pytest.mark.parametrize("impl", ["mfma", "f32"])
+def test_gemm_splitk_and_accumulate(impl):
+    dt = torch.float32 if impl == "f32" else torch.bfloat16
+    Mt, No, Ko = 4096, 200, 136
+    dy, x = rnd((Mt, No), dt, 7, 0.3), rnd((Mt, Ko), dt, 8, 0.3)
+    ref = dy.double().t() @ x.double()
+    for sk in (1, 4, 7):
+        c = torch.zeros((No, Ko), dtype=torch.float32, device=DEV)
+        ws = torch.empty(sk * No * Ko, dtype=torch.float32, device=DEV)
+        ops.gemm(dy, x, c, ta=True, tb=True, M=No, N=Ko, K=Mt, lda=No, ldb=Ko, splitk=sk, ws=ws)
+        assert relerr(c, ref) < 2e-4
+    c = torch.ones((No, Ko), dtype=torch.float32, device=DEV)
+    ops.gemm(dy, x, c, ta=True, tb=True, M=No, N=Ko, K=Mt, lda=No, ldb=Ko, accumulate=True)
+    assert relerr(c, ref + 1.0) < 2e-4
+
+
+def test_gemm_vocab_sized_tails():
+    """Decoder shapes: N = V = 30522 (not a multiple of 8) forward; K = V with zero-padded rows backward."""
+    V, H, R = 30522, 128, 96
+    Vp = (V + 7) // 8 * 8
+    t, E = rnd((R, H), torch.bfloat16, 9), rnd((V, H), torch.bfloat16, 10, 0.05)
+    logits = torch.zeros((R, Vp), dtype=torch.float32, device=DEV)
+    ops.gemm(t, E, logits, M=R, N=V, K=H, ldc=Vp)
+    assert relerr(logits[:, :V], t.double() @ E.double().t()) < 1e-4
+    dl = torch.zeros((R, Vp), dtype=torch.bfloat16, device=DEV)
+    dl[:, :V] = rnd((R, V), torch.bfloat16, 11, 0.01)
+    dt_ = torch.zeros((R, H), dtype=torch.float32, device=DEV)
+    ops.gemm(dl, E, dt_, tb=True, M=R, N=H, K=V, lda=Vp, ldb=H)
+    assert relerr(dt_, dl[:, :V].double() @ E.double()) < 1e-3
+    dE = torch.zeros((V, H), dtype=torch.float32, device=DEV)
+    ops.gemm(dl, t, dE, ta=True, tb=True, M=V, N=H, K=R, lda=Vp, ldb=H)
+    assert relerr(dE, dl[:, :V].double().t() @ t.double()) < 1e-4
+
+
+def test_gemm_rejects_bad_arguments():
+    a = torch.zeros((8, 12), dtype=torch.bfloat16, device=DEV)
+    c = torch.zeros((8, 8), dtype=torch.float32, device=DEV)
+    with pytest.raises(RuntimeError, match="MV_E_SHAPE"):
+        ops.gemm(a, a, c, M=8, N=8, K=12)                  # lda = 12 is not a multiple of 8
+    with pytest.raises(RuntimeError, match="MV_E_ARG"):
+        ops.gemm(a, a, c, M=0, N=8, K=8, lda=16, ldb=16)
+
+
+# ------------------------------------------------------------------------------------------ attention
+def attn_ref(qkv, mask, A):
+    B, Lq, H3 = qkv.shape
+    H = H3 // 3
+    dh = H // A
+    q, k, v = [t.view(B, Lq, A, dh).permute(0, 2, 1, 3) for t in qkv.double().split(H, dim=-1)]
+    add = (1.0 - (mask if mask.dim() == 3 else mask[:, None, :].expand(B, Lq, Lq)).double()) * -10000.0
+    s = q @ k.transpose(-1, -2) / math.sqrt(dh) + add[:, None]
+    p = torch.softmax(s, -1)
+    ctx = (p @ v).permute(0, 2, 1, 3).reshape(B, Lq, H)
+    return ctx, torch.logsumexp(s, -1)
+
+
+def _masks(name, B, N, S):
+    Lq = N + S + 3
+    g = torch.Generator().manual_seed(5)
+    n_ids = torch.randint(2, S + 2, (B,), generator=g)
+    if name == "random":
+        m = (torch.rand((B, Lq, Lq), generator=g) < 0.6).long()
+        m[:, :, 0] = 1
+        return m
+    if name == "deadrow":                 # one query row fully masked: additive -10000 on every key
+        m = D.build_mask("bar", N, S, n_ids)
+        m[0, Lq // 2, :] = 0
+        return m
+    if name == "mixed":
+        return D.mixed_mask(N, S, n_ids, torch.arange(B) % 2 == 0)
+    return D.build_mask(name, N, S, n_ids)
+
+
+ATT_CASES = [("full", 2, 2, 16, 45), ("s2s", 2, 2, 16, 45), ("bar", 3, 2, 5, 29), ("noncross", 2, 2, 16, 45), ("1d", 2, 2, 16, 45),
+             ("random", 2, 2, 7, 90), ("deadrow", 2, 2, 16, 45), ("s2s", 2, 4, 36, 473), ("mixed", 4, 3, 36, 150),
+             ("full", 1, 12, 100, 665)]
+
+
+@pytest.mark.parametrize("impl", ["mfma", "simple_bf16", "f32"])
+@pytest.mark.parametrize("fam,B,A,N,S", ATT_CASES)
+def test_attention_fwd_bwd(impl, fam, B, A, N, S):
+    dt = torch.float32 if impl == "f32" else torch.bfloat16
+    ops.set_impl(1 if impl == "simple_bf16" else 0)
+    try:
+        dh, Lq = 64, N + S + 3
+        H = A * dh
+        mask = _masks(fam, B, N, S).to(DEV)
+        qkv = rnd((B, Lq, 3 * H), dt, 21, 1.0)
+        dctx = rnd((B, Lq, H), dt, 22, 1.0)
+        bits = torch.zeros((B, Lq, (Lq + 31) // 32), dtype=torch.int32, device=DEV)
+        tinfo = torch.zeros((B, (Lq + 63) // 64, (Lq + 63) // 64), dtype=torch.uint8, device=DEV)
+        ops.mask_pack(mask, bits, tinfo)
+        ctx = torch.zeros((B, Lq, H), dtype=dt, device=DEV)
+        lse = torch.zeros((B, A, Lq), dtype=torch.float32, device=DEV)
+        ops.attn_fwd(qkv.view(B * Lq, 3 * H), bits, tinfo, ctx, lse, B, Lq, A, dh)
+        qd = qkv.double().requires_grad_(True)
+        rctx, rlse = attn_ref(qd, mask, A)
+        tol = 1e-5 if impl == "f32" else 1.5e-2
+        assert relerr(ctx, rctx) < tol
+        assert float((lse.double() - rlse).abs().max()) < (1e-4 if impl == "f32" else 2e-2)
+        # backward, with the kernel's own (rounded) ctx as the saved output
+        dqkv = torch.zeros((B, Lq, 3 * H), dtype=dt, device=DEV)
+        delta = torch.zeros((B, A, Lq), dtype=torch.float32, device=DEV)
+        ops.attn_bwd(qkv.view(B * Lq, 3 * H), ctx, dctx, lse, bits, tinfo, dqkv, delta, B, Lq, A, dh)
+        (rctx * dctx.double()).sum().backward()
+        assert relerr(dqkv, qd.grad) < (1e-5 if impl == "f32" else 2e-2)
+    finally:
+        ops.set_impl(0)
+
+
+def test_mask_pack_bits_and_tile_classes():
+    B, N, S = 3, 36, 120
+    Lq = N + S + 3
+    for fam in ("full", "s2s", "bar", "noncross", "1d", "random", "deadrow"):
+        mask = _masks(fam, B, N, S).to(DEV)
+        W, T = (Lq + 31) // 32, (Lq + 63) // 64
+        bits = torch.zeros((B, Lq, W), dtype=torch.int32, device=DEV)
+        tinfo = torch.full((B, T, T), 9, dtype=torch.uint8, device=DEV)
+        ops.mask_pack(mask, bits, tinfo)
+        m3 = (mask if mask.dim() == 3 else mask[:, None, :].expand(B, Lq, Lq)).cpu().numpy() != 0
+        pad = np.zeros((B, Lq, W * 32), bool)
+        pad[:, :, :Lq] = m3
+        want = (pad.reshape(B, Lq, W, 32).astype(np.uint64) << np.arange(32, dtype=np.uint64)).sum(-1).astype(np.uint32)
+        assert np.array_equal(bits.cpu().numpy().view(np.uint32), want), fam     # bit-exact
+        ti = tinfo.cpu().numpy()
+        rows_ok = m3.any(-1)
+        for b in range(B):
+            for tq in range(T):
+                for tk in range(T):
+                    blk = m3[b, tq * 64:(tq + 1) * 64, tk * 64:(tk + 1) * 64]
+                    c = 1 if blk.all() else (0 if (not blk.any() and rows_ok[b, tq * 64:(tq + 1) * 64].all()) else 2)
+                    assert ti[b, tq, tk] == c, (fam, b, tq, tk)
+
+
+# ------------------------------------------------------------------------------------------ row kernels
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,H", [(37, 128), (513, 768), (64, 1024), (10, 2048)])
+def test_layernorm_fwd_bwd(dt, M, H):
+    x = rnd((M, H), torch.float32, 31, 2.0) + 0.5
+    g, b = rnd((H,), torch.float32, 32) * 0.1 + 1.0, rnd((H,), torch.float32, 33) * 0.1
+    dy = rnd((M, H), dt, 34)
+    y = torch.zeros((M, H), dtype=dt, device=DEV)
+    mean, rstd = torch.zeros(M, device=DEV), torch.zeros(M, device=DEV)
+    eps = 1e-12
+    ops.layernorm_fwd(x, g, b, y, mean, rstd, M, H, eps)
+    xd = x.double().requires_grad_(True)
+    gd, bd = g.double().requires_grad_(True), b.double().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(xd, (H,), gd, bd, eps)
+    assert relerr(y, ref) < (1e-5 if dt == torch.float32 else 1e-2)
+    dx = torch.zeros((M, H), dtype=dt, device=DEV)
+    dg, db, cs = torch.zeros(H, device=DEV), torch.zeros(H, device=DEV), torch.zeros(H, device=DEV)
+    ops.layernorm_bwd(dy, x, mean, rstd, g, dx, dg, db, cs, M, H)
+    (ref * dy.double()).sum().backward()
+    tol = 1e-4 if dt == torch.float32 else 1e-2
+    assert relerr(dx, xd.grad) < tol and relerr(dg, gd.grad) < tol and relerr(db, bd.grad) < tol
+    assert relerr(cs, dx.double().sum(0)) < (1e-4 if dt == torch.float32 else 2e-2)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_embed_fwd_bwd(dt):
+    B, N, T, H, V, maxpos = 3, 5, 30, 128, 1024, 512
+    Lq = N + T + 2
+    g_ = torch.Generator().manual_seed(41)
+    cls_tok = torch.full((B,), 101, dtype=torch.int64, device=DEV)
+    sep_tok = torch.full((B,), 102, dtype=torch.int64, device=DEV)
+    txt = torch.randint(0, V, (B, T), generator=g_).to(DEV)
+    txt[:, -5:] = 0                                     # pads collide on row 0 (atomic contention path)
+    seg = torch.ones((B, T), dtype=torch.int64, device=DEV)
+    pos = torch.sort(torch.randperm(256, generator=g_)[:N])[0].view(1, N).expand(B, N).contiguous().to(DEV)
+    E, P, Ty = rnd((V, H), dt, 42, 0.05), rnd((maxpos, H), dt, 43, 0.05), rnd((2, H), dt, 44, 0.05)
+    imgproj = rnd((B, N, H), dt, 45, 0.5)
+    g, b = rnd((H,), torch.float32, 46) * 0.1 + 1.0, rnd((H,), torch.float32, 47) * 0.1
+    x0 = torch.zeros((B, Lq, H), dtype=dt, device=DEV)
+    pre = torch.zeros((B, Lq, H), device=DEV)
+    mean, rstd = torch.zeros(B * Lq, device=DEV), torch.zeros(B * Lq, device=DEV)
+    dtn = 0 if dt == torch.float32 else 1
+    ops.embed_fwd(dtn, cls_tok, txt, seg, pos, sep_tok, imgproj, E, P, Ty, g, b, x0, pre, mean, rstd, B, N, T, H, V, maxpos, 1e-12)
+    Ed, Pd, Td, Id = [t.double().requires_grad_(True) for t in (E, P, Ty, imgproj)]
+    gd, bd = g.double().requires_grad_(True), b.double().requires_grad_(True)
+    z = torch.zeros((B, 1), dtype=torch.int64, device=DEV)
+    rows = torch.cat([Ed[cls_tok][:, None] + Pd[z] + Td[z], Id + Pd[pos] + Td[0][None, None],
+                      Ed[sep_tok][:, None] + Pd[z] + Td[z], Ed[txt] + Pd[torch.arange(T, device=DEV)][None] + Td[seg]], 1)
+    ref = torch.nn.functional.layer_norm(rows, (H,), gd, bd, 1e-12)
+    assert relerr(x0, ref) < (1e-5 if dt == torch.float32 else 1e-2)
+    dx0 = rnd((B, Lq, H), dt, 48)
+    dE, dP, dTy = torch.zeros((V, H), device=DEV), torch.zeros((maxpos, H), device=DEV), torch.zeros((2, H), device=DEV)
+    dg, db = torch.zeros(H, device=DEV), torch.zeros(H, device=DEV)
+    dimg = torch.zeros((B, N, H), dtype=dt, device=DEV)
+    ops.embed_bwd(dtn, dx0, pre, mean, rstd, g, cls_tok, txt, seg, pos, sep_tok, dE, dP, dTy, dg, db, dimg, B, N, T, H, V, maxpos)
+    (ref * dx0.double()).sum().backward()
+    tol = 1e-4 if dt == torch.float32 else 1e-2
+    for got, want in ((dE, Ed.grad), (dP, Pd.grad), (dTy, Td.grad), (dg, gd.grad), (db, bd.grad), (dimg, Id.grad)):
+        assert relerr(got, want) < tol
+
+
+@pytest.mark.parametrize("V,ld", [(2, 2), (1000, 1000), (30522, 30528)])
+@pytest.mark.parametrize("ddt", [torch.float32, torch.bfloat16])
+def test_cross_entropy_fused(V, ld, ddt):
+    R = 37
+    logits = torch.zeros((R, ld), device=DEV)
+    logits[:, :V] = rnd((R, V), torch.float32, 51, 2.0)
+    g_ = torch.Generator().manual_seed(52)
+    labels = torch.randint(0, V, (R,), generator=g_)
+    labels[::5] = -100
+    labels = labels.to(DEV)
+    logits[3, int(labels[3])] = 50.0                     # a guaranteed argmax hit
+    out = torch.zeros(3, device=DEV)
+    ldd = (V + 7) // 8 * 8
+    dl = torch.full((R, ldd), 3.0, dtype=ddt, device=DEV)
+    scale = torch.tensor([0.125], device=DEV)
+    ops.ce_fwd_bwd(logits, ld, labels.to(torch.int32), R, V, out, dl, ldd, grad_scale_dev=scale)
+    ld_ = logits[:, :V].double().requires_grad_(True)
+    nll = torch.nn.functional.cross_entropy(ld_, labels, ignore_index=-100, reduction="sum")
+    nlab = int((labels != -100).sum())
+    corr = int(((ld_.argmax(-1) == labels) & (labels != -100)).sum())
+    assert abs(float(out[0]) - float(nll)) < 1e-3 * max(1.0, abs(float(nll)))
+    assert int(out[1]) == nlab and int(out[2]) == corr and corr >= 1
+    (nll * 0.125).backward()
+    assert relerr(dl[:, :V], ld_.grad) < (1e-5 if ddt == torch.float32 else 1e-2)
+    assert (dl[:, V:] == 0).all()
+
+
+def test_gather_scatter_colsum_cast_add():
+    M, H, R = 300, 768, 41
+    for dt in (torch.float32, torch.bfloat16):
+        src = rnd((M, H), dt, 61)
+        rows = torch.randperm(M)[:R].to(torch.int32).to(DEV)
+        dst = torch.zeros((R, H), dtype=dt, device=DEV)
+        ops.gather_rows(src, H, rows, R, H, dst, H)
+        assert torch.equal(dst, src[rows.long()])
+        back = torch.zeros((M, H), dtype=dt, device=DEV)
+        ops.scatter_rows(dst, H, rows, R, H, back, H)
+        assert torch.equal(back[rows.long()], dst) and float(back.float().abs().sum()) == float(dst.float().abs().sum())
+        cs = torch.ones(H, device=DEV)
+        ops.colsum(src, H, M, H, cs, accumulate=True)
+        assert relerr(cs, src.double().sum(0) + 1.0) < 1e-4
+        c = torch.zeros((M, H), dtype=dt, device=DEV)
+        ops.add(src, src, c, M * H)
+        assert torch.equal(c, (src.float() * 2).to(dt))
+    a = rnd((1001,), torch.float32, 62)
+    b = torch.zeros(1001, dtype=torch.bfloat16, device=DEV)
+    ops.cast(a, b, 1001)
+    assert torch.equal(b, a.to(torch.bfloat16))
+    z = rnd((64, 30), torch.float32, 63)
+    zp = torch.full((64, 32), 5.0, dtype=torch.bfloat16, device=DEV)
+    ops.cast2d(z, 30, zp, 32, 64, 30)
+    assert torch.equal(zp[:, :30], z.to(torch.bfloat16)) and (zp[:, 30:] == 0).all()
+    dy, zz = rnd((16, 64), torch.float32, 64), rnd((16, 64), torch.float32, 65)
+    o = torch.zeros_like(dy)
+    ops.dact(0, dy, zz, o, 16 * 64)
+    assert relerr(o, dy.double() * dgelu(zz.double())) < 1e-5
+    ops.dact(1, dy, torch.tanh(zz), o, 16 * 64)
+    assert relerr(o, dy.double() * (1 - torch.tanh(zz.double()) ** 2)) < 1e-5
+
+
+def test_adamw_known_answer(golden_dir):
+    """HF-AdamW KAT (tests/golden/adamw.npz, computed with python floats) on the fused kernel."""
+    import os
+    z = np.load(os.path.join(golden_dir, "adamw.npz"))
+    lr, b1, b2, eps, wd = [float(x) for x in z["hyper"]]
+    p = torch.tensor(z["p0"], dtype=torch.float32, device=DEV)
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    sh = torch.zeros(16, dtype=torch.bfloat16, device=DEV)
+    for t in range(1, 4):
+        g = torch.tensor(z["grads"][t - 1], dtype=torch.float32, device=DEV)
+        ops.adamw_step(p, g, m, v, sh, 16, lr, b1, b2, eps, wd, t)
+        assert np.abs(p.cpu().numpy() - z["p"][t - 1]).max() < 2e-6
+    assert torch.equal(sh, p.to(torch.bfloat16))
