@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""Benchmark of the MedViLL / CXRBERT pretraining step on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W            (N = 1)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
+
+One "step" = the loop body of models/train_origin.py:95-146 on one synthetic mini-batch that is
+already resident in HBM: forward, CE(mlm, ignore -100) + CE(itm), backward, HF AdamW, the
+ITM/MLM accuracy counters, and (N > 1) the RCCL gradient all-reduce.  Workload = BASELINE.json
+configs[1]: BERT-base (12L/12H/768), L = 512 (36 regions + 476 text), bidirectional mask, bf16
+MFMA path, batch 64 per GPU (weak scaling), random-init weights, synthetic inputs.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline     whole-step model FLOPs (dense MFU convention, 364.076 GFLOP/sample)
+               against the dense bf16 MFMA peak, plus the dominant kernel (the MFMA GEMM) timed
+               alone with HIP events on its own stream;
+  cpu_baseline the CPU oracle (a port; the reference's Python cannot travel) timed on the host
+               cores on a bounded sample (B = 2, same shape).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0       # MI355X dense bf16 MFMA (MI355X_MICROARCH.md); never the 2:1-sparse figure
+CONFIGS = {
+    "c2": dict(name="BERT-base L512 (36 regions + 476 text) bidirectional", N=36, S=473, family="full", max_pos=512),
+    "c3": dict(name="BERT-base L512 Bi+Seq2Seq mixed 75/25", N=36, S=473, family="mixed", max_pos=512),
+    "c4": dict(name="BERT-base L512 non-cross modality mask", N=36, S=473, family="noncross", max_pos=512),
+    "c5": dict(name="BERT-base L768 (100 regions + 668 text) seq2seq", N=100, S=665, family="s2s", max_pos=768),
+}
+
+
+def flops_fwd_per_sample(H, I, V, D, layers, L, N):
+    return 2.0 * N * D * H + layers * (L * (8.0 * H * H + 4.0 * H * I) + 4.0 * L * L * H) + 2.0 * H * H + L * (2.0 * H * H + 2.0 * H * V) + 4.0 * H
+
+
+def cpu_baseline(cfgname, steps=3):
+    """The oracle's training step (forward + both CE + autograd backward + HF AdamW, dropout on like
+    the reference's train mode) on the host cores; B = 2."""
+    from oracle import cxrbert_oracle as O
+    from oracle import synth
+    c = CONFIGS[cfgname]
+    ocfg = O.OracleConfig(max_pos=c["max_pos"])
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, int(os.environ.get("MV_CPU_THREADS", "16"))))    # the GPU box's CPU share is 16 per GPU
+    torch.set_num_threads(cores)
+    P = {k: v.clone().requires_grad_(True) for k, v in O.make_params(ocfg, seed=3).items()}
+    M = {k: torch.zeros_like(v) for k, v in P.items()}
+    V = {k: torch.zeros_like(v) for k, v in P.items()}
+    B = 2
+    b = {k: torch.from_numpy(v) for k, v in synth.make_batch(ocfg, B, c["N"], c["S"], c["family"], seed=1234).items()}
+    t00 = time.time()
+    O.train_step(P, M, V, 1, ocfg, b, p_drop=0.1, training=True)
+    print(f"[cpu_baseline] warm-up step {time.time() - t00:.1f}s on {cores} threads", file=sys.stderr, flush=True)
+    t0 = time.time()
+    for t in range(steps):
+        O.train_step(P, M, V, t + 2, ocfg, b, p_drop=0.1, training=True)
+    dt = (time.time() - t0) / steps
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return dict(value=B / dt, unit="pairs/s", cores=cores, kind="port",
+                sample=f"oracle/cxrbert_oracle.train_step, fp32, dropout 0.1, B={B}, {steps} timed steps after 1 warm-up, "
+                       f"same shape ({c['name']}); host CPU: {model}")
+
+
+def time_dominant_kernel(eng, B, L):
+    """The FFN-up projection GEMM ([B*L,768] x [3072,768]^T + bias + GELU) alone, HIP events on its stream."""
+    import medvill_amd.hip_ops as ops
+    from medvill_amd._lib import EPI_BIAS_GELU
+    M, H, I = B * L, eng.cfg.hidden, eng.cfg.intermediate
+    p = "enc.encoder.layer.0."
+    x = eng._buf("x0", (M, H), eng.adt)
+    out, z = eng._buf("i0", (M, I), eng.adt), eng._buf("z0", (M, I), eng.adt)
+    st = torch.cuda.current_stream()
+    reps = 20
+    for _ in range(3):
+        ops.gemm(x, eng.w[p + "intermediate.dense.weight"], out, M=M, N=I, K=H, bias=eng.p[p + "intermediate.dense.bias"],
+                 epi=EPI_BIAS_GELU, c2=z)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(st)
+    for _ in range(reps):
+        ops.gemm(x, eng.w[p + "intermediate.dense.weight"], out, M=M, N=I, K=H, bias=eng.p[p + "intermediate.dense.bias"],
+                 epi=EPI_BIAS_GELU, c2=z)
+    e1.record(st)
+    e1.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    fl = 2.0 * M * H * I
+    return dict(kernel="gemm_mfma_kernel<NT> 32768x3072x768 +bias+GELU", ms=ms, tflops=fl / ms / 1e9)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="per-GPU mini-batch")
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs a torch.distributed launch with WORLD_SIZE={args.gpus} (got {world})")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import medvill_amd as mv
+    c = CONFIGS[args.config]
+    cfg = mv.ModelConfig(max_pos=c["max_pos"])
+    torch.manual_seed(1234)                                 # identical init on every rank: no parameter broadcast
+    model = mv.CXRBERT(cfg, None, dtype=torch.bfloat16, device=dev)
+    step = mv.TrainStep(model, lr=1e-5, distributed=(world > 1))
+    B, N, S = args.batch, c["N"], c["S"]
+    L = N + S + 3
+    # a few distinct resident batches so that successive steps do not see identical data
+    batches = [mv.data.synthetic_batch(cfg.vocab_size, B, N, S, c["family"], seed=1234 + 1000 * i + rank, device=dev)
+               for i in range(4)]
+
+    def sync():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(batches[i % len(batches)])
+    sync()
+    print(f"[bench] rank {rank}: warm-up done", file=sys.stderr, flush=True)
+    t0 = time.perf_counter()
+    stats = None
+    for i in range(args.steps):
+        stats = step(batches[i % len(batches)])
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t[0])
+    ms_per_step = dt / args.steps * 1e3
+    print(f"[bench] rank {rank}: {ms_per_step:.2f} ms/step", file=sys.stderr, flush=True)
+    value = world * B * args.steps / dt
+    st = stats.cpu()
+    if rank == 0:
+        f_fwd = flops_fwd_per_sample(cfg.hidden, cfg.intermediate, cfg.vocab_size, cfg.img_hidden, cfg.layers, L, N)
+        f_step = 3.0 * f_fwd
+        achieved = value / world * f_step / 1e12
+        # executed FLOPs: the MLM head runs on the labelled rows only (unlabelled rows have zero loss and gradient)
+        n_lab = float(st[1]) / B
+        f_head_dense = L * (2.0 * cfg.hidden ** 2 + 2.0 * cfg.hidden * cfg.vocab_size)
+        f_exec = 3.0 * (f_fwd - f_head_dense + n_lab * (2.0 * cfg.hidden ** 2 + 2.0 * cfg.hidden * cfg.vocab_size))
+        kern = time_dominant_kernel(model.engine, B, L)
+        out = {
+            "metric": "image-text pairs/sec pretraining step, BERT-base seq512", "value": value, "unit": "pairs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": c["name"], "per_gpu_batch": B, "global_batch": B * world, "seq_len": L, "regions": N,
+                       "mask": c["family"], "layers": cfg.layers, "hidden": cfg.hidden, "vocab": cfg.vocab_size,
+                       "parallelism": f"dp{world}", "optimizer": "HF AdamW fused", "dropout": 0.0,
+                       "mlm_loss": float(st[0] / max(float(st[1]), 1.0)), "itm_loss": float(st[3] / max(float(st[4]), 1.0))},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_BF16_TFLOPS, "traffic": None,
+                         "flop_per_sample": f_step, "convention": "dense model FLOPs, backward = 2 x forward (SURVEY 8d)",
+                         "executed_tflops": value / world * f_exec / 1e12, "dominant_kernel": kern,
+                         "dominant_kernel_frac": kern["tflops"] / PEAK_BF16_TFLOPS},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.config)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

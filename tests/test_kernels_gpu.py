@@ -196,15 +196,17 @@ def test_attention_fwd_bwd(impl, fam, B, A, N, S):
         ops.attn_fwd(qkv.view(B * Lq, 3 * H), bits, tinfo, ctx, lse, B, Lq, A, dh)
         qd = qkv.double().requires_grad_(True)
         rctx, rlse = attn_ref(qd, mask, A)
-        tol = 1e-5 if impl == "f32" else 1.5e-2
+        # a fully masked row keeps only the fp32-rounded differences of (score - 10000): the fp64 restatement
+        # here does not round them, the fp32 reference does (ulp(1e4) = 9.8e-4)
+        tol = (1e-3 if fam == "deadrow" else 1e-5) if impl == "f32" else 1.5e-2
         assert relerr(ctx, rctx) < tol
-        assert float((lse.double() - rlse).abs().max()) < (1e-4 if impl == "f32" else 2e-2)
+        assert float((lse.double() - rlse).abs().max()) < ((2e-3 if fam == "deadrow" else 1e-4) if impl == "f32" else 2e-2)
         # backward, with the kernel's own (rounded) ctx as the saved output
         dqkv = torch.zeros((B, Lq, 3 * H), dtype=dt, device=DEV)
         delta = torch.zeros((B, A, Lq), dtype=torch.float32, device=DEV)
         ops.attn_bwd(qkv.view(B * Lq, 3 * H), ctx, dctx, lse, bits, tinfo, dqkv, delta, B, Lq, A, dh)
         (rctx * dctx.double()).sum().backward()
-        assert relerr(dqkv, qd.grad) < (1e-5 if impl == "f32" else 2e-2)
+        assert relerr(dqkv, qd.grad) < ((1e-3 if fam == "deadrow" else 1e-5) if impl == "f32" else 2e-2)
     finally:
         ops.set_impl(0)
 
@@ -331,7 +333,10 @@ def test_gather_scatter_colsum_cast_add():
         assert torch.equal(dst, src[rows.long()])
         back = torch.zeros((M, H), dtype=dt, device=DEV)
         ops.scatter_rows(dst, H, rows, R, H, back, H)
-        assert torch.equal(back[rows.long()], dst) and float(back.float().abs().sum()) == float(dst.float().abs().sum())
+        assert torch.equal(back[rows.long()], dst)
+        untouched = torch.ones(M, dtype=torch.bool, device=DEV)
+        untouched[rows.long()] = False
+        assert (back[untouched] == 0).all()
         cs = torch.ones(H, device=DEV)
         ops.colsum(src, H, M, H, cs, accumulate=True)
         assert relerr(cs, src.double().sum(0) + 1.0) < 1e-4

@@ -87,15 +87,23 @@ def test_dropin_backward_matches_reference_gradients(golden_dir, name, dtype, rt
     names = [str(n) for n in z["grad_names"]]
     grads = dict(model.named_parameters())
     worst = 0.0
+    gmax = float(z["grad_norms"].max())
     for i, k in enumerate(names):
         g = grads[k].grad.float().cpu()
         ref_norm = float(z["grad_norms"][i])
         got = g.reshape(-1)[torch.from_numpy(z["grad_idx"][i])].numpy()
-        scale = max(ref_norm / np.sqrt(g.numel()), float(np.abs(z["grad_vals"][i]).max()), 1e-8)
-        e1 = abs(float(g.double().norm()) - ref_norm) / max(ref_norm, 1e-8)
+        # gradients that are analytically zero (e.g. the key bias: softmax is shift-invariant) are pure rounding
+        # noise in the reference too (norm ~1e-8): compare those against an absolute floor tied to the largest gradient
+        # In bf16 the same holds for cancellation-dominated tensors: with random-init weights `pooled` is almost
+        # the same vector for every sample, so d(itm/pooler) = sum_b ditm[b] (x) pooled[b] cancels to ~1% of its terms
+        # and is decided by the low bits that bf16 STORAGE of `pooled` drops (c1_full: |g| = 9e-3 vs 0.9 in c1v1k_full).
+        floor = (1e-5 if dtype == torch.float32 else 3e-2) * gmax
+        efloor = floor if dtype == torch.float32 else 8 * floor / np.sqrt(g.numel())
+        scale = max(ref_norm / np.sqrt(g.numel()), float(np.abs(z["grad_vals"][i]).max()), efloor)
+        e1 = abs(float(g.double().norm()) - ref_norm) / max(ref_norm, floor)
         e2 = float(np.abs(got - z["grad_vals"][i]).max()) / scale
         worst = max(worst, e1, e2 * 0.25)
-        assert e1 < rtol, (k, e1)
+        assert e1 < rtol, (k, e1, ref_norm)
         assert e2 < 4 * rtol + 1e-6, (k, e2)
     print(f"{name} {dtype}: worst grad deviation {worst:.2e}")
 
@@ -110,7 +118,8 @@ def test_fused_train_step_equals_dropin_path(golden_dir, dtype):
     ce_m, ce_i = torch.nn.CrossEntropyLoss(ignore_index=-100), torch.nn.CrossEntropyLoss()
     ml, il = ce_m(mlm.transpose(1, 2), b["txt_labels"].to(DEV)), ce_i(itm, b["is_aligned"].to(DEV))
     (ml + il).backward()
-    ref = torch.cat([p.grad.reshape(-1) for p in model.parameters()]).clone()
+    named = dict(model.named_parameters())
+    ref = torch.cat([named[n].grad.reshape(-1) for n in model._param_names]).clone()
     ts = mv.TrainStep(model, lr=0.0)
     stats = ts({k: v for k, v in b.items()}, train=True).cpu()
     got = torch.cat([model.engine.g[n].reshape(-1) for n in model._param_names])
