@@ -64,6 +64,9 @@ int mv_abi_version(void);
 void mv_set_impl(int impl);
 int mv_get_impl(void);
 const char* mv_build_info(void);
+/* test hook for mv_gemm's MFMA tile choice: force = 0 auto / 1 the 128x128x64 kernel / 2 the 256-row
+ * LDS-DMA kernel; nj = 0 auto / 3 (256x192 tile) / 4 (256x256 tile). */
+void mv_set_gemm_variant(int force, int nj);
 
 /* ---- dense projections --------------------------------------------------------------------
  * Replaces every nn.Linear on the path and its autograd backward:
@@ -80,6 +83,7 @@ const char* mv_build_info(void);
  * bf16 operands need 16-byte aligned bases and lda, ldb multiples of 8; a contraction length
  * K that is not a multiple of 8 is allowed only when the k-contiguous operand's rows are
  * zero-padded up to the next multiple of 8.
+ * splitk = 0: let the library pick (needs ws for up to 16 slices, else 1 is used).
  * splitk > 1: the K range is cut in `splitk` slices whose partial tiles go to `ws`
  * (>= splitk*M*N floats) and are summed by a second kernel; only with MV_EPI_NONE and an f32 C.
  * accumulate != 0: C += result (f32 C, MV_EPI_NONE only).                                      */

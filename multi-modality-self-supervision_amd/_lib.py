@@ -27,6 +27,7 @@ PROTOTYPES = {
     "mv_set_impl": [i32],
     "mv_get_impl": [],
     "mv_build_info": [],
+    "mv_set_gemm_variant": [i32, i32],
     "mv_gemm": [i32, i32, i32, i32, i32, i32, vp, i32, vp, i32, vp, i32, i32, vp, i32, vp, i32, i32, vp, i32, i32, vp, sz,
                 i32, vp],
     "mv_mask_pack": [vp, i32, i32, i32, vp, vp, vp],
@@ -46,7 +47,7 @@ PROTOTYPES = {
     "mv_cast": [vp, i32, vp, i32, sz, vp],
     "mv_adamw_step": [vp, vp, vp, vp, vp, sz, f32, f32, f32, f32, f32, i32, i32, f32, vp],
 }
-_RESTYPE = {"mv_set_impl": None, "mv_build_info": C.c_char_p}
+_RESTYPE = {"mv_set_impl": None, "mv_set_gemm_variant": None, "mv_build_info": C.c_char_p}
 
 _lib = None
 

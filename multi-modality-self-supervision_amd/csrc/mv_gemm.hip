@@ -25,52 +25,16 @@ struct GemmArgs {
   int kchunk, splitk;
   float* ws;
   unsigned bytesA, bytesB;
+  int dbg;   // ablation bits (timing experiments only): 1 skip C stores, 2 skip operand loads, 4 skip LDS reads + MFMA
 };
 
 // ------------------------------------------------------------------------------------------
 // fused epilogue on 4 consecutive columns (n .. n+3) of row m.
-__device__ __forceinline__ void epilogue4(const GemmArgs& p, int m, int n, f32x4 v) {
+// Slow path (scalar, run-time epilogue selector): ragged right edge / unaligned leading dimensions.
+__device__ __forceinline__ void epilogue4_slow(const GemmArgs& p, int m, int n, f32x4 v) {
   const int nv = p.N - n;
   if (m >= p.M || nv <= 0) return;
   const size_t co = (size_t)m * p.ldc + n;
-  if (p.vec_ok && nv >= 4) {
-    f32x4 b = {0.f, 0.f, 0.f, 0.f}, r = {0.f, 0.f, 0.f, 0.f};
-    const int e = p.epi;
-    if (e == MV_EPI_BIAS || e == MV_EPI_BIAS_GELU || e == MV_EPI_BIAS_RES || e == MV_EPI_BIAS_TANH)
-      b = *(const f32x4*)(p.bias + n);
-    if (e == MV_EPI_BIAS_RES || e == MV_EPI_DGELU || e == MV_EPI_RES) {
-      const size_t ro = (size_t)m * p.ldr + n;
-      r = (p.r_dtype == MV_F32) ? ld4<float>((const float*)p.R + ro) : ld4<bf16_t>((const bf16_t*)p.R + ro);
-    }
-    f32x4 o;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      float x = v[i];
-      switch (e) {
-        case MV_EPI_BIAS: x += b[i]; break;
-        case MV_EPI_BIAS_GELU: x += b[i]; break;
-        case MV_EPI_BIAS_RES: x += b[i] + r[i]; break;
-        case MV_EPI_DGELU: x *= dgelu_erf(r[i]); break;
-        case MV_EPI_RES: x += r[i]; break;
-        case MV_EPI_BIAS_TANH: x = tanhf(x + b[i]); break;
-        default: break;
-      }
-      o[i] = x;
-    }
-    if (e == MV_EPI_BIAS_GELU) {
-      const size_t c2 = (size_t)m * p.ldc2 + n;
-      if (p.c_dtype == MV_F32) st4<float>((float*)p.C2 + c2, o); else st4<bf16_t>((bf16_t*)p.C2 + c2, o);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) o[i] = gelu_erf(o[i]);
-    }
-    if (p.c_dtype == MV_F32) {
-      if (p.accumulate) { f32x4 old = *(const f32x4*)((const float*)p.C + co); o += old; }
-      st4<float>((float*)p.C + co, o);
-    } else {
-      st4<bf16_t>((bf16_t*)p.C + co, o);
-    }
-    return;
-  }
   const int lim = nv < 4 ? nv : 4;
   for (int i = 0; i < lim; ++i) {
     float x = v[i];
@@ -95,6 +59,55 @@ __device__ __forceinline__ void epilogue4(const GemmArgs& p, int m, int n, f32x4
     st_any(p.C, co + i, p.c_dtype, x);
   }
 }
+
+// Fast path: compile-time epilogue, 16-byte bias / residual loads, 8- or 16-byte stores.
+template <int E>
+__device__ __forceinline__ void epilogue4t(const GemmArgs& p, int m, int n, f32x4 v) {
+  if (!p.vec_ok || p.N - n < 4) { epilogue4_slow(p, m, n, v); return; }
+  if (m >= p.M) return;
+  const size_t co = (size_t)m * p.ldc + n;
+  f32x4 o = v;
+  if (E == MV_EPI_BIAS || E == MV_EPI_BIAS_GELU || E == MV_EPI_BIAS_RES || E == MV_EPI_BIAS_TANH) o += *(const f32x4*)(p.bias + n);
+  if (E == MV_EPI_BIAS_RES || E == MV_EPI_DGELU || E == MV_EPI_RES) {
+    const size_t ro = (size_t)m * p.ldr + n;
+    const f32x4 r = (p.r_dtype == MV_F32) ? ld4<float>((const float*)p.R + ro) : ld4<bf16_t>((const bf16_t*)p.R + ro);
+    if (E == MV_EPI_DGELU) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[i] *= dgelu_erf(r[i]);
+    } else {
+      o += r;
+    }
+  }
+  if (E == MV_EPI_BIAS_TANH) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = tanhf(o[i]);
+  }
+  if (E == MV_EPI_BIAS_GELU) {
+    const size_t c2 = (size_t)m * p.ldc2 + n;
+    if (p.c_dtype == MV_F32) st4<float>((float*)p.C2 + c2, o); else st4<bf16_t>((bf16_t*)p.C2 + c2, o);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = gelu_erf(o[i]);
+  }
+  if (p.c_dtype == MV_F32) {
+    if (E == MV_EPI_NONE && p.accumulate) o += *(const f32x4*)((const float*)p.C + co);
+    st4<float>((float*)p.C + co, o);
+  } else {
+    st4<bf16_t>((bf16_t*)p.C + co, o);
+  }
+}
+__device__ __forceinline__ void epilogue4(const GemmArgs& p, int m, int n, f32x4 v) { epilogue4_slow(p, m, n, v); }
+
+// run BODY(E) with the run-time epilogue selector turned into a compile-time constant
+#define MV_EPI_SWITCH(epi_, BODY)                          \
+  switch (epi_) {                                          \
+    case MV_EPI_BIAS: BODY(MV_EPI_BIAS); break;            \
+    case MV_EPI_BIAS_GELU: BODY(MV_EPI_BIAS_GELU); break;  \
+    case MV_EPI_BIAS_RES: BODY(MV_EPI_BIAS_RES); break;    \
+    case MV_EPI_DGELU: BODY(MV_EPI_DGELU); break;          \
+    case MV_EPI_RES: BODY(MV_EPI_RES); break;              \
+    case MV_EPI_BIAS_TANH: BODY(MV_EPI_BIAS_TANH); break;  \
+    default: BODY(MV_EPI_NONE); break;                     \
+  }
 
 // raw partial tile store for split-K (ws is [splitk][M][N] f32)
 __device__ __forceinline__ void store_partial4(const GemmArgs& p, int split, int m, int n, f32x4 v) {
@@ -183,8 +196,19 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmArgs p) {
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, in = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + in;
   }
+  // grouped rasterisation inside each XCD's run: the ~64 blocks resident on an XCD form an 8 x 8 window of
+  // tiles, so every A / B panel fetched into the XCD's 4 MiB L2 is reused by 8 blocks instead of 2-3
   const int tiles_n = (p.N + GT_BN - 1) / GT_BN;
-  const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+  const int tiles_m = (p.M + GT_BM - 1) / GT_BM;
+  int tm, tn;
+  {
+    const int GM = 8;
+    const int per_group = GM * tiles_n;
+    const int group = bid / per_group, rem = bid - group * per_group;
+    const int gm = min(GM, tiles_m - group * GM);
+    tm = group * GM + rem % gm;
+    tn = rem / gm;
+  }
   const int m0 = tm * GT_BM, n0 = tn * GT_BN;
   const int split = blockIdx.y;
   const int kbeg = split * p.kchunk;
@@ -238,16 +262,210 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmArgs p) {
   }
 
   // D[r = n][c = m]: lane holds C[m = .. + l15][n = .. + 4*lq + 0..3]
+  if (p.splitk > 1) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = m0 + wm + i * 16 + l15;
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = n0 + wn + j * 16 + 4 * lq;
-      if (p.splitk > 1) store_partial4(p, split, m, n, acc[i][j]);
-      else epilogue4(p, m, n, acc[i][j]);
-    }
+      for (int j = 0; j < 4; ++j) store_partial4(p, split, m0 + wm + i * 16 + l15, n0 + wn + j * 16 + 4 * lq, acc[i][j]);
+    return;
   }
+#define EPI_BODY(E_)                                                                                          \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                               \
+  _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                               \
+      epilogue4t<E_>(p, m0 + wm + i * 16 + l15, n0 + wn + j * 16 + 4 * lq, acc[i][j]);
+  MV_EPI_SWITCH(p.epi, EPI_BODY)
+#undef EPI_BODY
+}
+
+
+// ------------------------------------------------------------------------------------------
+// Large-tile MFMA kernel ("ring" kernel): 256 x BN x 32 per stage, waves 2 x WN, each wave 128 x (16*NJ).
+//   <NJ=4, WN=4, 4 stages>  256x256 tile, 8 waves, 128 KiB LDS, 1 block / CU
+//   <NJ=3, WN=4, 4 stages>  256x192 tile (N = 768 / 2304 without a ragged last column of tiles)
+//   <NJ=4, WN=2, 3 stages>  256x128 tile, 4 waves,  72 KiB LDS, 2 blocks / CU: the second block's MFMAs cover the
+//                           first one's prologue / epilogue
+// Operands go HBM -> LDS directly (buffer_load ... lds, 16 B per lane, out-of-range lanes write 0) into a ring of
+// NSTAGE stages: while stage s feeds the MFMAs, the following NSTAGE-1 stages are in flight, tracked with a counted
+// s_waitcnt vmcnt(N) and ONE raw s_barrier per stage -- the loads are never drained inside the loop.  The LDS image
+// is lane-linear per 1-KiB piece (that is what an LDS-DMA writes); the bank-conflict swizzle is applied to the
+// per-lane SOURCE address and again on the fragment read.  0.375 LDS fragment reads per MFMA.
+#define G2_BM 256
+#define G2_BK 32
+
+// k-contiguous image: [rows][32 k] bf16 = 64-B rows, 4 chunks per row
+__device__ __forceinline__ int r2_f(int r) { return (0 - (r >> 2)) & 3; }
+__device__ __forceinline__ int r2_off(int r, int c) { return r * 64 + ((c ^ r2_f(r)) << 4); }
+// contraction-major image, 512-B rows ([32 k][256 cols]): 32 chunks per row, XOR at 32-B granularity
+__device__ __forceinline__ int t2_g(int kr) { return (kr & 3) | (((kr >> 3) & 1) << 2); }
+__device__ __forceinline__ int t2_off(int kr, int ch) { return kr * 512 + ((ch ^ (t2_g(kr) << 1)) << 4); }
+// contraction-major image, 256-B rows ([32 k][128 cols]): tr_img_off() of the 128x128 kernel
+
+// PITCH512: contraction-major image with 512-B rows (tile width 192/256) or 256-B rows (tile width 128)
+template <bool TR, bool PITCH512, int NPIECE, int NW>
+__device__ __forceinline__ void g2_issue(__amdgpu_buffer_rsrc_t rs, unsigned bytes, int ld, int row0, int rows_total,
+                                         int tile_rows, int k0, int kend, char* region, int wid, int lane) {
+#pragma unroll
+  for (int q = 0; q < NPIECE / NW; ++q) {
+    const int pc = wid + NW * q;                // 1-KiB piece of the operand image
+    unsigned off;
+    bool ok;
+    if (!TR) {
+      const int r = 16 * pc + (lane >> 2), c = (lane & 3) ^ r2_f(16 * pc + (lane >> 2));
+      const int gr = row0 + r, gk = k0 + c * 8;
+      ok = (r < tile_rows) && (gr < rows_total) && (gk < kend);
+      off = ((unsigned)gr * (unsigned)ld + (unsigned)gk) * 2u;
+    } else if (PITCH512) {
+      const int kr = 2 * pc + (lane >> 5), c = (lane & 31) ^ (t2_g(2 * pc + (lane >> 5)) << 1);
+      const int gk = k0 + kr, gc = row0 + c * 8;
+      ok = (c * 8 < tile_rows) && (gk < kend) && (gc < rows_total);
+      off = ((unsigned)gk * (unsigned)ld + (unsigned)gc) * 2u;
+    } else {
+      const int kr = 4 * pc + (lane >> 4), c = (lane & 15) ^ tr_swz(4 * pc + (lane >> 4));
+      const int gk = k0 + kr, gc = row0 + c * 8;
+      ok = (c * 8 < tile_rows) && (gk < kend) && (gc < rows_total);
+      off = ((unsigned)gk * (unsigned)ld + (unsigned)gc) * 2u;
+    }
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (MV_LDS void*)(region + pc * 1024), 16, ok ? off : bytes, 0, 0, 0);
+  }
+}
+
+template <bool TR, bool PITCH512>
+__device__ __forceinline__ bf16x8 g2_frag(const char* tile, int base, int l15, int lq) {
+  if (!TR) {
+    return *(const bf16x8*)(tile + r2_off(base + l15, lq));
+  } else {
+    const int kr = 8 * lq + (l15 >> 2);
+    const int ch = (base >> 3) + ((l15 & 3) >> 1);
+    const int sub = (l15 & 1) * 8;
+    const int o0 = PITCH512 ? t2_off(kr, ch) : tr_img_off(kr, ch);
+    const int o1 = PITCH512 ? t2_off(kr + 4, ch) : tr_img_off(kr + 4, ch);
+    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((MV_LDS bf16x4*)(tile + o0 + sub));
+    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((MV_LDS bf16x4*)(tile + o1 + sub));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  }
+}
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <bool TA, bool TB, int NJ, int WN, int NSTAGE>
+__global__ __launch_bounds__(128 * WN, (WN == 2 ? 2 : 2)) void gemm_ring_kernel(GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NW = 2 * WN;                      // waves per block
+  constexpr int BN = WN * 16 * NJ;
+  constexpr bool BP512 = BN > 128;                // pitch of a contraction-major B image
+  constexpr int A_BYTES = 16384;
+  constexpr int B_BYTES = BP512 ? 16384 : 8192;
+  constexpr int STAGE = A_BYTES + B_BYTES;
+  constexpr int LPS = (A_BYTES + B_BYTES) / 1024 / NW;   // LDS-DMA instructions per wave per stage
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, lq = lane >> 4;
+  const int wm = (wid / WN) * 128, wn = (wid % WN) * (16 * NJ);
+
+  const int nwg = gridDim.x;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, in = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + in;
+  }
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int tiles_m = (p.M + G2_BM - 1) / G2_BM;
+  int tm, tn;
+  {
+    const int GM = 8;
+    const int per_group = GM * tiles_n;
+    const int group = bid / per_group, rem = bid - group * per_group;
+    const int gm = min(GM, tiles_m - group * GM);
+    tm = group * GM + rem % gm;
+    tn = rem / gm;
+  }
+  const int m0 = tm * G2_BM, n0 = tn * BN;
+  const int split = blockIdx.y;
+  const int kbeg = split * p.kchunk;
+  const int kend = min(p.K, kbeg + p.kchunk);
+  const int nst = (kend - kbeg + G2_BK - 1) / G2_BK;
+
+  __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, p.bytesA, 0x00020000);
+  __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, p.bytesB, 0x00020000);
+
+  f32x4 acc[8][NJ];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+#define G2_ISSUE(S_)                                                                                        \
+  do {                                                                                                      \
+    char* st__ = smem + ((S_) % NSTAGE) * STAGE;                                                            \
+    const int k0__ = kbeg + (S_) * G2_BK;                                                                   \
+    g2_issue<TA, true, A_BYTES / 1024, NW>(rsA, p.bytesA, p.lda, m0, p.M, G2_BM, k0__, kend, st__, wid, lane); \
+    g2_issue<TB, BP512, B_BYTES / 1024, NW>(rsB, p.bytesB, p.ldb, n0, p.N, BN, k0__, kend, st__ + A_BYTES, wid, lane); \
+  } while (0)
+
+  const bool do_load = !(p.dbg & 2), do_mma = !(p.dbg & 4);
+  if (do_load) {
+#pragma unroll
+    for (int s = 0; s < NSTAGE - 1; ++s)
+      if (s < nst) G2_ISSUE(s);
+  }
+
+  for (int s = 0; s < nst; ++s) {
+    // stage s must have landed: at most the LPS LDS-DMA instructions of each younger in-flight stage may be pending
+    const int younger = min(NSTAGE - 2, nst - 1 - s);
+    if (younger >= 2) wait_vmcnt<(NSTAGE > 3 ? 2 : 0) * LPS>();
+    else if (younger == 1) wait_vmcnt<LPS>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (do_load && s + NSTAGE - 1 < nst) G2_ISSUE(s + NSTAGE - 1);   // refills the buffer everyone finished reading
+    if (!do_mma) continue;
+    const char* tA = smem + (s % NSTAGE) * STAGE;
+    const char* tB = tA + A_BYTES;
+    bf16x8 fa[8], fb[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) fb[j] = g2_frag<TB, BP512>(tB, wn + j * 16, l15, lq);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) fa[i] = g2_frag<TA, true>(tA, wm + i * 16, l15, lq);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+  }
+#undef G2_ISSUE
+
+  if (p.dbg & 1) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    if (t == 123.456f) ((float*)p.C)[0] = t;     // keeps the accumulators live without storing the tile
+    return;
+  }
+  // Epilogue through LDS: an accumulator tile holds 4 columns x 16 rows per lane, which would store as sixteen
+  // 32-byte fragments per instruction (measured: ~1 TB/s).  Each wave transposes 16 rows at a time through its own
+  // 4.25-KiB scratch (272-B row pitch: conflict-free both ways) so that 16 lanes cover one full output row:
+  // whole 128/256-byte lines per store, and coalesced bias / residual loads in the fused epilogue.
+  __builtin_amdgcn_s_barrier();             // every wave is done with the operand ring before it becomes scratch
+  char* scr = smem + wid * 4608;
+  const int rrow = lane >> 4, c4 = lane & 15;
+  const bool col_on = (c4 * 4) < 16 * NJ;
+#define EPI_BODY(E_)                                                                                          \
+  _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                             \
+    _Pragma("unroll") for (int j = 0; j < NJ; ++j) *(f32x4*)(scr + l15 * 272 + j * 64 + lq * 16) = acc[i][j]; \
+    _Pragma("unroll 1") for (int rr = 0; rr < 4; ++rr) {                                                      \
+      const int row = rr * 4 + rrow;                                                                          \
+      const f32x4 v = *(const f32x4*)(scr + row * 272 + c4 * 16);                                             \
+      if (col_on) {                                                                                           \
+        if (E_ < 0) store_partial4(p, split, m0 + wm + i * 16 + row, n0 + wn + c4 * 4, v);                    \
+        else epilogue4t<(E_ < 0 ? 0 : E_)>(p, m0 + wm + i * 16 + row, n0 + wn + c4 * 4, v);                   \
+      }                                                                                                       \
+    }                                                                                                         \
+  }
+  if (p.splitk > 1) { EPI_BODY(-1) return; }
+  MV_EPI_SWITCH(p.epi, EPI_BODY)
+#undef EPI_BODY
 }
 
 // ------------------------------------------------------------------------------------------
@@ -329,6 +547,11 @@ __global__ void splitk_reduce_kernel(GemmArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------
+int g_mv_gemm_force = 0;   // test hook: 0 auto, 1 force the 128x128 kernel, 2 force the 256-row kernel
+int g_mv_gemm_nj = 0;      // test hook: 0 auto, 3 / 4 force the 192- / 256-column variant
+int g_mv_gemm_dbg = 0;
+extern "C" void mv_set_gemm_variant(int force, int nj) { g_mv_gemm_force = force & 0xff; g_mv_gemm_nj = nj; g_mv_gemm_dbg = force >> 8; }
+
 static inline bool aligned_to(const void* p, size_t a) { return p == nullptr || (((uintptr_t)p) % a) == 0; }
 
 extern "C" int mv_gemm(int dtype, int ta, int tb, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
@@ -346,18 +569,19 @@ extern "C" int mv_gemm(int dtype, int ta, int tb, int M, int N, int K, const voi
   if (epi == MV_EPI_BIAS_GELU && !C2) return MV_E_ARG;
   if (lda < (ta ? M : K) || ldb < (tb ? N : K) || ldc < N) return MV_E_SHAPE;
   if (need_r && ldr < N) return MV_E_SHAPE;
-  if (splitk < 1) splitk = 1;
+  if (splitk < 0) splitk = 1;
   if (splitk > 1 || accumulate) {
     if (epi != MV_EPI_NONE || c_dtype != MV_F32) return MV_E_SHAPE;
   }
   if (splitk > 1) {
     if (!ws || ws_bytes < (size_t)splitk * M * N * sizeof(float)) return MV_E_WORKSPACE;
   }
+  if (splitk == 0 && (dtype != MV_BF16 || g_mv_impl != 0)) splitk = 1;   // auto split-K only on the MFMA kernels
   GemmArgs p;
   p.A = A; p.B = B; p.C = C; p.C2 = C2; p.bias = bias; p.R = R;
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldc2 = ldc2; p.ldr = ldr;
   p.c_dtype = c_dtype; p.r_dtype = r_dtype; p.epi = epi; p.accumulate = accumulate;
-  p.splitk = splitk; p.ws = ws;
+  p.splitk = splitk; p.ws = ws; p.dbg = g_mv_gemm_dbg;
   const size_t csz = (c_dtype == MV_F32) ? 16 : 8;
   const size_t rsz = (r_dtype == MV_F32) ? 16 : 8;
   p.vec_ok = ((ldc & 3) == 0) && aligned_to(C, csz) && (!need_bias || aligned_to(bias, 16)) &&
@@ -370,28 +594,93 @@ extern "C" int mv_gemm(int dtype, int ta, int tb, int M, int N, int K, const voi
     const size_t bytesB = ((size_t)((tb ? K : N) - 1) * ldb + (size_t)(((tb ? N : K) + 7) & ~7)) * 2;
     if (bytesA >= 0x7fffffffULL || bytesB >= 0x7fffffffULL) return MV_E_SHAPE;
     p.bytesA = (unsigned)bytesA; p.bytesB = (unsigned)bytesB;
-    int kchunk = (K + splitk - 1) / splitk;
-    kchunk = (kchunk + GT_BK - 1) / GT_BK * GT_BK;
-    p.kchunk = kchunk;
-    p.splitk = splitk = (K + kchunk - 1) / kchunk;
-    const int tiles = ((M + GT_BM - 1) / GT_BM) * ((N + GT_BN - 1) / GT_BN);
-    dim3 grid(tiles, splitk), block(256);
-    const size_t shm = 2 * GT_STAGE_BYTES;
+    // tile choice: a 256-row ring kernel when it fills the chip, in the column width (256 / 192 / 128) that needs
+    // the least MFMA time over whole rounds of CUs; the 128x128 kernel for small problems
+    const int tm2 = (M + 255) / 256;
+    const long long t256 = (long long)tm2 * ((N + 255) / 256), t192 = (long long)tm2 * ((N + 191) / 192),
+                    t128 = (long long)tm2 * ((N + 127) / 128);
+    // measured on the model's shapes (profiles/r01_gemm_variants.txt): the ring kernels win for y = x.W^T and
+    // dW = dy^T.x, the 128x128 register-staged kernel for dx = dy.W
+    const bool big = (g_mv_gemm_force == 2) || (g_mv_gemm_force == 0 && M >= 256 && N >= 128 && (K & 7) == 0 && !(!ta && tb) &&
+                                               (t128 >= 128 || (K >= 4096 && splitk != 1)));
+    if (big) {
+      long long sk = splitk;
+      if (splitk > 1 || splitk == 0) {      // 0 = auto
+        const long long tiles = t256;
+        sk = 1;
+        if (tiles < 256 && K >= 2048) { sk = 256 / tiles; if (sk > K / 1024) sk = K / 1024; if (sk > 16) sk = 16; if (sk < 1) sk = 1; }
+        if (splitk > 1 && sk > splitk) sk = splitk;
+        if (sk > 1 && (!ws || ws_bytes < (size_t)sk * M * N * sizeof(float) || epi != MV_EPI_NONE || c_dtype != MV_F32)) sk = 1;
+      }
+      // cost ~ rounds x tile width (1 block / CU for the 8-wave tiles, 2 blocks / CU for 256x128)
+      const long long r256 = (t256 * sk + 255) / 256 * 256, r192 = (t192 * sk + 255) / 256 * 192,
+                      r128 = (t128 * sk + 511) / 512 * 256;
+      int variant = g_mv_gemm_nj;           // 4: 256x256, 3: 256x192, 2: 256x128
+      if (variant == 0) {
+        variant = 2;                        // 256x128, 2 blocks / CU: best or tied on every shape measured
+        (void)r256; (void)r192; (void)r128;
+      }
+      int kchunk = (int)((K + sk - 1) / sk);
+      kchunk = (kchunk + G2_BK - 1) / G2_BK * G2_BK;
+      p.kchunk = kchunk;
+      p.splitk = splitk = (K + kchunk - 1) / kchunk;
+      const int tiles = (int)(variant == 4 ? t256 : (variant == 3 ? t192 : t128));
+      dim3 grid(tiles, splitk);
+#define LAUNCH_RING(TA_, TB_, NJ_, WN_, NS_)                                                                         \
+  do {                                                                                                               \
+    constexpr size_t shm = (size_t)(NS_) * (16384 + ((WN_) * 16 * (NJ_) > 128 ? 16384 : 8192));                       \
+    static bool attr_set = false;                                                                                    \
+    if (!attr_set) {                                                                                                 \
+      (void)hipFuncSetAttribute((const void*)gemm_ring_kernel<TA_, TB_, NJ_, WN_, NS_>,                              \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);                               \
+      attr_set = true;                                                                                               \
+    }                                                                                                                \
+    hipLaunchKernelGGL((gemm_ring_kernel<TA_, TB_, NJ_, WN_, NS_>), grid, dim3(128 * (WN_)), shm, stream, p);         \
+  } while (0)
+#define LAUNCH_RING_V(TA_, TB_)                                  \
+  do {                                                           \
+    if (variant == 4) LAUNCH_RING(TA_, TB_, 4, 4, 4);            \
+    else if (variant == 3) LAUNCH_RING(TA_, TB_, 3, 4, 4);       \
+    else LAUNCH_RING(TA_, TB_, 4, 2, 3);                         \
+  } while (0)
+      if (!ta && !tb) LAUNCH_RING_V(false, false);
+      else if (!ta && tb) LAUNCH_RING_V(false, true);
+      else if (ta && tb) LAUNCH_RING_V(true, true);
+      else LAUNCH_RING_V(true, false);
+#undef LAUNCH_RING_V
+#undef LAUNCH_RING
+    } else {
+      if (splitk == 0) {
+        const int tiles = ((M + GT_BM - 1) / GT_BM) * ((N + GT_BN - 1) / GT_BN);
+        splitk = 1;
+        if (tiles < 512 && K >= 2048 && ws && epi == MV_EPI_NONE && c_dtype == MV_F32) {
+          splitk = 768 / tiles; if (splitk > K / 1024) splitk = K / 1024; if (splitk > 16) splitk = 16; if (splitk < 1) splitk = 1;
+          if (ws_bytes < (size_t)splitk * M * N * sizeof(float)) splitk = 1;
+        }
+      }
+      int kchunk = (K + splitk - 1) / splitk;
+      kchunk = (kchunk + GT_BK - 1) / GT_BK * GT_BK;
+      p.kchunk = kchunk;
+      p.splitk = splitk = (K + kchunk - 1) / kchunk;
+      const int tiles = ((M + GT_BM - 1) / GT_BM) * ((N + GT_BN - 1) / GT_BN);
+      dim3 grid(tiles, splitk), block(256);
+      const size_t shm = 2 * GT_STAGE_BYTES;
 #define LAUNCH_MFMA(TA_, TB_)                                                                              \
   do {                                                                                                     \
     static bool attr_set = false;                                                                          \
     if (!attr_set) {                                                                                       \
-      hipFuncSetAttribute((const void*)gemm_mfma_kernel<TA_, TB_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                          (int)shm);                                                                       \
+      (void)hipFuncSetAttribute((const void*)gemm_mfma_kernel<TA_, TB_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                (int)shm);                                                                 \
       attr_set = true;                                                                                     \
     }                                                                                                      \
     hipLaunchKernelGGL((gemm_mfma_kernel<TA_, TB_>), grid, block, shm, stream, p);                          \
   } while (0)
-    if (!ta && !tb) LAUNCH_MFMA(false, false);
-    else if (!ta && tb) LAUNCH_MFMA(false, true);
-    else if (ta && tb) LAUNCH_MFMA(true, true);
-    else LAUNCH_MFMA(true, false);
+      if (!ta && !tb) LAUNCH_MFMA(false, false);
+      else if (!ta && tb) LAUNCH_MFMA(false, true);
+      else if (ta && tb) LAUNCH_MFMA(true, true);
+      else LAUNCH_MFMA(true, false);
 #undef LAUNCH_MFMA
+    }
   } else {
     int kchunk = (K + splitk - 1) / splitk;
     kchunk = (kchunk + 15) / 16 * 16;

@@ -209,12 +209,10 @@ class Engine:
 
     # dW[No,Ko] = dy[Mtok,No]^T . x[Mtok,Ko]  (contraction over tokens; split-K when the tile grid is small)
     def _dW(self, dy, x, gW, No, Ko, Mtok, lda, ldb, ldc=None):
-        tiles = ((No + 127) // 128) * ((Ko + 127) // 128)
-        splitk = 1
-        if self.dt == MV_BF16 and Mtok >= 2048 and tiles < 512:
-            splitk = max(1, min(16, 768 // tiles, Mtok // 1024))
-        ws = self._gemm_workspace(splitk * No * Ko) if splitk > 1 else None
-        ops.gemm(dy, x, gW, ta=True, tb=True, M=No, N=Ko, K=Mtok, lda=lda, ldb=ldb, ldc=ldc, splitk=splitk, ws=ws)
+        # split-K is chosen by the library (splitk=0) from the tile grid; it needs room for up to 16 partial slabs
+        auto = self.dt == MV_BF16 and Mtok >= 2048 and No * Ko <= 4 * 1024 * 1024
+        ws = self._gemm_workspace(16 * No * Ko) if auto else None
+        ops.gemm(dy, x, gW, ta=True, tb=True, M=No, N=Ko, K=Mtok, lda=lda, ldb=ldb, ldc=ldc, splitk=0 if auto else 1, ws=ws)
 
     # ------------------------------------------------------------------ encoder forward
     def encoder_forward(self, cls_tok, input_txt, attn_mask, segment, img_feats, img_pos, sep_tok):

@@ -137,3 +137,7 @@ def adamw_step(p, g, m, v, shadow, n, lr, b1, b2, eps, wd, step, correct_bias=Tr
 
 def set_impl(impl: int):
     _lib().mv_set_impl(int(impl))
+
+
+def set_gemm_variant(force: int = 0, nj: int = 0):
+    _lib().mv_set_gemm_variant(int(force), int(nj))

@@ -40,12 +40,16 @@ def dgelu(z):
 GEMM_SHAPES = [(256, 256, 256), (130, 70, 200), (1024, 768, 768), (64, 2, 768), (96, 1000, 128), (517, 264, 3072)]
 
 
-@pytest.mark.parametrize("impl", ["mfma", "simple_bf16", "f32"])
+VARIANT = {"mfma": (1, 0), "mfma256": (2, 4), "mfma192": (2, 3), "mfma128r": (2, 2), "mfma_auto": (0, 0)}   # mv_set_gemm_variant(force, nj)
+
+
+@pytest.mark.parametrize("impl", ["mfma", "mfma256", "mfma192", "mfma128r", "simple_bf16", "f32"])
 @pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 1), (1, 0)])
 @pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
 def test_gemm_layouts(impl, ta, tb, M, N, K):
     dt = torch.float32 if impl == "f32" else torch.bfloat16
     ops.set_impl(1 if impl == "simple_bf16" else 0)
+    ops.set_gemm_variant(*VARIANT.get(impl, (0, 0)))
     try:
         pad = lambda n: (n + 7) // 8 * 8
         lda = pad(M if ta else K) + 8
@@ -66,9 +70,10 @@ def test_gemm_layouts(impl, ta, tb, M, N, K):
         assert (c[:, N:] == 7.0).all()           # nothing written outside [M,N]
     finally:
         ops.set_impl(0)
+        ops.set_gemm_variant(0, 0)
 
 
-@pytest.mark.parametrize("impl", ["mfma", "f32"])
+@pytest.mark.parametrize("impl", ["mfma", "mfma256", "mfma192", "mfma128r", "f32"])
 @pytest.mark.parametrize("epi", [EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RES, EPI_DGELU, EPI_RES, EPI_BIAS_TANH])
 @pytest.mark.parametrize("M,N,K,cdt", [(256, 384, 128, "bf16"), (200, 130, 72, "f32"), (128, 768, 768, "f32")])
 def test_gemm_epilogues(impl, epi, M, N, K, cdt):
@@ -79,7 +84,11 @@ def test_gemm_epilogues(impl, epi, M, N, K, cdt):
     r = rnd((M, N), dt, 6)
     c = torch.zeros((M, N), dtype=cd, device=DEV)
     c2 = torch.zeros((M, N), dtype=cd, device=DEV)
-    ops.gemm(a, b, c, M=M, N=N, K=K, bias=bias, epi=epi, r=r, c2=c2)
+    ops.set_gemm_variant(*VARIANT.get(impl, (0, 0)))
+    try:
+        ops.gemm(a, b, c, M=M, N=N, K=K, bias=bias, epi=epi, r=r, c2=c2)
+    finally:
+        ops.set_gemm_variant(0, 0)
     y = a.double() @ b.double().t()
     rr = r.double()
     if epi == EPI_BIAS:
@@ -99,20 +108,36 @@ def test_gemm_epilogues(impl, epi, M, N, K, cdt):
     assert relerr(c, ref) < (2e-5 if cd == torch.float32 else 1e-2)
 
 
-@pytest.mark.parametrize("impl", ["mfma", "f32"])
+@pytest.mark.parametrize("impl", ["mfma", "mfma256", "mfma192", "mfma128r", "f32"])
 def test_gemm_splitk_and_accumulate(impl):
     dt = torch.float32 if impl == "f32" else torch.bfloat16
     Mt, No, Ko = 4096, 200, 136
     dy, x = rnd((Mt, No), dt, 7, 0.3), rnd((Mt, Ko), dt, 8, 0.3)
     ref = dy.double().t() @ x.double()
-    for sk in (1, 4, 7):
+    ops.set_gemm_variant(*VARIANT.get(impl, (0, 0)))
+    for sk in (1, 4, 7, 0):
         c = torch.zeros((No, Ko), dtype=torch.float32, device=DEV)
-        ws = torch.empty(sk * No * Ko, dtype=torch.float32, device=DEV)
+        ws = torch.empty(max(sk, 16) * No * Ko, dtype=torch.float32, device=DEV)
         ops.gemm(dy, x, c, ta=True, tb=True, M=No, N=Ko, K=Mt, lda=No, ldb=Ko, splitk=sk, ws=ws)
         assert relerr(c, ref) < 2e-4
     c = torch.ones((No, Ko), dtype=torch.float32, device=DEV)
     ops.gemm(dy, x, c, ta=True, tb=True, M=No, N=Ko, K=Mt, lda=No, ldb=Ko, accumulate=True)
+    ops.set_gemm_variant(0, 0)
     assert relerr(c, ref + 1.0) < 2e-4
+
+
+@pytest.mark.parametrize("ta,tb,M,N,K", [(0, 0, 1024, 768, 768), (0, 1, 2048, 768, 2304), (1, 1, 768, 3072, 8192),
+                                         (0, 0, 515, 2304, 264), (0, 1, 1000, 304, 1032)])
+def test_gemm_auto_dispatch_large(ta, tb, M, N, K):
+    """Shapes that take the 256-row LDS-DMA kernel under the automatic tile choice, incl. auto split-K."""
+    a = rnd((K, M) if ta else (M, K), torch.bfloat16, 12, 0.5)
+    b = rnd((K, N) if tb else (N, K), torch.bfloat16, 13, 0.5)
+    c = torch.zeros((M, N), dtype=torch.float32, device=DEV)
+    ws = torch.empty(16 * M * N, dtype=torch.float32, device=DEV)
+    ops.gemm(a, b, c, ta=bool(ta), tb=bool(tb), M=M, N=N, K=K, splitk=0, ws=ws)
+    A = (a.t() if ta else a).double()
+    Bm = (b if tb else b.t()).double()
+    assert relerr(c, A @ Bm) < 2e-5 * math.sqrt(K)
 
 
 def test_gemm_vocab_sized_tails():
