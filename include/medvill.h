@@ -154,12 +154,14 @@ int mv_embed_fwd(int dtype, const int64_t* cls_tok, const int64_t* txt, const in
                  int B, int N, int T, int H, int V, int maxpos, float eps, void* stream);
 
 /* Backward of the above: LN backward of dx0, scatter-add (f32 atomics) into dE [V,H], dP, dTy,
- * dgamma, dbeta (all ACCUMULATED) and write d(imgproj) [B,N,H] in `dtype`.                     */
+ * dgamma, dbeta (all ACCUMULATED) and write d(imgproj) [B,N,H] in `dtype`.  Row `pad_token_id`
+ * of dE receives no look-up gradient (HF BertEmbeddings builds nn.Embedding(..., padding_idx=
+ * pad_token_id = 0)); pass -1 for none.                                                       */
 int mv_embed_bwd(int dtype, const void* dx0, const float* pre, const float* mean, const float* rstd,
                  const float* gamma, const int64_t* cls_tok, const int64_t* txt, const int64_t* segment,
                  const int64_t* img_pos, const int64_t* sep_tok,
                  float* dE, float* dP, float* dTy, float* dgamma, float* dbeta, void* dimgproj,
-                 int B, int N, int T, int H, int V, int maxpos, void* stream);
+                 int B, int N, int T, int H, int V, int maxpos, int pad_token_id, void* stream);
 
 /* ---- losses + step metrics ------------------------------------------------------------------
  * Replaces nn.CrossEntropyLoss(ignore_index=-100) on mlm.transpose(1,2) and

@@ -36,7 +36,7 @@ PROTOTYPES = {
     "mv_layernorm_fwd": [i32, vp, i32, vp, vp, vp, vp, vp, i32, i32, f32, vp],
     "mv_layernorm_bwd": [i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp],
     "mv_embed_fwd": [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, vp],
-    "mv_embed_bwd": [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
+    "mv_embed_bwd": [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
     "mv_ce_fwd_bwd": [vp, i32, i32, vp, i32, i32, vp, vp, i32, i32, vp, f32, vp],
     "mv_gather_rows": [i32, vp, i32, vp, i32, i32, vp, i32, vp],
     "mv_scatter_rows": [i32, vp, i32, vp, i32, i32, vp, i32, i32, vp],

@@ -243,8 +243,9 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(EmbArgs a, const T* __re
                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
                                                         const float* __restrict__ g, float* __restrict__ dE, float* __restrict__ dP,
                                                         float* __restrict__ dTy, float* __restrict__ dgamma,
-                                                        float* __restrict__ dbeta, T* __restrict__ dimg) {
+                                                        float* __restrict__ dbeta, T* __restrict__ dimg, int pad_id) {
   __shared__ float red[4][4][260];
+  __shared__ __attribute__((aligned(16))) float rowbuf[4][MV_MAX_H];   // per-wave row, re-read lane-contiguously for the atomics
   const int lane = threadIdx.x & 63, wl = threadIdx.x >> 6, H = a.H;
   f32x4 ag[NC], ab[NC], at0[NC], at1[NC];
 #pragma unroll
@@ -281,17 +282,19 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(EmbArgs a, const T* __re
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = rs * (gd[n][e] - s1 - xh[n][e] * s2);
         if (typ == 0) at0[n] += o; else at1[n] += o;
-        float* pp = dP + (size_t)pos * H + c;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) atomicAdd(pp + e, o[e]);
-        if (tok >= 0) {
-          float* ep = dE + (size_t)tok * H + c;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) atomicAdd(ep + e, o[e]);
-        } else {
-          st4<T>(dimg + ((size_t)b * a.N + reg) * H + c, o);
-        }
+        *(f32x4*)(&rowbuf[wl][c]) = o;
+        if (tok < 0) st4<T>(dimg + ((size_t)b * a.N + reg) * H + c, o);
       }
+    }
+    // scatter-add with 64 consecutive floats per wave instruction (the shape float atomics run at full rate in);
+    // the [PAD] row receives no look-up gradient (nn.Embedding padding_idx of HF BertEmbeddings)
+    const bool do_e = (tok >= 0) && (tok != pad_id);
+    float* pp = dP + (size_t)pos * H;
+    float* ep = dE + (size_t)(tok >= 0 ? tok : 0) * H;
+    for (int c = lane; c < H; c += 64) {
+      const float v = rowbuf[wl][c];
+      atomicAdd(pp + c, v);
+      if (do_e) atomicAdd(ep + c, v);
     }
   }
 #pragma unroll
@@ -345,7 +348,7 @@ extern "C" int mv_embed_fwd(int dtype, const int64_t* cls_tok, const int64_t* tx
 extern "C" int mv_embed_bwd(int dtype, const void* dx0, const float* pre, const float* mean, const float* rstd, const float* gamma,
                             const int64_t* cls_tok, const int64_t* txt, const int64_t* segment, const int64_t* img_pos,
                             const int64_t* sep_tok, float* dE, float* dP, float* dTy, float* dgamma, float* dbeta, void* dimgproj,
-                            int B, int N, int T, int H, int V, int maxpos, void* stream_) {
+                            int B, int N, int T, int H, int V, int maxpos, int pad_token_id, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!dx0 || !pre || !mean || !rstd || !gamma || !cls_tok || !txt || !segment || !sep_tok || !dE || !dP || !dTy || !dgamma || !dbeta)
     return MV_E_ARG;
@@ -356,7 +359,7 @@ extern "C" int mv_embed_bwd(int dtype, const void* dx0, const float* pre, const 
   int blocks = (B * a.L + 3) / 4;
   if (blocks > 1024) blocks = 1024;
   dim3 grid(blocks), block(256);
-#define EMB(NC_) hipLaunchKernelGGL((embed_bwd_kernel<T_, NC_>), grid, block, 0, stream, a, (const T_*)dx0, pre, mean, rstd, gamma, dE, dP, dTy, dgamma, dbeta, (T_*)dimgproj)
+#define EMB(NC_) hipLaunchKernelGGL((embed_bwd_kernel<T_, NC_>), grid, block, 0, stream, a, (const T_*)dx0, pre, mean, rstd, gamma, dE, dP, dTy, dgamma, dbeta, (T_*)dimgproj, pad_token_id)
   if (dtype == MV_F32) { typedef float T_; NC_DISPATCH(H, EMB); }
   else if (dtype == MV_BF16) { typedef bf16_t T_; NC_DISPATCH(H, EMB); }
   else return MV_E_DTYPE;
@@ -508,17 +511,50 @@ extern "C" int mv_scatter_rows(int dtype, const void* src, int lds_, const int32
   return MV_OK;
 }
 
-// out[n] += sum_m x[m,n]: block = 64 columns x 4 row-lanes... each thread owns one column of a
-// 256-column strip and walks a slice of the rows (coalesced across the strip).
+// out[n] += sum_m x[m,n].  A block owns a strip of 128 (f32) / 256 (bf16) columns: 32 lanes x one 16-byte vector
+// per row, 8 row-lanes walking a slice of the rows, LDS reduction over the row-lanes, one atomic per column.
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, int ldx, int M, int N, float* __restrict__ out) {
-  const int col = blockIdx.x * 256 + threadIdx.x;
-  if (col >= N) return;
+  constexpr int VEC = 16 / sizeof(T);
+  __shared__ float red[8][32 * VEC + 1];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int col = (blockIdx.x * 32 + tx) * VEC;
   const int rows_per = (M + gridDim.y - 1) / gridDim.y;
   const int r0 = blockIdx.y * rows_per, r1 = min(M, r0 + rows_per);
-  float s = 0.f;
-  for (int r = r0; r < r1; ++r) s += ldf<T>(x + (size_t)r * ldx + col);
-  atomicAdd(out + col, s);
+  float acc[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
+  const bool vec = (col + VEC <= N) && ((ldx % VEC) == 0) && ((((uintptr_t)x) & 15) == 0);
+  if (col < N) {
+    for (int r = r0 + ty; r < r1; r += 8) {
+      const T* p = x + (size_t)r * ldx + col;
+      if (vec) {
+        if (sizeof(T) == 2) {
+          const bf16x8 v = *(const bf16x8*)p;
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) acc[e] += (float)v[e];
+        } else {
+          const f32x4 v = *(const f32x4*)p;
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) acc[e] += v[e];
+        }
+      } else {
+        for (int e = 0; e < VEC && col + e < N; ++e) acc[e] += ldf<T>(p + e);
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) red[ty][tx * VEC + e] = acc[e];
+  __syncthreads();
+  for (int c = threadIdx.x; c < 32 * VEC; c += 256) {
+    const int gc = blockIdx.x * 32 * VEC + c;
+    if (gc < N) {
+      float s_ = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s_ += red[k][c];
+      atomicAdd(out + gc, s_);
+    }
+  }
 }
 __global__ void zero_f32_kernel(float* p, size_t n) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = 0.f;
@@ -531,9 +567,13 @@ extern "C" int mv_colsum(int dtype, const void* x, int ldx, int M, int N, float*
     hipLaunchKernelGGL(zero_f32_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, out, (size_t)N);
     MV_CHECK_LAUNCH();
   }
-  int ysplit = (M + 127) / 128;
-  if (ysplit > 256) ysplit = 256;
-  dim3 grid((N + 255) / 256, ysplit), block(256);
+  const int strip = (dtype == MV_F32) ? 128 : 256;
+  const int xb = (N + strip - 1) / strip;
+  int ysplit = (M + 255) / 256;
+  const int want = (2048 + xb - 1) / xb;          // ~2048 blocks in flight
+  if (ysplit > want) ysplit = want;
+  if (ysplit < 1) ysplit = 1;
+  dim3 grid(xb, ysplit), block(256);
   if (dtype == MV_F32) hipLaunchKernelGGL(colsum_kernel<float>, grid, block, 0, stream, (const float*)x, ldx, M, N, out);
   else if (dtype == MV_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, block, 0, stream, (const bf16_t*)x, ldx, M, N, out);
   else return MV_E_DTYPE;

@@ -77,10 +77,10 @@ def embed_fwd(dt, cls_tok, txt, segment, img_pos, sep_tok, imgproj, E, P, Ty, ga
 
 
 def embed_bwd(dt, dx0, pre, mean, rstd, gamma, cls_tok, txt, segment, img_pos, sep_tok, dE, dP, dTy, dgamma, dbeta, dimgproj, B,
-              N, T, H, V, maxpos):
+              N, T, H, V, maxpos, pad_token_id=0):
     rc = _lib().mv_embed_bwd(dt, L.ptr(dx0), L.ptr(pre), L.ptr(mean), L.ptr(rstd), L.ptr(gamma), L.ptr(cls_tok), L.ptr(txt),
                              L.ptr(segment), L.ptr(img_pos), L.ptr(sep_tok), L.ptr(dE), L.ptr(dP), L.ptr(dTy), L.ptr(dgamma),
-                             L.ptr(dbeta), L.ptr(dimgproj), B, N, T, H, V, maxpos, L.stream_ptr())
+                             L.ptr(dbeta), L.ptr(dimgproj), B, N, T, H, V, maxpos, int(pad_token_id), L.stream_ptr())
     L.check(rc, "mv_embed_bwd")
 
 

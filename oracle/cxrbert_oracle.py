@@ -162,6 +162,9 @@ def expand_aliases(params: "dict[str, torch.Tensor]") -> "OrderedDict[str, torch
 
 
 # --------------------------------------------------------------------------- arithmetic
+PAD_TOKEN_ID = 0
+
+
 def layer_norm(x, g, b, eps):
     """(x-mean)/sqrt(var_biased+eps)*g+b -- HF LayerNorm and the TF-style BertLayerNorm of
     cxrbert_origin.py:198-202 are the same formula (eps inside the sqrt)."""
@@ -203,10 +206,15 @@ def embed(P, cfg, cls_tok, input_txt, segment, img_feats, img_pos, sep_tok, p_dr
         x = layer_norm(x, g, b, cfg.ln_eps)
         return F.dropout(x, p_drop, training) if (training and p_drop > 0) else x
 
-    cls_o = ln_drop(E[cls_tok] + Ty[torch.zeros_like(cls_tok)] + Pos[:1][None])
-    sep_o = ln_drop(E[sep_tok] + Ty[torch.zeros_like(sep_tok)] + Pos[:1][None])
+    def word(ids):
+        # HF BertEmbeddings builds nn.Embedding(vocab, hidden, padding_idx=pad_token_id=0): the LOOK-UP gradient of
+        # row 0 ([PAD]) is always zero (row 0 still gets the tied-decoder gradient, cxrbert_origin.py:231)
+        return F.embedding(ids, E, padding_idx=PAD_TOKEN_ID)
+
+    cls_o = ln_drop(word(cls_tok) + Ty[torch.zeros_like(cls_tok)] + Pos[:1][None])
+    sep_o = ln_drop(word(sep_tok) + Ty[torch.zeros_like(sep_tok)] + Pos[:1][None])
     img_o = ln_drop(F.linear(img_feats, Wi, bi) + Pos[img_pos] + Ty[0][None, None])
-    txt_o = ln_drop(E[input_txt] + Ty[segment] + Pos[:T][None])
+    txt_o = ln_drop(word(input_txt) + Ty[segment] + Pos[:T][None])
     return torch.cat([cls_o, img_o, sep_o, txt_o], dim=1)
 
 

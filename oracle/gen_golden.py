@@ -205,6 +205,8 @@ def run_case(cx, CfgCls, cfg, B, N, S, family, seed, with_grads, full_logits=Fal
         (itm_loss + mlm_loss).backward()
         g = ref_named_grads(model)
         out.update(grad_summary(g, O.param_shapes(cfg)))
+        # full gradient rows of the special tokens of the tied word-embedding matrix ([PAD] row: look-up part is zero)
+        out["dE_special_rows"] = g["enc.txt_embeddings.word_embeddings.weight"][[0, 100, 101, 102, 103]].numpy()
     return out
 
 

@@ -306,8 +306,9 @@ def test_embed_fwd_bwd(dt):
     Ed, Pd, Td, Id = [t.double().requires_grad_(True) for t in (E, P, Ty, imgproj)]
     gd, bd = g.double().requires_grad_(True), b.double().requires_grad_(True)
     z = torch.zeros((B, 1), dtype=torch.int64, device=DEV)
-    rows = torch.cat([Ed[cls_tok][:, None] + Pd[z] + Td[z], Id + Pd[pos] + Td[0][None, None],
-                      Ed[sep_tok][:, None] + Pd[z] + Td[z], Ed[txt] + Pd[torch.arange(T, device=DEV)][None] + Td[seg]], 1)
+    emb = lambda ids: torch.nn.functional.embedding(ids, Ed, padding_idx=0)      # HF BertEmbeddings: padding_idx = 0
+    rows = torch.cat([emb(cls_tok)[:, None] + Pd[z] + Td[z], Id + Pd[pos] + Td[0][None, None],
+                      emb(sep_tok)[:, None] + Pd[z] + Td[z], emb(txt) + Pd[torch.arange(T, device=DEV)][None] + Td[seg]], 1)
     ref = torch.nn.functional.layer_norm(rows, (H,), gd, bd, 1e-12)
     assert relerr(x0, ref) < (1e-5 if dt == torch.float32 else 1e-2)
     dx0 = rnd((B, Lq, H), dt, 48)
@@ -319,6 +320,7 @@ def test_embed_fwd_bwd(dt):
     tol = 1e-4 if dt == torch.float32 else 1e-2
     for got, want in ((dE, Ed.grad), (dP, Pd.grad), (dTy, Td.grad), (dg, gd.grad), (db, bd.grad), (dimg, Id.grad)):
         assert relerr(got, want) < tol
+    assert float(dE[0].abs().max()) == 0.0          # no look-up gradient for the [PAD] row
 
 
 @pytest.mark.parametrize("V,ld", [(2, 2), (1000, 1000), (30522, 30528)])

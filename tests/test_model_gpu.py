@@ -105,6 +105,9 @@ def test_dropin_backward_matches_reference_gradients(golden_dir, name, dtype, rt
         worst = max(worst, e1, e2 * 0.25)
         assert e1 < rtol, (k, e1, ref_norm)
         assert e2 < 4 * rtol + 1e-6, (k, e2)
+    dE = grads["enc.txt_embeddings.word_embeddings.weight"].grad[[0, 100, 101, 102, 103]].float().cpu().numpy()
+    ref = z["dE_special_rows"]
+    assert np.abs(dE - ref).max() < (1e-4 if dtype == torch.float32 else 5e-2) * max(np.abs(ref).max(), 1e-6)
     print(f"{name} {dtype}: worst grad deviation {worst:.2e}")
 
 

@@ -123,6 +123,9 @@ def test_gradients_match_reference(golden_dir, name):
         assert abs(float(g.double().norm()) - ref_norm) <= 1e-4 * max(ref_norm, 1e-6) + 1e-7, k
         got = g.reshape(-1)[torch.from_numpy(z["grad_idx"][i])].numpy()
         assert np.abs(got - z["grad_vals"][i]).max() <= 1e-5 * max(1.0, np.abs(z["grad_vals"][i]).max()) + 1e-7, k
+    # [PAD]/[UNK]/[CLS]/[SEP]/[MASK] rows of the tied matrix (the [PAD] row has no look-up gradient: padding_idx)
+    dE = P["enc.txt_embeddings.word_embeddings.weight"].grad[[0, 100, 101, 102, 103]].numpy()
+    assert np.abs(dE - z["dE_special_rows"]).max() <= 2e-6 * max(1.0, np.abs(z["dE_special_rows"]).max())
 
 
 def test_bert_base_l512_matches_reference(golden_dir):
