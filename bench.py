@@ -132,6 +132,7 @@ def main():
     cfg = mv.ModelConfig(max_pos=c["max_pos"])
     torch.manual_seed(1234)                                 # identical init on every rank: no parameter broadcast
     model = mv.CXRBERT(cfg, None, dtype=torch.bfloat16, device=dev)
+    model.train()                                           # dropout 0.1 at every site, like the reference's train()
     step = mv.TrainStep(model, lr=1e-5, distributed=(world > 1))
     B, N, S = args.batch, c["N"], c["S"]
     L = N + S + 3
@@ -177,7 +178,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": c["name"], "per_gpu_batch": B, "global_batch": B * world, "seq_len": L, "regions": N,
                        "mask": c["family"], "layers": cfg.layers, "hidden": cfg.hidden, "vocab": cfg.vocab_size,
-                       "parallelism": f"dp{world}", "optimizer": "HF AdamW fused", "dropout": 0.0,
+                       "parallelism": f"dp{world}", "optimizer": "HF AdamW fused", "dropout": cfg.dropout,
                        "mlm_loss": float(st[0] / max(float(st[1]), 1.0)), "itm_loss": float(st[3] / max(float(st[4]), 1.0))},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_BF16_TFLOPS, "traffic": None,

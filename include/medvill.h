@@ -86,14 +86,17 @@ void mv_set_gemm_variant(int force, int nj);
  * splitk = 0: let the library pick (needs ws for up to 16 slices, else 1 is used).
  * splitk > 1: the K range is cut in `splitk` slices whose partial tiles go to `ws`
  * (>= splitk*M*N floats) and are summed by a second kernel; only with MV_EPI_NONE and an f32 C.
- * accumulate != 0: C += result (f32 C, MV_EPI_NONE only).                                      */
+ * accumulate != 0: C += result (f32 C, MV_EPI_NONE only).
+ * p_drop > 0 (MV_EPI_BIAS_RES only, N % 4 == 0): C = dropout(A.B + bias) + R -- the hidden-state dropout
+ * of HF BertSelfOutput / BertOutput; mask = mv_dropout_mask(p_drop, drop_key) over index m*N + n.  */
 int mv_gemm(int dtype, int ta, int tb, int M, int N, int K,
             const void* A, int lda, const void* B, int ldb,
             void* C, int ldc, int c_dtype,
             const float* bias, int epi,
             const void* R, int ldr, int r_dtype,
             void* C2, int ldc2,
-            int splitk, float* ws, size_t ws_bytes, int accumulate, void* stream);
+            int splitk, float* ws, size_t ws_bytes, int accumulate,
+            float p_drop, unsigned long long drop_key, void* stream);
 
 /* ---- attention masks ----------------------------------------------------------------------
  * Replaces CXRBertEncoder.get_extended_attn_mask (cxrbert_origin.py:75-85): instead of an
@@ -115,14 +118,18 @@ int mv_mask_pack(const int64_t* mask, int mask_ndim, int B, int L,
  *   ctx[b,i,h,:] = sum_j softmax_j( q.k/sqrt(dh) + (1-mask)*-10000 ) v
  * qkv is the fused projection output [B*L, 3H] (q | k | v, heads contiguous inside each).
  * lse [B, A, L] (f32) = log-sum-exp of each score row, kept for the backward.
- * dh must be 64 (bf16 MFMA path) or <= 128 (f32 path).                                        */
+ * dh must be 64 (bf16 MFMA path) or <= 128 (f32 path).
+ * p_drop > 0: attention-probability dropout (HF BertSelfAttention.dropout): ctx = dropout(softmax).v with the
+ * mask of mv_dropout_mask(p_drop, drop_key) over index ((b*A + h)*L + q)*Lp + k, Lp = L rounded up to 4.  */
 int mv_attn_fwd(int dtype, const void* qkv, const uint32_t* bits, const uint8_t* tileinfo,
-                void* ctx, float* lse, int B, int L, int A, int dh, void* stream);
+                void* ctx, float* lse, int B, int L, int A, int dh,
+                float p_drop, unsigned long long drop_key, void* stream);
 
 /* dqkv [B*L,3H] from dctx [B*L,H]; `delta` is a [B,A,L] f32 scratch (rowsum(dctx*ctx)). */
 int mv_attn_bwd(int dtype, const void* qkv, const void* ctx, const void* dctx, const float* lse,
                 const uint32_t* bits, const uint8_t* tileinfo,
-                void* dqkv, float* delta, int B, int L, int A, int dh, void* stream);
+                void* dqkv, float* delta, int B, int L, int A, int dh,
+                float p_drop, unsigned long long drop_key, void* stream);
 
 /* ---- LayerNorm ------------------------------------------------------------------------------
  * y = (x-mean)/sqrt(var+eps)*gamma+beta over the last dim (HF LayerNorm eps=1e-12 in the
@@ -134,10 +141,13 @@ int mv_layernorm_fwd(int dtype, const void* x, int x_dtype, const float* gamma, 
 
 /* dx (dtype) = LN backward of dy (dtype) w.r.t. x; dgamma/dbeta (f32 [H]) are ACCUMULATED
  * (atomically) -- zero them first; colsum (f32 [H], nullable) accumulates sum_m dx[m,:]
- * (the bias gradient of the projection that produced x).                                      */
+ * (the bias gradient of the projection that produced x).
+ * dx_drop (nullable): second output = dx * dropout_mask / (1 - p), the gradient w.r.t. the projection
+ * output when x = dropout(projection) + residual (mask index m*H + c); colsum then sums dx_drop.  */
 int mv_layernorm_bwd(int dtype, const void* dy, const void* x, int x_dtype, const float* mean,
                      const float* rstd, const float* gamma, void* dx, float* dgamma, float* dbeta,
-                     float* colsum, int M, int H, void* stream);
+                     float* colsum, int M, int H,
+                     void* dx_drop, float p_drop, unsigned long long drop_key, void* stream);
 
 /* ---- sequence assembly + embeddings ---------------------------------------------------------
  * Replaces CXRBertEncoder.forward's else-branch assembly (cxrbert_origin.py:114-125),
@@ -151,7 +161,8 @@ int mv_embed_fwd(int dtype, const int64_t* cls_tok, const int64_t* txt, const in
                  const int64_t* img_pos, const int64_t* sep_tok, const void* imgproj,
                  const void* E, const void* P, const void* Ty, const float* gamma, const float* beta,
                  void* x0, float* pre, float* mean, float* rstd,
-                 int B, int N, int T, int H, int V, int maxpos, float eps, void* stream);
+                 int B, int N, int T, int H, int V, int maxpos, float eps,
+                 float p_drop, unsigned long long drop_key, void* stream);
 
 /* Backward of the above: LN backward of dx0, scatter-add (f32 atomics) into dE [V,H], dP, dTy,
  * dgamma, dbeta (all ACCUMULATED) and write d(imgproj) [B,N,H] in `dtype`.  Row `pad_token_id`
@@ -161,7 +172,8 @@ int mv_embed_bwd(int dtype, const void* dx0, const float* pre, const float* mean
                  const float* gamma, const int64_t* cls_tok, const int64_t* txt, const int64_t* segment,
                  const int64_t* img_pos, const int64_t* sep_tok,
                  float* dE, float* dP, float* dTy, float* dgamma, float* dbeta, void* dimgproj,
-                 int B, int N, int T, int H, int V, int maxpos, int pad_token_id, void* stream);
+                 int B, int N, int T, int H, int V, int maxpos, int pad_token_id,
+                 float p_drop, unsigned long long drop_key, void* stream);
 
 /* ---- losses + step metrics ------------------------------------------------------------------
  * Replaces nn.CrossEntropyLoss(ignore_index=-100) on mlm.transpose(1,2) and
@@ -203,6 +215,13 @@ int mv_cast2d(const void* src, int src_dtype, long long lds, void* dst, int dst_
 
 /* dst(dst_dtype) = src(src_dtype), n elements */
 int mv_cast(const void* src, int src_dtype, void* dst, int dst_dtype, size_t n, void* stream);
+
+/* ---- dropout mask (inspection / tests) -----------------------------------------------------------
+ * The kernels above never store dropout masks: they regenerate them from a counter-based hash of
+ * (drop_key, linear element index).  keep[i] = 1 if element i survives; an element is dropped with
+ * probability round(p_drop*256)/256 and survivors are scaled by *scale_out (HOST pointer, nullable). */
+int mv_dropout_mask(float p_drop, unsigned long long drop_key, size_t n, uint8_t* keep, float* scale_out,
+                    void* stream);
 
 /* ---- optimizer ------------------------------------------------------------------------------
  * HF transformers.optimization.AdamW (<= 4.x) as called at train_origin.py:60,131:

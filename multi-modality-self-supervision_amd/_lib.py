@@ -18,7 +18,7 @@ EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RES, EPI_DGELU, EPI_RES, EPI_BIAS_TA
 _ERR = {-1: "MV_E_ARG (null pointer / bad size)", -2: "MV_E_SHAPE (unsupported shape or alignment)",
         -3: "MV_E_DTYPE", -4: "MV_E_WORKSPACE (workspace too small)"}
 
-vp, i32, i64, f32, sz = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_size_t
+vp, i32, i64, f32, sz, u64 = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_size_t, C.c_ulonglong
 
 # name -> argtypes; every function returns int unless listed in _RESTYPE.  This table is also
 # what tests/test_abi.py checks against include/medvill.h.
@@ -29,14 +29,17 @@ PROTOTYPES = {
     "mv_build_info": [],
     "mv_set_gemm_variant": [i32, i32],
     "mv_gemm": [i32, i32, i32, i32, i32, i32, vp, i32, vp, i32, vp, i32, i32, vp, i32, vp, i32, i32, vp, i32, i32, vp, sz,
-                i32, vp],
+                i32, f32, u64, vp],
     "mv_mask_pack": [vp, i32, i32, i32, vp, vp, vp],
-    "mv_attn_fwd": [i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
-    "mv_attn_bwd": [i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
+    "mv_attn_fwd": [i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, u64, vp],
+    "mv_attn_bwd": [i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, u64, vp],
     "mv_layernorm_fwd": [i32, vp, i32, vp, vp, vp, vp, vp, i32, i32, f32, vp],
-    "mv_layernorm_bwd": [i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp],
-    "mv_embed_fwd": [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, vp],
-    "mv_embed_bwd": [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
+    "mv_layernorm_bwd": [i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, f32, u64, vp],
+    "mv_embed_fwd": [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, f32,
+                     u64, vp],
+    "mv_embed_bwd": [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32,
+                     u64, vp],
+    "mv_dropout_mask": [f32, u64, sz, vp, C.POINTER(C.c_float), vp],
     "mv_ce_fwd_bwd": [vp, i32, i32, vp, i32, i32, vp, vp, i32, i32, vp, f32, vp],
     "mv_gather_rows": [i32, vp, i32, vp, i32, i32, vp, i32, vp],
     "mv_scatter_rows": [i32, vp, i32, vp, i32, i32, vp, i32, i32, vp],

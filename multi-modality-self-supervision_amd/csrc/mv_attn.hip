@@ -102,7 +102,13 @@ struct AttnArgs {
   int B, L, A, H, W, T;
   float scale;
   unsigned bytes_qkv, bytes_ctx;
+  DropCfg drop;   // attention-probability dropout; mask index = ((b*A + h)*L + q)*Lp + k, Lp = L rounded up to 4
+  int Lp;
 };
+// keep-bits of the 4 consecutive keys k4..k4+3 (k4 % 4 == 0) of query row q
+__device__ __forceinline__ unsigned attn_drop_hash(const DropCfg& d, size_t bh, int L, int Lp, int q, int k4) {
+  return mv_hash32((unsigned)(((bh * L + q) * (size_t)Lp + k4) >> 2), d.k0, d.k1);
+}
 
 // dual-use LDS image of a [64 rows][64 x bf16] tile: 128-B rows, 16-B chunk index XORed with f(row)
 __device__ __forceinline__ int att_f(int r) { return (((r >> 1) & 1) << 2) | ((r >> 2) & 3); }
@@ -250,7 +256,19 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_mfma_kernel(AttnArgs a) {
       for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
         for (int r = 0; r < 16; ++r) { const float pv = exp2f(st[kk][r] - mn); st[kk][r] = pv; ps += pv; }
-      lsum = lsum * alpha + ps;
+      lsum = lsum * alpha + ps;          // the normaliser sums the UNdropped probabilities
+      if (a.drop.thr) {
+        const size_t bh = (size_t)b * a.A + head;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const unsigned hh = attn_drop_hash(a.drop, bh, L, a.Lp, q_ok ? q : 0, k0 + 32 * kk + 8 * g + 4 * h);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (!mv_keep(hh, e, a.drop.thr)) st[kk][4 * g + e] = 0.f;
+          }
+      }
 #pragma unroll
       for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
 #pragma unroll
@@ -273,7 +291,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_mfma_kernel(AttnArgs a) {
   }
   if (!q_ok) return;
   const float ltot = lsum + __shfl_xor(lsum, 32, 64);
-  const float inv = 1.0f / ltot;
+  const float inv = (a.drop.thr ? a.drop.inv_keep : 1.0f) / ltot;
   bf16_t* orow = a.out + (rowbase + q) * (size_t)H + head * 64;
 #pragma unroll
   for (int dt = 0; dt < 2; ++dt)
@@ -351,6 +369,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_mfma_kernel(AttnArgs a) {
         }
         uint32_t w = 0xffffffffu;
         if (cls != 1) { const int wi = (k0 >> 5) + kk; w = (q_ok && wi < a.W) ? myw[wi] : 0xffffffffu; }
+        unsigned hcur = 0;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int kr = acc_row(r, h);
@@ -358,7 +377,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_mfma_kernel(AttnArgs a) {
           if (cls != 1) v += ((w >> kr) & 1u) ? 0.f : MASK_ADD * LOG2E;
           float pv = exp2f(v - lse2);
           if (tail && (k0 + 32 * kk + kr >= L)) pv = 0.f;
-          st[r] = pv * (dp[r] - dlt) * a.scale;
+          float dpr = dp[r];
+          if (a.drop.thr) {
+            if ((r & 3) == 0) hcur = attn_drop_hash(a.drop, (size_t)b * a.A + head, L, a.Lp, q_ok ? q : 0, k0 + 32 * kk + kr);
+            dpr = mv_keep(hcur, r & 3, a.drop.thr) ? dpr * a.drop.inv_keep : 0.f;
+          }
+          st[r] = pv * (dpr - dlt) * a.scale;
         }
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
@@ -482,8 +506,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_mfma_kernel(AttnArgs a) {
               v += ((w >> l31) & 1u) ? 0.f : MASK_ADD * LOG2E;
             }
             const float p = exp2f(v - l4[e]);     // rows q >= L carry lse = +inf -> p = 0
-            pv[r] = p;
-            sc[r] = p * (dp[r] - d4[e]) * a.scale;
+            float keepf = 1.0f;
+            if (a.drop.thr) {
+              const int qg = min(cur * 64 + qr0 + e, L - 1), kg = min(key, L - 1);
+              const unsigned hh = attn_drop_hash(a.drop, (size_t)b * a.A + head, L, a.Lp, qg, kg & ~3);
+              keepf = mv_keep(hh, kg & 3, a.drop.thr) ? a.drop.inv_keep : 0.f;
+            }
+            pv[r] = p * keepf;
+            sc[r] = p * (keepf * dp[r] - d4[e]) * a.scale;
           }
         }
 #pragma unroll
@@ -526,6 +556,8 @@ struct SArgs {
   const uint32_t* bits; float* lse; const float* lse_in; float* delta;
   int B, L, A, H, W, dh;
   float scale;
+  DropCfg drop;
+  int Lp;
 };
 
 // delta[b,h,q] = sum_d dctx*ctx   (one wave per (b,q,h))
@@ -578,7 +610,12 @@ __global__ __launch_bounds__(256) void attn_fwd_simple_kernel(SArgs<T> a) {
     const float p = (k < a.L) ? expf(s - mn) : 0.f;
     l = l * alpha + wave_sum(p);
     m = mn;
-    sp[wl][lane] = p;
+    float pd = p;
+    if (a.drop.thr && k < a.L) {
+      const unsigned hh = attn_drop_hash(a.drop, (size_t)b * a.A + hd, a.L, a.Lp, q, k & ~3);
+      pd = mv_keep(hh, k & 3, a.drop.thr) ? p * a.drop.inv_keep : 0.f;
+    }
+    sp[wl][lane] = pd;
     o0 *= alpha; o1 *= alpha;
     const int kn = min(64, a.L - k0);
     for (int j = 0; j < kn; ++j) {
@@ -624,6 +661,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_simple_kernel(SArgs<T> a) {
       float acc = 0.f, dp = 0.f;
       for (int i = 0; i < dh; ++i) { acc = fmaf(sq[wl][i], ldf<T>(kp + i), acc); dp = fmaf(sdo[wl][i], ldf<T>(vp + i), dp); }
       const float s = acc * a.scale + (((wrow[k >> 5] >> (k & 31)) & 1u) ? 0.f : MASK_ADD);
+      if (a.drop.thr) {
+        const unsigned hh = attn_drop_hash(a.drop, (size_t)b * a.A + hd, a.L, a.Lp, q, k & ~3);
+        dp = mv_keep(hh, k & 3, a.drop.thr) ? dp * a.drop.inv_keep : 0.f;
+      }
       ds = expf(s - lse) * (dp - dl) * a.scale;
     }
     sds[wl][lane] = ds;
@@ -671,7 +712,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_simple_kernel(SArgs<T> a) {
       const uint32_t w = a.bits[(rb + q) * a.W + (k >> 5)];
       const float s = acc * a.scale + (((w >> (k & 31)) & 1u) ? 0.f : MASK_ADD);
       p = expf(s - a.lse_in[sb + q]);
-      ds = p * (dp - a.delta[sb + q]) * a.scale;
+      float keepf = 1.0f;
+      if (a.drop.thr) {
+        const unsigned hh = attn_drop_hash(a.drop, (size_t)b * a.A + hd, a.L, a.Lp, q, k & ~3);
+        keepf = mv_keep(hh, k & 3, a.drop.thr) ? a.drop.inv_keep : 0.f;
+      }
+      ds = p * (keepf * dp - a.delta[sb + q]) * a.scale;
+      p *= keepf;
     }
     sds[wl][lane] = ds;
     spp[wl][lane] = p;
@@ -695,8 +742,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_simple_kernel(SArgs<T> a) {
 // =========================================================================================
 template <typename T>
 static int launch_simple_fwd(const void* qkv, const uint32_t* bits, void* ctx, float* lse, int B, int L, int A, int dh,
-                             hipStream_t stream) {
+                             DropCfg drop, hipStream_t stream) {
   SArgs<T> s{};
+  s.drop = drop; s.Lp = (L + 3) & ~3;
   s.qkv = (const T*)qkv; s.out = (T*)ctx; s.bits = bits; s.lse = lse;
   s.B = B; s.L = L; s.A = A; s.H = A * dh; s.W = (L + 31) / 32; s.dh = dh; s.scale = 1.0f / sqrtf((float)dh);
   const long long waves = (long long)B * A * L;
@@ -706,8 +754,10 @@ static int launch_simple_fwd(const void* qkv, const uint32_t* bits, void* ctx, f
 }
 
 extern "C" int mv_attn_fwd(int dtype, const void* qkv, const uint32_t* bits, const uint8_t* tileinfo, void* ctx, float* lse,
-                           int B, int L, int A, int dh, void* stream_) {
+                           int B, int L, int A, int dh, float p_drop, unsigned long long drop_key, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  const DropCfg drop = mv_make_drop(p_drop, drop_key);
+  if ((size_t)B * A * L * ((L + 3) & ~3) >= (1ull << 34)) return MV_E_SHAPE;   // mask counter is 32 bits of (index >> 2)
   if (!qkv || !bits || !tileinfo || !ctx || !lse || B <= 0 || L <= 0 || A <= 0 || dh <= 0) return MV_E_ARG;
   if (dtype != MV_F32 && dtype != MV_BF16) return MV_E_DTYPE;
   const int H = A * dh;
@@ -720,6 +770,7 @@ extern "C" int mv_attn_fwd(int dtype, const void* qkv, const uint32_t* bits, con
     a.B = B; a.L = L; a.A = A; a.H = H; a.W = (L + 31) / 32; a.T = (L + 63) / 64;
     a.scale = 1.0f / sqrtf((float)dh);
     a.bytes_qkv = (unsigned)bq;
+    a.drop = drop; a.Lp = (L + 3) & ~3;
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void*)attn_fwd_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 32768); attr = true; }
     hipLaunchKernelGGL(attn_fwd_mfma_kernel, dim3((L + 127) / 128, A, B), dim3(256), 32768, stream, a);
@@ -727,14 +778,15 @@ extern "C" int mv_attn_fwd(int dtype, const void* qkv, const uint32_t* bits, con
     return MV_OK;
   }
   if (dh > 128) return MV_E_SHAPE;
-  return dtype == MV_F32 ? launch_simple_fwd<float>(qkv, bits, ctx, lse, B, L, A, dh, stream)
-                         : launch_simple_fwd<bf16_t>(qkv, bits, ctx, lse, B, L, A, dh, stream);
+  return dtype == MV_F32 ? launch_simple_fwd<float>(qkv, bits, ctx, lse, B, L, A, dh, drop, stream)
+                         : launch_simple_fwd<bf16_t>(qkv, bits, ctx, lse, B, L, A, dh, drop, stream);
 }
 
 template <typename T>
 static int launch_simple_bwd(const void* qkv, const void* ctx, const void* dctx, const float* lse, const uint32_t* bits,
-                             void* dqkv, float* delta, int B, int L, int A, int dh, hipStream_t stream) {
+                             void* dqkv, float* delta, int B, int L, int A, int dh, DropCfg drop, hipStream_t stream) {
   SArgs<T> s{};
+  s.drop = drop; s.Lp = (L + 3) & ~3;
   s.qkv = (const T*)qkv; s.ctx = (const T*)ctx; s.dctx = (const T*)dctx; s.dqkv = (T*)dqkv; s.bits = bits;
   s.lse_in = lse; s.delta = delta;
   s.B = B; s.L = L; s.A = A; s.H = A * dh; s.W = (L + 31) / 32; s.dh = dh; s.scale = 1.0f / sqrtf((float)dh);
@@ -750,8 +802,10 @@ static int launch_simple_bwd(const void* qkv, const void* ctx, const void* dctx,
 }
 
 extern "C" int mv_attn_bwd(int dtype, const void* qkv, const void* ctx, const void* dctx, const float* lse, const uint32_t* bits,
-                           const uint8_t* tileinfo, void* dqkv, float* delta, int B, int L, int A, int dh, void* stream_) {
+                           const uint8_t* tileinfo, void* dqkv, float* delta, int B, int L, int A, int dh, float p_drop,
+                           unsigned long long drop_key, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  const DropCfg drop = mv_make_drop(p_drop, drop_key);
   if (!qkv || !ctx || !dctx || !lse || !bits || !tileinfo || !dqkv || !delta || B <= 0 || L <= 0 || A <= 0 || dh <= 0)
     return MV_E_ARG;
   if (dtype != MV_F32 && dtype != MV_BF16) return MV_E_DTYPE;
@@ -770,6 +824,7 @@ extern "C" int mv_attn_bwd(int dtype, const void* qkv, const void* ctx, const vo
     a.B = B; a.L = L; a.A = A; a.H = H; a.W = (L + 31) / 32; a.T = (L + 63) / 64;
     a.scale = 1.0f / sqrtf((float)dh);
     a.bytes_qkv = (unsigned)bq; a.bytes_ctx = (unsigned)bc;
+    a.drop = drop; a.Lp = (L + 3) & ~3;
     static bool attr = false;
     if (!attr) {
       (void)hipFuncSetAttribute((const void*)attn_bwd_dq_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 32768);
@@ -784,6 +839,6 @@ extern "C" int mv_attn_bwd(int dtype, const void* qkv, const void* ctx, const vo
     return MV_OK;
   }
   if (dh > 128) return MV_E_SHAPE;
-  return dtype == MV_F32 ? launch_simple_bwd<float>(qkv, ctx, dctx, lse, bits, dqkv, delta, B, L, A, dh, stream)
-                         : launch_simple_bwd<bf16_t>(qkv, ctx, dctx, lse, bits, dqkv, delta, B, L, A, dh, stream);
+  return dtype == MV_F32 ? launch_simple_bwd<float>(qkv, ctx, dctx, lse, bits, dqkv, delta, B, L, A, dh, drop, stream)
+                         : launch_simple_bwd<bf16_t>(qkv, ctx, dctx, lse, bits, dqkv, delta, B, L, A, dh, drop, stream);
 }

@@ -79,6 +79,47 @@ __device__ __forceinline__ float dgelu_erf(float z) {
   return cdf + z * pdf;
 }
 
+// ---- dropout: counter-based mask, regenerated (never stored) in the backward kernels --------------------------
+// One 32-bit hash per group of 4 consecutive elements (linear index >> 2), one byte per element; an element is
+// dropped when its byte < thr, i.e. with probability thr/256 (p = 0.1 -> thr = 26 -> 0.1016; survivors are scaled by
+// 1/(1 - thr/256) so the expectation is preserved exactly).  Keys are derived on the host per (step, site, layer).
+struct DropCfg {
+  unsigned k0, k1, thr;   // thr == 0: dropout off
+  float inv_keep;
+};
+__device__ __forceinline__ unsigned mv_hash32(unsigned x, unsigned k0, unsigned k1) {
+  x = (x ^ k0) * 0x9E3779B1u;
+  x ^= x >> 15;
+  x = (x ^ k1) * 0x85EBCA6Bu;
+  x ^= x >> 13;
+  x *= 0xC2B2AE35u;
+  x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ bool mv_keep(unsigned h, int e, unsigned thr) { return ((h >> (8 * e)) & 0xffu) >= thr; }
+// 4 consecutive elements starting at linear index idx (idx % 4 == 0)
+__device__ __forceinline__ f32x4 mv_drop4(f32x4 v, size_t idx, const DropCfg& d) {
+  const unsigned h = mv_hash32((unsigned)(idx >> 2), d.k0, d.k1);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] = mv_keep(h, e, d.thr) ? v[e] * d.inv_keep : 0.f;
+  return v;
+}
+__device__ __forceinline__ float mv_drop1(float v, size_t idx, const DropCfg& d) {
+  const unsigned h = mv_hash32((unsigned)(idx >> 2), d.k0, d.k1);
+  return mv_keep(h, (int)(idx & 3), d.thr) ? v * d.inv_keep : 0.f;
+}
+static inline DropCfg mv_make_drop(float p, unsigned long long key) {
+  DropCfg d;
+  int thr = (int)(p * 256.0f + 0.5f);
+  if (p <= 0.f) thr = 0;
+  if (thr > 255) thr = 255;
+  d.thr = (unsigned)thr;
+  d.k0 = (unsigned)(key & 0xffffffffULL);
+  d.k1 = (unsigned)(key >> 32);
+  d.inv_keep = 1.0f / (1.0f - (float)thr / 256.0f);
+  return d;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -25,6 +25,7 @@ struct GemmArgs {
   int kchunk, splitk;
   float* ws;
   unsigned bytesA, bytesB;
+  DropCfg drop;   // MV_EPI_BIAS_RES only: C = dropout(A.B + bias) + R
   int dbg;   // ablation bits (timing experiments only): 1 skip C stores, 2 skip operand loads, 4 skip LDS reads + MFMA
 };
 
@@ -45,7 +46,11 @@ __device__ __forceinline__ void epilogue4_slow(const GemmArgs& p, int m, int n, 
     switch (e) {
       case MV_EPI_BIAS: x += b; break;
       case MV_EPI_BIAS_GELU: x += b; break;
-      case MV_EPI_BIAS_RES: x += b + r; break;
+      case MV_EPI_BIAS_RES:
+        x += b;
+        if (p.drop.thr) x = mv_drop1(x, (size_t)m * p.N + n + i, p.drop);
+        x += r;
+        break;
       case MV_EPI_DGELU: x *= dgelu_erf(r); break;
       case MV_EPI_RES: x += r; break;
       case MV_EPI_BIAS_TANH: x = tanhf(x + b); break;
@@ -68,6 +73,7 @@ __device__ __forceinline__ void epilogue4t(const GemmArgs& p, int m, int n, f32x
   const size_t co = (size_t)m * p.ldc + n;
   f32x4 o = v;
   if (E == MV_EPI_BIAS || E == MV_EPI_BIAS_GELU || E == MV_EPI_BIAS_RES || E == MV_EPI_BIAS_TANH) o += *(const f32x4*)(p.bias + n);
+  if (E == MV_EPI_BIAS_RES && p.drop.thr) o = mv_drop4(o, (size_t)m * p.N + n, p.drop);
   if (E == MV_EPI_BIAS_RES || E == MV_EPI_DGELU || E == MV_EPI_RES) {
     const size_t ro = (size_t)m * p.ldr + n;
     const f32x4 r = (p.r_dtype == MV_F32) ? ld4<float>((const float*)p.R + ro) : ld4<bf16_t>((const bf16_t*)p.R + ro);
@@ -556,7 +562,8 @@ static inline bool aligned_to(const void* p, size_t a) { return p == nullptr || 
 
 extern "C" int mv_gemm(int dtype, int ta, int tb, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
                        void* C, int ldc, int c_dtype, const float* bias, int epi, const void* R, int ldr, int r_dtype,
-                       void* C2, int ldc2, int splitk, float* ws, size_t ws_bytes, int accumulate, void* stream_) {
+                       void* C2, int ldc2, int splitk, float* ws, size_t ws_bytes, int accumulate, float p_drop,
+                       unsigned long long drop_key, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) return MV_E_ARG;
   if (dtype != MV_F32 && dtype != MV_BF16) return MV_E_DTYPE;
@@ -582,6 +589,8 @@ extern "C" int mv_gemm(int dtype, int ta, int tb, int M, int N, int K, const voi
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldc2 = ldc2; p.ldr = ldr;
   p.c_dtype = c_dtype; p.r_dtype = r_dtype; p.epi = epi; p.accumulate = accumulate;
   p.splitk = splitk; p.ws = ws; p.dbg = g_mv_gemm_dbg;
+  p.drop = mv_make_drop(epi == MV_EPI_BIAS_RES ? p_drop : 0.f, drop_key);
+  if (p.drop.thr && (N & 3)) return MV_E_SHAPE;   // the mask is keyed on groups of 4 consecutive columns
   const size_t csz = (c_dtype == MV_F32) ? 16 : 8;
   const size_t rsz = (r_dtype == MV_F32) ? 16 : 8;
   p.vec_ok = ((ldc & 3) == 0) && aligned_to(C, csz) && (!need_bias || aligned_to(bias, 16)) &&

@@ -67,7 +67,8 @@ template <typename TX, typename TD, int NC>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const TD* __restrict__ dy, const TX* __restrict__ x,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ g, TD* __restrict__ dx, float* __restrict__ dgamma,
-                                                     float* __restrict__ dbeta, float* __restrict__ colsum, int M, int H) {
+                                                     float* __restrict__ dbeta, float* __restrict__ colsum, int M, int H,
+                                                     TD* __restrict__ dx_drop, DropCfg drop) {
   __shared__ float red[3][4][260];
   const int lane = threadIdx.x & 63, wl = threadIdx.x >> 6;
   f32x4 ag[NC], ab[NC], ac[NC];
@@ -105,8 +106,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TD* __restrict__ dy, 
       if (c < H) {
         f32x4 o;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { o[e] = rs * (gd[n][e] - s1 - xh[n][e] * s2); ac[n][e] += o[e]; }
+        for (int e = 0; e < 4; ++e) o[e] = rs * (gd[n][e] - s1 - xh[n][e] * s2);
         st4<TD>(dxr + c, o);
+        if (dx_drop) {      // gradient w.r.t. the projection output that went through dropout before the residual add
+          o = mv_drop4(o, (size_t)row * H + c, drop);
+          st4<TD>(dx_drop + (size_t)row * H + c, o);
+        }
+        ac[n] += o;         // colsum = bias gradient of that projection
       }
     }
   }
@@ -147,14 +153,16 @@ extern "C" int mv_layernorm_fwd(int dtype, const void* x, int x_dtype, const flo
 
 extern "C" int mv_layernorm_bwd(int dtype, const void* dy, const void* x, int x_dtype, const float* mean, const float* rstd,
                                 const float* gamma, void* dx, float* dgamma, float* dbeta, float* colsum, int M, int H,
-                                void* stream_) {
+                                void* dx_drop, float p_drop, unsigned long long drop_key, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!dy || !x || !mean || !rstd || !gamma || !dx || !dgamma || !dbeta || M <= 0 || H <= 0) return MV_E_ARG;
   if ((H & 3) || H > MV_MAX_H) return MV_E_SHAPE;
   int blocks = (M + 3) / 4;
   if (blocks > 1024) blocks = 1024;
   dim3 grid(blocks), block(256);
-#define LNB(NC_) hipLaunchKernelGGL((ln_bwd_kernel<TX_, TD_, NC_>), grid, block, 0, stream, (const TD_*)dy, (const TX_*)x, mean, rstd, gamma, (TD_*)dx, dgamma, dbeta, colsum, M, H)
+  const DropCfg drop = mv_make_drop(dx_drop ? p_drop : 0.f, drop_key);
+  if (dx_drop && drop.thr == 0) dx_drop = nullptr;
+#define LNB(NC_) hipLaunchKernelGGL((ln_bwd_kernel<TX_, TD_, NC_>), grid, block, 0, stream, (const TD_*)dy, (const TX_*)x, mean, rstd, gamma, (TD_*)dx, dgamma, dbeta, colsum, M, H, (TD_*)dx_drop, drop)
   if (dtype == MV_F32 && x_dtype == MV_F32) { typedef float TX_; typedef float TD_; NC_DISPATCH(H, LNB); }
   else if (dtype == MV_BF16 && x_dtype == MV_F32) { typedef float TX_; typedef bf16_t TD_; NC_DISPATCH(H, LNB); }
   else if (dtype == MV_BF16 && x_dtype == MV_BF16) { typedef bf16_t TX_; typedef bf16_t TD_; NC_DISPATCH(H, LNB); }
@@ -190,7 +198,7 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(EmbArgs a, const T* __re
                                                         const T* __restrict__ P, const T* __restrict__ Ty,
                                                         const float* __restrict__ g, const float* __restrict__ bta,
                                                         T* __restrict__ x0, float* __restrict__ pre, float* __restrict__ mean,
-                                                        float* __restrict__ rstd, float eps) {
+                                                        float* __restrict__ rstd, float eps, DropCfg drop) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= a.B * a.L) return;
@@ -231,6 +239,7 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(EmbArgs a, const T* __re
       f32x4 o;
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = (v[n][e] - mu) * rs * gg[e] + bb[e];
+      if (drop.thr) o = mv_drop4(o, (size_t)row * H + c, drop);
       st4<T>(x0 + (size_t)row * H + c, o);
       *(f32x4*)(pre + (size_t)row * H + c) = v[n];
     }
@@ -243,7 +252,7 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(EmbArgs a, const T* __re
                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
                                                         const float* __restrict__ g, float* __restrict__ dE, float* __restrict__ dP,
                                                         float* __restrict__ dTy, float* __restrict__ dgamma,
-                                                        float* __restrict__ dbeta, T* __restrict__ dimg, int pad_id) {
+                                                        float* __restrict__ dbeta, T* __restrict__ dimg, int pad_id, DropCfg drop) {
   __shared__ float red[4][4][260];
   __shared__ __attribute__((aligned(16))) float rowbuf[4][MV_MAX_H];   // per-wave row, re-read lane-contiguously for the atomics
   const int lane = threadIdx.x & 63, wl = threadIdx.x >> 6, H = a.H;
@@ -263,7 +272,9 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(EmbArgs a, const T* __re
       const int c = lane * 4 + 256 * n;
       xh[n] = (f32x4){0, 0, 0, 0}; gd[n] = xh[n];
       if (c < H) {
-        const f32x4 d = ld4<T>(dx0 + (size_t)row * H + c), xv = *(const f32x4*)(pre + (size_t)row * H + c), gg = *(const f32x4*)(g + c);
+        f32x4 d = ld4<T>(dx0 + (size_t)row * H + c);
+        const f32x4 xv = *(const f32x4*)(pre + (size_t)row * H + c), gg = *(const f32x4*)(g + c);
+        if (drop.thr) d = mv_drop4(d, (size_t)row * H + c, drop);      // back through the embedding dropout
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const float h_ = (xv[e] - mu) * rs, gde = gg[e] * d[e];
@@ -327,7 +338,7 @@ static int emb_check(int B, int N, int T, int H, int V, int maxpos) {
 extern "C" int mv_embed_fwd(int dtype, const int64_t* cls_tok, const int64_t* txt, const int64_t* segment, const int64_t* img_pos,
                             const int64_t* sep_tok, const void* imgproj, const void* E, const void* P, const void* Ty,
                             const float* gamma, const float* beta, void* x0, float* pre, float* mean, float* rstd, int B, int N,
-                            int T, int H, int V, int maxpos, float eps, void* stream_) {
+                            int T, int H, int V, int maxpos, float eps, float p_drop, unsigned long long drop_key, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!cls_tok || !txt || !segment || !sep_tok || !E || !P || !Ty || !gamma || !beta || !x0 || !pre || !mean || !rstd) return MV_E_ARG;
   if (N > 0 && (!img_pos || !imgproj)) return MV_E_ARG;
@@ -336,7 +347,8 @@ extern "C" int mv_embed_fwd(int dtype, const int64_t* cls_tok, const int64_t* tx
   if (T > maxpos) return MV_E_SHAPE;   // text positions 0..T-1 must exist
   EmbArgs a{cls_tok, txt, segment, img_pos, sep_tok, B, N, T, H, V, maxpos, N + T + 2};
   dim3 grid((B * a.L + 3) / 4), block(256);
-#define EMF(NC_) hipLaunchKernelGGL((embed_fwd_kernel<T_, NC_>), grid, block, 0, stream, a, (const T_*)imgproj, (const T_*)E, (const T_*)P, (const T_*)Ty, gamma, beta, (T_*)x0, pre, mean, rstd, eps)
+  const DropCfg drop = mv_make_drop(p_drop, drop_key);
+#define EMF(NC_) hipLaunchKernelGGL((embed_fwd_kernel<T_, NC_>), grid, block, 0, stream, a, (const T_*)imgproj, (const T_*)E, (const T_*)P, (const T_*)Ty, gamma, beta, (T_*)x0, pre, mean, rstd, eps, drop)
   if (dtype == MV_F32) { typedef float T_; NC_DISPATCH(H, EMF); }
   else if (dtype == MV_BF16) { typedef bf16_t T_; NC_DISPATCH(H, EMF); }
   else return MV_E_DTYPE;
@@ -348,7 +360,8 @@ extern "C" int mv_embed_fwd(int dtype, const int64_t* cls_tok, const int64_t* tx
 extern "C" int mv_embed_bwd(int dtype, const void* dx0, const float* pre, const float* mean, const float* rstd, const float* gamma,
                             const int64_t* cls_tok, const int64_t* txt, const int64_t* segment, const int64_t* img_pos,
                             const int64_t* sep_tok, float* dE, float* dP, float* dTy, float* dgamma, float* dbeta, void* dimgproj,
-                            int B, int N, int T, int H, int V, int maxpos, int pad_token_id, void* stream_) {
+                            int B, int N, int T, int H, int V, int maxpos, int pad_token_id, float p_drop,
+                            unsigned long long drop_key, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!dx0 || !pre || !mean || !rstd || !gamma || !cls_tok || !txt || !segment || !sep_tok || !dE || !dP || !dTy || !dgamma || !dbeta)
     return MV_E_ARG;
@@ -359,7 +372,8 @@ extern "C" int mv_embed_bwd(int dtype, const void* dx0, const float* pre, const 
   int blocks = (B * a.L + 3) / 4;
   if (blocks > 1024) blocks = 1024;
   dim3 grid(blocks), block(256);
-#define EMB(NC_) hipLaunchKernelGGL((embed_bwd_kernel<T_, NC_>), grid, block, 0, stream, a, (const T_*)dx0, pre, mean, rstd, gamma, dE, dP, dTy, dgamma, dbeta, (T_*)dimgproj, pad_token_id)
+  const DropCfg drop = mv_make_drop(p_drop, drop_key);
+#define EMB(NC_) hipLaunchKernelGGL((embed_bwd_kernel<T_, NC_>), grid, block, 0, stream, a, (const T_*)dx0, pre, mean, rstd, gamma, dE, dP, dTy, dgamma, dbeta, (T_*)dimgproj, pad_token_id, drop)
   if (dtype == MV_F32) { typedef float T_; NC_DISPATCH(H, EMB); }
   else if (dtype == MV_BF16) { typedef bf16_t T_; NC_DISPATCH(H, EMB); }
   else return MV_E_DTYPE;
@@ -577,6 +591,25 @@ extern "C" int mv_colsum(int dtype, const void* x, int ldx, int M, int N, float*
   if (dtype == MV_F32) hipLaunchKernelGGL(colsum_kernel<float>, grid, block, 0, stream, (const float*)x, ldx, M, N, out);
   else if (dtype == MV_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, block, 0, stream, (const bf16_t*)x, ldx, M, N, out);
   else return MV_E_DTYPE;
+  MV_CHECK_LAUNCH();
+  return MV_OK;
+}
+
+// keep-mask of the counter-based dropout for linear indices 0..n-1 (test / inspection utility)
+__global__ void dropout_mask_kernel(uint8_t* __restrict__ out, size_t n, DropCfg d) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const unsigned h = mv_hash32((unsigned)(i >> 2), d.k0, d.k1);
+    out[i] = (d.thr == 0 || mv_keep(h, (int)(i & 3), d.thr)) ? 1 : 0;
+  }
+}
+extern "C" int mv_dropout_mask(float p_drop, unsigned long long drop_key, size_t n, uint8_t* keep, float* scale_out, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!keep || n == 0) return MV_E_ARG;
+  const DropCfg d = mv_make_drop(p_drop, drop_key);
+  if (scale_out) *scale_out = d.inv_keep;     // host pointer: 1 / (1 - thr/256)
+  int blocks = (int)((n + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(dropout_mask_kernel, dim3(blocks), dim3(256), 0, stream, keep, n, d);
   MV_CHECK_LAUNCH();
   return MV_OK;
 }

@@ -34,7 +34,8 @@ def model_config_from(config) -> ModelConfig:
     return ModelConfig(vocab_size=get("vocab_size", 30522), hidden=get("hidden_size", 768), layers=get("num_hidden_layers", 12),
                        heads=get("num_attention_heads", 12), intermediate=get("intermediate_size", 3072),
                        max_pos=get("max_position_embeddings", 512), type_vocab=get("type_vocab_size", 2),
-                       img_hidden=get("img_hidden_sz", 2048), ln_eps=get("layer_norm_eps", 1e-12))
+                       img_hidden=get("img_hidden_sz", 2048), ln_eps=get("layer_norm_eps", 1e-12),
+                       dropout=get("hidden_dropout_prob", 0.1))
 
 
 class _CXRBertFn(torch.autograd.Function):
@@ -47,6 +48,7 @@ class _CXRBertFn(torch.autograd.Function):
     def forward(ctx, model, want_heads, cls_tok, input_txt, attn_mask, segment, feats, pos, sep_tok, *params):
         eng = model.engine
         eng.shadow_dirty = True                 # parameters may have been stepped by an external optimizer
+        eng.training = model.training           # dropout (p = 0.1 at every site of the reference) only in train mode
         hidden, pooled = eng.encoder_forward(cls_tok, input_txt, attn_mask, segment, feats, pos, sep_tok)
         ctx.model, ctx.want_heads = model, want_heads
         if want_heads:

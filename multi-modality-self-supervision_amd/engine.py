@@ -38,6 +38,7 @@ class ModelConfig:
     img_hidden: int = 2048
     ln_eps: float = 1e-12
     head_ln_eps: float = 1e-5
+    dropout: float = 0.1          # hidden_dropout_prob = attention_probs_dropout_prob = args.dropout_prob = 0.1 in the reference
 
     def to_dict(self):
         return asdict(self)
@@ -126,6 +127,9 @@ class Engine:
         self.shadow_dirty = True
         self._ws = {}
         self._gemm_ws = None
+        self.training = False         # dropout is active only when True (CXRBERT.train() / TrainStep(train=True))
+        self.drop_seed = 0x5DEECE66D
+        self.drop_counter = 0         # advanced once per forward: every step draws fresh masks
         self._bind()
 
     # ------------------------------------------------------------------ storage
@@ -193,6 +197,23 @@ class Engine:
             gb = self.flat_g[boff:boff + 3 * H]
         return W, b, gW, gb
 
+    # ------------------------------------------------------------------ dropout keys
+    SITE_EMB, SITE_ATTN, SITE_OUT1, SITE_OUT2 = 1, 2, 3, 4
+
+    def _drop_keys(self, layers):
+        """64-bit keys of the counter-based dropout masks of this forward pass: (site, layer) -> key (splitmix64)."""
+        def mix(x):
+            x = (x + 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+            x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+            x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+            return x ^ (x >> 31)
+        base = mix(self.drop_seed ^ (self.drop_counter << 24))
+        keys = {(self.SITE_EMB, 0): mix(base ^ 1)}
+        for l in range(layers):
+            for site in (self.SITE_ATTN, self.SITE_OUT1, self.SITE_OUT2):
+                keys[(site, l)] = mix(base ^ (site << 16) ^ (l + 1))
+        return keys
+
     # ------------------------------------------------------------------ workspaces
     def _buf(self, key, shape, dtype):
         t = self._ws.get(key)
@@ -229,6 +250,9 @@ class Engine:
             self.sync_shadow()
         f32 = torch.float32
         S = self.S = dict(B=B, T=T, N=N, L=Lq, M=M)
+        pd = S["p_drop"] = float(cfg.dropout) if self.training else 0.0
+        self.drop_counter += 1
+        dk = S["drop_keys"] = self._drop_keys(cfg.layers)
         i64 = torch.int64
         S["cls_tok"] = cls_tok.to(dev, i64).contiguous().view(-1)
         S["sep_tok"] = sep_tok.to(dev, i64).contiguous().view(-1)
@@ -262,7 +286,8 @@ class Engine:
         ops.embed_fwd(dt, S["cls_tok"], S["txt"], S["segment"], S["img_pos"], S["sep_tok"], imgproj,
                       self.w[e + "word_embeddings.weight"], self.w[e + "position_embeddings.weight"],
                       self.w[e + "token_type_embeddings.weight"], self.p[e + "LayerNorm.weight"], self.p[e + "LayerNorm.bias"],
-                      x, pre0, mean0, rstd0, B, N, T, H, cfg.vocab_size, cfg.max_pos, cfg.ln_eps)
+                      x, pre0, mean0, rstd0, B, N, T, H, cfg.vocab_size, cfg.max_pos, cfg.ln_eps, p_drop=pd,
+                      drop_key=dk[(self.SITE_EMB, 0)])
         S["layers"] = []
         for l in range(cfg.layers):
             p = f"enc.encoder.layer.{l}."
@@ -273,10 +298,11 @@ class Engine:
             ops.gemm(x, Wqkv, qkv, M=M, N=3 * H, K=H, bias=bqkv, epi=EPI_BIAS)
             ctx = a_["ctx"] = self._buf(f"ctx{l}", (M, H), adt)
             lse = a_["lse"] = self._buf(f"lse{l}", (B, A, Lq), f32)
-            ops.attn_fwd(qkv, bits, tinfo, ctx, lse, B, Lq, A, dh)
+            ops.attn_fwd(qkv, bits, tinfo, ctx, lse, B, Lq, A, dh, p_drop=pd, drop_key=dk[(self.SITE_ATTN, l)])
             pre1 = a_["pre1"] = self._buf(f"pre1_{l}", (M, H), f32)
             ops.gemm(ctx, self.w[p + "attention.output.dense.weight"], pre1, M=M, N=H, K=H,
-                     bias=self.p[p + "attention.output.dense.bias"], epi=EPI_BIAS_RES, r=x)
+                     bias=self.p[p + "attention.output.dense.bias"], epi=EPI_BIAS_RES, r=x, p_drop=pd,
+                     drop_key=dk[(self.SITE_OUT1, l)])
             a1 = a_["a"] = self._buf(f"a{l}", (M, H), adt)
             a_["mean1"], a_["rstd1"] = self._buf(f"mean1_{l}", (M,), f32), self._buf(f"rstd1_{l}", (M,), f32)
             ops.layernorm_fwd(pre1, self.p[p + "attention.output.LayerNorm.weight"], self.p[p + "attention.output.LayerNorm.bias"],
@@ -287,7 +313,7 @@ class Engine:
                      epi=EPI_BIAS_GELU, c2=z)
             pre2 = a_["pre2"] = self._buf(f"pre2_{l}", (M, H), f32)
             ops.gemm(act, self.w[p + "output.dense.weight"], pre2, M=M, N=H, K=I, bias=self.p[p + "output.dense.bias"],
-                     epi=EPI_BIAS_RES, r=a1)
+                     epi=EPI_BIAS_RES, r=a1, p_drop=pd, drop_key=dk[(self.SITE_OUT2, l)])
             x = self._buf(f"x{l + 1}", (M, H), adt)
             a_["mean2"], a_["rstd2"] = self._buf(f"mean2_{l}", (M,), f32), self._buf(f"rstd2_{l}", (M,), f32)
             ops.layernorm_fwd(pre2, self.p[p + "output.LayerNorm.weight"], self.p[p + "output.LayerNorm.bias"], x, a_["mean2"],
@@ -446,7 +472,10 @@ class Engine:
         dy = S["dhidden"]
         if bucket_hook:
             bucket_hook("heads")
+        pd, dk = S["p_drop"], S["drop_keys"]
         dpre = self._buf("bw_dpre", (M, H), adt)
+        # with dropout the projection branch sees dpre * mask / (1-p) while the residual branch sees dpre itself
+        dprd = self._buf("bw_dprd", (M, H), adt) if pd > 0 else None
         dz = self._buf("bw_dz", (M, I), adt)
         dctx = self._buf("bw_dctx", (M, H), adt)
         dqkv = self._buf("bw_dqkv", (M, 3 * H), adt)
@@ -459,19 +488,23 @@ class Engine:
             Wqkv, _, gWqkv, gbqkv = self.qkv_views(l)
             # LN2 backward (+ bias grad of output.dense)
             ops.layernorm_bwd(dy, a_["pre2"], a_["mean2"], a_["rstd2"], self.p[p + "output.LayerNorm.weight"], dpre,
-                              g[p + "output.LayerNorm.weight"], g[p + "output.LayerNorm.bias"], g[p + "output.dense.bias"], M, H)
-            self._dW(dpre, a_["i"], g[p + "output.dense.weight"], H, I, M, lda=H, ldb=I)
-            ops.gemm(dpre, self.w[p + "output.dense.weight"], dz, tb=True, M=M, N=I, K=H, epi=EPI_DGELU, r=a_["z"])
+                              g[p + "output.LayerNorm.weight"], g[p + "output.LayerNorm.bias"], g[p + "output.dense.bias"], M, H,
+                              dx_drop=dprd, p_drop=pd, drop_key=dk[(self.SITE_OUT2, l)])
+            dproj = dprd if dprd is not None else dpre
+            self._dW(dproj, a_["i"], g[p + "output.dense.weight"], H, I, M, lda=H, ldb=I)
+            ops.gemm(dproj, self.w[p + "output.dense.weight"], dz, tb=True, M=M, N=I, K=H, epi=EPI_DGELU, r=a_["z"])
             ops.colsum(dz, I, M, I, g[p + "intermediate.dense.bias"], accumulate=True)
             self._dW(dz, a_["a"], g[p + "intermediate.dense.weight"], I, H, M, lda=I, ldb=H)
             ops.gemm(dz, self.w[p + "intermediate.dense.weight"], da, tb=True, M=M, N=H, K=I, epi=EPI_RES, r=dpre)
             # LN1 backward (+ bias grad of attention.output.dense)
             ops.layernorm_bwd(da, a_["pre1"], a_["mean1"], a_["rstd1"], self.p[p + "attention.output.LayerNorm.weight"], dpre,
                               g[p + "attention.output.LayerNorm.weight"], g[p + "attention.output.LayerNorm.bias"],
-                              g[p + "attention.output.dense.bias"], M, H)
-            self._dW(dpre, a_["ctx"], g[p + "attention.output.dense.weight"], H, H, M, lda=H, ldb=H)
-            ops.gemm(dpre, self.w[p + "attention.output.dense.weight"], dctx, tb=True, M=M, N=H, K=H)
-            ops.attn_bwd(a_["qkv"], a_["ctx"], dctx, a_["lse"], S["bits"], S["tinfo"], dqkv, delta, B, Lq, A, dh)
+                              g[p + "attention.output.dense.bias"], M, H, dx_drop=dprd, p_drop=pd,
+                              drop_key=dk[(self.SITE_OUT1, l)])
+            self._dW(dproj, a_["ctx"], g[p + "attention.output.dense.weight"], H, H, M, lda=H, ldb=H)
+            ops.gemm(dproj, self.w[p + "attention.output.dense.weight"], dctx, tb=True, M=M, N=H, K=H)
+            ops.attn_bwd(a_["qkv"], a_["ctx"], dctx, a_["lse"], S["bits"], S["tinfo"], dqkv, delta, B, Lq, A, dh, p_drop=pd,
+                         drop_key=dk[(self.SITE_ATTN, l)])
             ops.colsum(dqkv, 3 * H, M, 3 * H, gbqkv, accumulate=True)
             self._dW(dqkv, a_["x"], gWqkv, 3 * H, H, M, lda=3 * H, ldb=H)
             dx = dxb[l & 1]          # never the buffer dy currently lives in
@@ -484,7 +517,8 @@ class Engine:
         ops.embed_bwd(self.dt, dy, self._ws["pre0"][:M * H].view(M, H), self._ws["mean0"][:M], self._ws["rstd0"][:M],
                       self.p[e + "LayerNorm.weight"], S["cls_tok"], S["txt"], S["segment"], S["img_pos"], S["sep_tok"],
                       g[e + "word_embeddings.weight"], g[e + "position_embeddings.weight"], g[e + "token_type_embeddings.weight"],
-                      g[e + "LayerNorm.weight"], g[e + "LayerNorm.bias"], dimg, B, N, T, H, cfg.vocab_size, cfg.max_pos)
+                      g[e + "LayerNorm.weight"], g[e + "LayerNorm.bias"], dimg, B, N, T, H, cfg.vocab_size, cfg.max_pos,
+                      pad_token_id=0, p_drop=pd, drop_key=dk[(self.SITE_EMB, 0)])
         if N > 0:
             ops.colsum(dimg, H, B * N, H, g["enc.img_embeddings.img_embeddings.bias"], accumulate=True)
             self._dW(dimg, S["feats"], g["enc.img_embeddings.img_embeddings.weight"], H, D, B * N, lda=H, ldb=D)

@@ -14,7 +14,7 @@ def _lib():
 
 
 def gemm(a, b, c, *, ta=False, tb=False, M, N, K, lda=None, ldb=None, ldc=None, bias=None, epi=EPI_NONE, r=None, ldr=None,
-         c2=None, ldc2=None, splitk=1, ws=None, accumulate=False):
+         c2=None, ldc2=None, splitk=1, ws=None, accumulate=False, p_drop=0.0, drop_key=0):
     """c[M,N] = epi(op(a)[M,K] . op(b)[K,N]); see mv_gemm in include/medvill.h."""
     L.require_cuda(a, b, c, bias, r, c2, ws)
     lda = lda if lda is not None else (M if ta else K)
@@ -28,7 +28,8 @@ def gemm(a, b, c, *, ta=False, tb=False, M, N, K, lda=None, ldb=None, ldc=None, 
         raise TypeError("bias must be f32")
     rc = _lib().mv_gemm(L.dt_of(a), int(ta), int(tb), M, N, K, L.ptr(a), lda, L.ptr(b), ldb, L.ptr(c), ldc, L.dt_of(c),
                         L.ptr(bias), epi, L.ptr(r), ldr, L.dt_of(r) if r is not None else 0, L.ptr(c2), ldc2, splitk,
-                        L.ptr(ws), (ws.numel() * 4) if ws is not None else 0, int(accumulate), L.stream_ptr())
+                        L.ptr(ws), (ws.numel() * 4) if ws is not None else 0, int(accumulate), float(p_drop), int(drop_key),
+                        L.stream_ptr())
     L.check(rc, f"mv_gemm(M={M},N={N},K={K},ta={ta},tb={tb},epi={epi})")
     return c
 
@@ -44,15 +45,15 @@ def mask_pack(mask, bits, tileinfo):
     L.check(rc, "mv_mask_pack")
 
 
-def attn_fwd(qkv, bits, tileinfo, ctx, lse, B, Lq, A, dh):
+def attn_fwd(qkv, bits, tileinfo, ctx, lse, B, Lq, A, dh, p_drop=0.0, drop_key=0):
     rc = _lib().mv_attn_fwd(L.dt_of(qkv), L.ptr(qkv), L.ptr(bits), L.ptr(tileinfo), L.ptr(ctx), L.ptr(lse), B, Lq, A, dh,
-                            L.stream_ptr())
+                            float(p_drop), int(drop_key), L.stream_ptr())
     L.check(rc, "mv_attn_fwd")
 
 
-def attn_bwd(qkv, ctx, dctx, lse, bits, tileinfo, dqkv, delta, B, Lq, A, dh):
+def attn_bwd(qkv, ctx, dctx, lse, bits, tileinfo, dqkv, delta, B, Lq, A, dh, p_drop=0.0, drop_key=0):
     rc = _lib().mv_attn_bwd(L.dt_of(qkv), L.ptr(qkv), L.ptr(ctx), L.ptr(dctx), L.ptr(lse), L.ptr(bits), L.ptr(tileinfo),
-                            L.ptr(dqkv), L.ptr(delta), B, Lq, A, dh, L.stream_ptr())
+                            L.ptr(dqkv), L.ptr(delta), B, Lq, A, dh, float(p_drop), int(drop_key), L.stream_ptr())
     L.check(rc, "mv_attn_bwd")
 
 
@@ -62,25 +63,27 @@ def layernorm_fwd(x, gamma, beta, y, mean, rstd, M, H, eps):
     L.check(rc, "mv_layernorm_fwd")
 
 
-def layernorm_bwd(dy, x, mean, rstd, gamma, dx, dgamma, dbeta, colsum, M, H):
+def layernorm_bwd(dy, x, mean, rstd, gamma, dx, dgamma, dbeta, colsum, M, H, dx_drop=None, p_drop=0.0, drop_key=0):
     rc = _lib().mv_layernorm_bwd(L.dt_of(dy), L.ptr(dy), L.ptr(x), L.dt_of(x), L.ptr(mean), L.ptr(rstd), L.ptr(gamma),
-                                 L.ptr(dx), L.ptr(dgamma), L.ptr(dbeta), L.ptr(colsum), M, H, L.stream_ptr())
+                                 L.ptr(dx), L.ptr(dgamma), L.ptr(dbeta), L.ptr(colsum), M, H, L.ptr(dx_drop), float(p_drop),
+                                 int(drop_key), L.stream_ptr())
     L.check(rc, "mv_layernorm_bwd")
 
 
 def embed_fwd(dt, cls_tok, txt, segment, img_pos, sep_tok, imgproj, E, P, Ty, gamma, beta, x0, pre, mean, rstd, B, N, T, H, V,
-              maxpos, eps):
+              maxpos, eps, p_drop=0.0, drop_key=0):
     rc = _lib().mv_embed_fwd(dt, L.ptr(cls_tok), L.ptr(txt), L.ptr(segment), L.ptr(img_pos), L.ptr(sep_tok), L.ptr(imgproj),
                              L.ptr(E), L.ptr(P), L.ptr(Ty), L.ptr(gamma), L.ptr(beta), L.ptr(x0), L.ptr(pre), L.ptr(mean),
-                             L.ptr(rstd), B, N, T, H, V, maxpos, float(eps), L.stream_ptr())
+                             L.ptr(rstd), B, N, T, H, V, maxpos, float(eps), float(p_drop), int(drop_key), L.stream_ptr())
     L.check(rc, "mv_embed_fwd")
 
 
 def embed_bwd(dt, dx0, pre, mean, rstd, gamma, cls_tok, txt, segment, img_pos, sep_tok, dE, dP, dTy, dgamma, dbeta, dimgproj, B,
-              N, T, H, V, maxpos, pad_token_id=0):
+              N, T, H, V, maxpos, pad_token_id=0, p_drop=0.0, drop_key=0):
     rc = _lib().mv_embed_bwd(dt, L.ptr(dx0), L.ptr(pre), L.ptr(mean), L.ptr(rstd), L.ptr(gamma), L.ptr(cls_tok), L.ptr(txt),
                              L.ptr(segment), L.ptr(img_pos), L.ptr(sep_tok), L.ptr(dE), L.ptr(dP), L.ptr(dTy), L.ptr(dgamma),
-                             L.ptr(dbeta), L.ptr(dimgproj), B, N, T, H, V, maxpos, int(pad_token_id), L.stream_ptr())
+                             L.ptr(dbeta), L.ptr(dimgproj), B, N, T, H, V, maxpos, int(pad_token_id), float(p_drop), int(drop_key),
+                             L.stream_ptr())
     L.check(rc, "mv_embed_bwd")
 
 
@@ -133,6 +136,16 @@ def adamw_step(p, g, m, v, shadow, n, lr, b1, b2, eps, wd, step, correct_bias=Tr
     rc = _lib().mv_adamw_step(L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), L.ptr(shadow), n, float(lr), float(b1), float(b2),
                               float(eps), float(wd), int(step), int(correct_bias), float(grad_scale), L.stream_ptr())
     L.check(rc, "mv_adamw_step")
+
+
+def dropout_mask(p_drop, drop_key, n, device):
+    """(keep uint8 [n], scale) of the kernels' counter-based dropout for linear indices 0..n-1."""
+    import ctypes
+    keep = torch.empty(n, dtype=torch.uint8, device=device)
+    sc = ctypes.c_float(1.0)
+    rc = _lib().mv_dropout_mask(float(p_drop), int(drop_key), n, L.ptr(keep), ctypes.byref(sc), L.stream_ptr())
+    L.check(rc, "mv_dropout_mask")
+    return keep, float(sc.value)
 
 
 def set_impl(impl: int):

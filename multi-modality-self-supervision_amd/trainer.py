@@ -48,6 +48,7 @@ class TrainStep:
         (local to this rank); no host sync happens here."""
         eng = self.eng
         rows, ids, aligned = self._prep(batch)
+        eng.training = bool(train and self.model.training)      # dropout like the reference's model.train()
         if train:
             eng.flat_g.zero_()
         eng.encoder_forward(batch["cls_tok"], batch["input_txt"], batch["attn_mask"], batch["segment"], batch["img_feats"],

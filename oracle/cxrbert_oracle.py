@@ -191,7 +191,15 @@ def extend_mask(attn_mask: torch.Tensor) -> torch.Tensor:
     return ((1.0 - m) * -10000.0).to(torch.float32)
 
 
-def embed(P, cfg, cls_tok, input_txt, segment, img_feats, img_pos, sep_tok, p_drop=0.0, training=False):
+def _drop(t, p_drop, training, masks, key):
+    """Dropout as the reference applies it (nn.Dropout, p = 0.1 at every site in train mode).  `masks` lets a
+    test inject explicit keep*scale tensors (the HIP kernels' counter-based masks) instead of torch's RNG."""
+    if masks is not None:
+        return t * masks[key]
+    return F.dropout(t, p_drop, training) if (training and p_drop > 0) else t
+
+
+def embed(P, cfg, cls_tok, input_txt, segment, img_feats, img_pos, sep_tok, p_drop=0.0, training=False, masks=None):
     """cxrbert_origin.py:114-125 + :22-35 + HF BertEmbeddings.  One shared set of
     position / type tables and one LayerNorm for all four calls (cxrbert_origin.py:17-20).
     cls and sep use position 0 and type 0; text positions restart at 0; image
@@ -204,7 +212,7 @@ def embed(P, cfg, cls_tok, input_txt, segment, img_feats, img_pos, sep_tok, p_dr
 
     def ln_drop(x):
         x = layer_norm(x, g, b, cfg.ln_eps)
-        return F.dropout(x, p_drop, training) if (training and p_drop > 0) else x
+        return x if masks is not None else _drop(x, p_drop, training, None, None)
 
     def word(ids):
         # HF BertEmbeddings builds nn.Embedding(vocab, hidden, padding_idx=pad_token_id=0): the LOOK-UP gradient of
@@ -215,17 +223,18 @@ def embed(P, cfg, cls_tok, input_txt, segment, img_feats, img_pos, sep_tok, p_dr
     sep_o = ln_drop(word(sep_tok) + Ty[torch.zeros_like(sep_tok)] + Pos[:1][None])
     img_o = ln_drop(F.linear(img_feats, Wi, bi) + Pos[img_pos] + Ty[0][None, None])
     txt_o = ln_drop(word(input_txt) + Ty[segment] + Pos[:T][None])
-    return torch.cat([cls_o, img_o, sep_o, txt_o], dim=1)
+    x = torch.cat([cls_o, img_o, sep_o, txt_o], dim=1)
+    return x * masks["emb"] if masks is not None else x
 
 
-def encoder_layer(P, cfg, l, x, add_mask, p_drop=0.0, training=False):
+def encoder_layer(P, cfg, l, x, add_mask, p_drop=0.0, training=False, masks=None):
     """One BertLayer."""
     p = f"enc.encoder.layer.{l}."
     B, L, H = x.shape
     A, dh = cfg.heads, cfg.hidden // cfg.heads
 
-    def drop(t):
-        return F.dropout(t, p_drop, training) if (training and p_drop > 0) else t
+    def drop(t, site=None):
+        return _drop(t, p_drop, training, masks, (site, l))
 
     def heads(t):
         return t.view(B, L, A, dh).permute(0, 2, 1, 3)
@@ -234,23 +243,23 @@ def encoder_layer(P, cfg, l, x, add_mask, p_drop=0.0, training=False):
     k = heads(F.linear(x, P[p + "attention.self.key.weight"], P[p + "attention.self.key.bias"]))
     v = heads(F.linear(x, P[p + "attention.self.value.weight"], P[p + "attention.self.value.bias"]))
     s = torch.matmul(q, k.transpose(-1, -2)) / math.sqrt(dh) + add_mask
-    pr = drop(torch.softmax(s, dim=-1))
+    pr = drop(torch.softmax(s, dim=-1), "attn")
     c = torch.matmul(pr, v).permute(0, 2, 1, 3).reshape(B, L, H)
-    a = layer_norm(drop(F.linear(c, P[p + "attention.output.dense.weight"], P[p + "attention.output.dense.bias"])) + x,
+    a = layer_norm(drop(F.linear(c, P[p + "attention.output.dense.weight"], P[p + "attention.output.dense.bias"]), "out1") + x,
                    P[p + "attention.output.LayerNorm.weight"], P[p + "attention.output.LayerNorm.bias"], cfg.ln_eps)
     i = gelu_erf(F.linear(a, P[p + "intermediate.dense.weight"], P[p + "intermediate.dense.bias"]))
-    o = layer_norm(drop(F.linear(i, P[p + "output.dense.weight"], P[p + "output.dense.bias"])) + a,
+    o = layer_norm(drop(F.linear(i, P[p + "output.dense.weight"], P[p + "output.dense.bias"]), "out2") + a,
                    P[p + "output.LayerNorm.weight"], P[p + "output.LayerNorm.bias"], cfg.ln_eps)
     return o
 
 
-def encode(P, cfg, cls_tok, input_txt, attn_mask, segment, img_feats, img_pos, sep_tok, p_drop=0.0, training=False):
+def encode(P, cfg, cls_tok, input_txt, attn_mask, segment, img_feats, img_pos, sep_tok, p_drop=0.0, training=False, masks=None):
     """CXRBertEncoder.forward else-branch (cxrbert_origin.py:114-130): returns
     (last_hidden [B,L,H], pooled [B,H])."""
     add = extend_mask(attn_mask)
-    x = embed(P, cfg, cls_tok, input_txt, segment, img_feats, img_pos, sep_tok, p_drop, training)
+    x = embed(P, cfg, cls_tok, input_txt, segment, img_feats, img_pos, sep_tok, p_drop, training, masks)
     for l in range(cfg.layers):
-        x = encoder_layer(P, cfg, l, x, add, p_drop, training)
+        x = encoder_layer(P, cfg, l, x, add, p_drop, training, masks)
     pooled = torch.tanh(F.linear(x[:, 0], P["enc.pooler.dense.weight"], P["enc.pooler.dense.bias"]))
     return x, pooled
 
@@ -272,9 +281,9 @@ def heads(P, cfg, x, pooled):
     return mlm, itm
 
 
-def forward(P, cfg, cls_tok, input_txt, attn_mask, segment, img_feats, img_pos, sep_tok, p_drop=0.0, training=False):
+def forward(P, cfg, cls_tok, input_txt, attn_mask, segment, img_feats, img_pos, sep_tok, p_drop=0.0, training=False, masks=None):
     """CXRBERT.forward (cxrbert_origin.py:144-149) -> (mlm_logits [B,L,V], itm_logits [B,2])."""
-    x, pooled = encode(P, cfg, cls_tok, input_txt, attn_mask, segment, img_feats, img_pos, sep_tok, p_drop, training)
+    x, pooled = encode(P, cfg, cls_tok, input_txt, attn_mask, segment, img_feats, img_pos, sep_tok, p_drop, training, masks)
     return heads(P, cfg, x, pooled)
 
 

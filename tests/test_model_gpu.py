@@ -37,6 +37,7 @@ def load_case(golden_dir, name):
 def make_model(cfg, P, dtype):
     m = mv.CXRBERT(cfg_dict(cfg), None, dtype=dtype, device=DEV)
     m.load_state_dict(P, strict=True)
+    m.eval()            # parity runs with dropout off, like the golden vectors (the reference in .eval())
     return m
 
 
@@ -181,6 +182,57 @@ def test_bert_base_l512_against_reference_golden(golden_dir):
         torch.cuda.empty_cache()
 
 
+def test_dropout_training_step_against_oracle_with_the_same_masks(golden_dir):
+    """Train mode (dropout 0.1 at the embedding, attention-probability and both hidden-state sites, like the
+    reference's model.train()): the kernels regenerate counter-based masks instead of storing them; feeding the very
+    same masks to the oracle must reproduce loss and gradients (fp32 path), and the masks must look like Bernoulli(0.9)."""
+    from medvill_amd import hip_ops as ops
+    z, meta, cfg, P, b = load_case(golden_dir, "c1v1k_bar_ragged")
+    model = make_model(cfg, P, torch.float32)
+    model.train()
+    ts = mv.TrainStep(model, lr=0.0)
+    stats = ts(dict(b), train=True).cpu()
+    eng = model.engine
+    assert eng.S["p_drop"] == pytest.approx(0.1)
+    B, Lq, H, A = meta["B"], meta["N"] + meta["S"] + 3, cfg.hidden, cfg.heads
+    Lp = (Lq + 3) // 4 * 4
+    masks, fracs = {}, []
+    for (site, l), key in eng.S["drop_keys"].items():
+        if site == eng.SITE_ATTN:
+            keep, sc = ops.dropout_mask(0.1, key, B * A * Lq * Lp, DEV)
+            masks[("attn", l)] = (keep.view(B, A, Lq, Lp)[..., :Lq].float() * sc).cpu()
+        else:
+            keep, sc = ops.dropout_mask(0.1, key, B * Lq * H, DEV)
+            name = {eng.SITE_EMB: "emb", eng.SITE_OUT1: ("out1", l), eng.SITE_OUT2: ("out2", l)}[site]
+            masks[name] = (keep.view(B, Lq, H).float() * sc).cpu()
+        fracs.append(float(keep.float().mean()))
+        assert sc == pytest.approx(1.0 / (1.0 - 26.0 / 256.0))
+    assert all(abs(f - (1 - 26 / 256)) < 0.01 for f in fracs), fracs
+    assert len({float(m.sum()) for m in masks.values()}) == len(masks)        # every site / layer draws its own mask
+    Po = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    mlm, itm = O.forward(Po, cfg, b["cls_tok"], b["input_txt"], b["attn_mask"], b["segment"], b["img_feats"], b["img_pos"],
+                         b["sep_tok"], masks=masks)
+    ml, il = O.losses(mlm, itm, b["txt_labels"], b["is_aligned"])
+    (ml + il).backward()
+    assert abs(float(stats[0] / stats[1]) - float(ml)) < 1e-4 and abs(float(stats[3] / stats[4]) - float(il)) < 1e-4
+    assert abs(float(ml) - float(z["mlm_loss"])) > 1e-4                        # dropout really changed the forward
+    gmax = max(float(Po[k].grad.norm()) for k in P)
+    for k in P:
+        got, ref = eng.g[k].cpu(), Po[k].grad
+        assert float((got - ref).norm()) <= 1e-3 * float(ref.norm()) + 1e-5 * gmax, k
+    # a second step draws different masks; the bf16 MFMA path runs the same schedule and stays close to the fp32 one
+    ts(dict(b), train=True)
+    assert eng.S["drop_keys"][(eng.SITE_EMB, 0)] != list(masks.keys()) and eng.drop_counter == 2
+    m16 = make_model(cfg, P, torch.bfloat16)
+    m16.train()
+    m16.engine.drop_seed, m16.engine.drop_counter = eng.drop_seed, 0
+    s16 = mv.TrainStep(m16, lr=0.0)(dict(b), train=True).cpu()
+    assert abs(float(s16[0] / s16[1]) - float(ml)) < 1e-2
+    g32 = torch.cat([Po[k].grad.reshape(-1) for k in P])
+    g16 = torch.cat([m16.engine.g[k].reshape(-1) for k in P]).cpu()
+    assert float((g16 - g32).norm() / g32.norm()) < 3e-2
+
+
 def test_half_batches_sum_to_full_batch_gradient():
     """Size-independent linearity property at BERT-base scale (bf16 MFMA path): the gradients of two
     half mini-batches, each normalised by the GLOBAL label / batch counts (what every DP rank
@@ -188,6 +240,7 @@ def test_half_batches_sum_to_full_batch_gradient():
     cfg = mv.ModelConfig()
     model = mv.CXRBERT(cfg, None, dtype=torch.bfloat16, device=DEV)
     model.reset_parameters(seed=3)
+    model.eval()                   # linearity holds for a fixed function: dropout off
     B, N, S = 8, 36, 473
     full = mv.data.synthetic_batch(cfg.vocab_size, B, N, S, "mixed", seed=77, device=DEV)
     ts = mv.TrainStep(model, lr=0.0)
