@@ -309,7 +309,7 @@ __device__ __forceinline__ int t2_off(int kr, int ch) { return kr * 512 + ((ch ^
 // PITCH512: contraction-major image with 512-B rows (tile width 192/256) or 256-B rows (tile width 128)
 template <bool TR, bool PITCH512, int NPIECE, int NW>
 __device__ __forceinline__ void g2_issue(__amdgpu_buffer_rsrc_t rs, unsigned bytes, int ld, int row0, int rows_total,
-                                         int tile_rows, int k0, int kend, char* region, int wid, int lane) {
+                                         int tile_rows, int k0, int kend, char* region, int wid, int lane, int dbg = 0) {
 #pragma unroll
   for (int q = 0; q < NPIECE / NW; ++q) {
     const int pc = wid + NW * q;                // 1-KiB piece of the operand image
@@ -320,6 +320,7 @@ __device__ __forceinline__ void g2_issue(__amdgpu_buffer_rsrc_t rs, unsigned byt
       const int gr = row0 + r, gk = k0 + c * 8;
       ok = (r < tile_rows) && (gr < rows_total) && (gk < kend);
       off = ((unsigned)gr * (unsigned)ld + (unsigned)gk) * 2u;
+      if (dbg & 8) off = ((unsigned)(row0 + 8 * pc + (lane >> 3)) * (unsigned)ld + (unsigned)((k0 & ~63) + (lane & 7) * 8)) * 2u;
     } else if (PITCH512) {
       const int kr = 2 * pc + (lane >> 5), c = (lane & 31) ^ (t2_g(2 * pc + (lane >> 5)) << 1);
       const int gk = k0 + kr, gc = row0 + c * 8;
@@ -404,40 +405,85 @@ __global__ __launch_bounds__(128 * WN, (WN == 2 ? 2 : 2)) void gemm_ring_kernel(
   do {                                                                                                      \
     char* st__ = smem + ((S_) % NSTAGE) * STAGE;                                                            \
     const int k0__ = kbeg + (S_) * G2_BK;                                                                   \
-    g2_issue<TA, true, A_BYTES / 1024, NW>(rsA, p.bytesA, p.lda, m0, p.M, G2_BM, k0__, kend, st__, wid, lane); \
-    g2_issue<TB, BP512, B_BYTES / 1024, NW>(rsB, p.bytesB, p.ldb, n0, p.N, BN, k0__, kend, st__ + A_BYTES, wid, lane); \
+    g2_issue<TA, true, A_BYTES / 1024, NW>(rsA, p.bytesA, p.lda, m0, p.M, G2_BM, k0__, kend, st__, wid, lane, p.dbg); \
+    g2_issue<TB, BP512, B_BYTES / 1024, NW>(rsB, p.bytesB, p.ldb, n0, p.N, BN, k0__, kend, st__ + A_BYTES, wid, lane, p.dbg); \
   } while (0)
 
   const bool do_load = !(p.dbg & 2), do_mma = !(p.dbg & 4);
+  // Software pipeline: all NSTAGE buffers are filled up front; while the MFMAs of stage s run, the fragments of
+  // stage s+1 are already being read into the second register set and stages s+2.. are in flight.  Per stage: one
+  // counted vmcnt wait + one barrier (stage s+1 visible to every wave, buffer of stage s free), then the refill of
+  // that buffer with stage s+NSTAGE.
+  // (The second fragment set does not fit in 256 registers next to the transposed-read addresses, so the kernels
+  // with a contraction-major operand keep the simpler schedule: read the fragments after the barrier, then MFMA.)
+  constexpr bool PF = !TA && !TB;
   if (do_load) {
 #pragma unroll
-    for (int s = 0; s < NSTAGE - 1; ++s)
+    for (int s = 0; s < (PF ? NSTAGE : NSTAGE - 1); ++s)
       if (s < nst) G2_ISSUE(s);
   }
+#define G2_WAIT(YOUNGER_)                                           \
+  do {                                                              \
+    const int y__ = (YOUNGER_);                                     \
+    if (y__ <= 0) wait_vmcnt<0>();                                  \
+    else if (y__ == 1) wait_vmcnt<LPS>();                           \
+    else if (y__ == 2) wait_vmcnt<2 * LPS>();                       \
+    else wait_vmcnt<3 * LPS>();                                     \
+  } while (0)
+#define G2_FRAGS(FA_, FB_, S_)                                                                   \
+  do {                                                                                           \
+    const char* tA__ = smem + ((S_) % NSTAGE) * STAGE;                                           \
+    const char* tB__ = tA__ + A_BYTES;                                                           \
+    _Pragma("unroll") for (int j = 0; j < NJ; ++j) FB_[j] = g2_frag<TB, BP512>(tB__, wn + j * 16, l15, lq); \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i) FA_[i] = g2_frag<TA, true>(tA__, wm + i * 16, l15, lq);   \
+  } while (0)
+#define G2_MMA(FA_, FB_)                                                                         \
+  do {                                                                                           \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i)                                                \
+    _Pragma("unroll") for (int j = 0; j < NJ; ++j)                                               \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FB_[j], FA_[i], acc[i][j], 0, 0, 0); \
+  } while (0)
+#define G2_STEP(S_, FA_, FB_, FAN_, FBN_)                                                        \
+  do {                                                                                           \
+    if ((S_) + 1 < nst) {                                                                        \
+      G2_WAIT(min(nst - 2 - (S_), NSTAGE - 2));       /* stage S+1 landed (this wave's part) */  \
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* my fragment reads of stage S are done */ \
+      __builtin_amdgcn_s_barrier();                                                              \
+      __builtin_amdgcn_sched_barrier(0);                                                         \
+      if (do_load && (S_) + NSTAGE < nst) G2_ISSUE((S_) + NSTAGE);                               \
+      if (do_mma) G2_FRAGS(FAN_, FBN_, (S_) + 1);                                                \
+    }                                                                                            \
+    if (do_mma) G2_MMA(FA_, FB_);                                                                \
+  } while (0)
 
-  for (int s = 0; s < nst; ++s) {
-    // stage s must have landed: at most the LPS LDS-DMA instructions of each younger in-flight stage may be pending
-    const int younger = min(NSTAGE - 2, nst - 1 - s);
-    if (younger >= 2) wait_vmcnt<(NSTAGE > 3 ? 2 : 0) * LPS>();
-    else if (younger == 1) wait_vmcnt<LPS>();
-    else wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    if (do_load && s + NSTAGE - 1 < nst) G2_ISSUE(s + NSTAGE - 1);   // refills the buffer everyone finished reading
-    if (!do_mma) continue;
-    const char* tA = smem + (s % NSTAGE) * STAGE;
-    const char* tB = tA + A_BYTES;
-    bf16x8 fa[8], fb[NJ];
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) fb[j] = g2_frag<TB, BP512>(tB, wn + j * 16, l15, lq);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) fa[i] = g2_frag<TA, true>(tA, wm + i * 16, l15, lq);
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-      for (int j = 0; j < NJ; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+  if constexpr (PF) {
+    bf16x8 fa0[8], fb0[NJ], fa1[8], fb1[NJ];
+    if (nst > 0) {
+      G2_WAIT(min(nst - 1, NSTAGE - 1));
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      if (do_mma) G2_FRAGS(fa0, fb0, 0);
+    }
+    for (int s = 0; s < nst; s += 2) {
+      G2_STEP(s, fa0, fb0, fa1, fb1);
+      if (s + 1 < nst) G2_STEP(s + 1, fa1, fb1, fa0, fb0);
+    }
+  } else {
+    for (int s = 0; s < nst; ++s) {
+      G2_WAIT(min(nst - 1 - s, NSTAGE - 2));            // stage s landed
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      if (do_load && s + NSTAGE - 1 < nst) G2_ISSUE(s + NSTAGE - 1);   // refills the buffer everyone finished reading
+      if (!do_mma) continue;
+      bf16x8 fa[8], fb[NJ];
+      G2_FRAGS(fa, fb, s);
+      G2_MMA(fa, fb);
+    }
   }
+#undef G2_STEP
+#undef G2_MMA
+#undef G2_FRAGS
+#undef G2_WAIT
 #undef G2_ISSUE
 
   if (p.dbg & 1) {
