@@ -98,7 +98,7 @@ extern "C" int mv_mask_pack(const int64_t* mask, int mask_ndim, int B, int L, ui
 // =========================================================================================
 struct AttnArgs {
   const bf16_t* qkv; const bf16_t* ctx; const bf16_t* dctx; bf16_t* out; bf16_t* dqkv;
-  const uint32_t* bits; const uint8_t* info; float* lse; const float* lse_in; const float* delta;
+  const uint32_t* bits; const uint8_t* info; float* lse; const float* lse_in; const float* delta; float* delta_out;
   int B, L, A, H, W, T;
   float scale;
   unsigned bytes_qkv, bytes_ctx;
@@ -108,6 +108,19 @@ struct AttnArgs {
 // keep-bits of the 4 consecutive keys k4..k4+3 (k4 % 4 == 0) of query row q
 __device__ __forceinline__ unsigned attn_drop_hash(const DropCfg& d, size_t bh, int L, int Lp, int q, int k4) {
   return mv_hash32((unsigned)(((bh * L + q) * (size_t)Lp + k4) >> 2), d.k0, d.k1);
+}
+
+// value of lane `e` of each quad (DPP quad_perm broadcast); e is a compile-time constant after unrolling
+template <int E> __device__ __forceinline__ unsigned quad_bcast_c(unsigned v) {
+  return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, E * 0x55, 0xf, 0xf, true);
+}
+__device__ __forceinline__ unsigned quad_bcast(unsigned v, int e) {
+  switch (e) {
+    case 0: return quad_bcast_c<0>(v);
+    case 1: return quad_bcast_c<1>(v);
+    case 2: return quad_bcast_c<2>(v);
+    default: return quad_bcast_c<3>(v);
+  }
 }
 
 // dual-use LDS image of a [64 rows][64 x bf16] tile: 128-B rows, 16-B chunk index XORed with f(row)
@@ -233,29 +246,45 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_mfma_kernel(AttnArgs a) {
       }
       const bool tail = (k0 + 64 > L);
       float mx = -INFINITY;
+      const bool plain = (cls == 1) && !tail;       // fully visible tile: no mask words, no bounds, scale folded into the exp
+      if (plain) {
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        uint32_t w = 0xffffffffu;
-        if (cls != 1) { const int wi = (k0 >> 5) + kk; w = (q_ok && wi < a.W) ? myw[wi] : 0xffffffffu; }
+        for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int kr = acc_row(r, h);
-          float v = st[kk][r] * c2;
-          if (cls != 1) v += ((w >> kr) & 1u) ? 0.f : MASK_ADD * LOG2E;
-          if (tail && (k0 + 32 * kk + kr >= L)) v = -INFINITY;
-          st[kk][r] = v;
-          mx = fmaxf(mx, v);
+          for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[kk][r]);
+        mx *= c2;
+      } else {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          uint32_t w = 0xffffffffu;
+          if (cls != 1) { const int wi = (k0 >> 5) + kk; w = (q_ok && wi < a.W) ? myw[wi] : 0xffffffffu; }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int kr = acc_row(r, h);
+            float v = st[kk][r] * c2;
+            if (cls != 1) v += ((w >> kr) & 1u) ? 0.f : MASK_ADD * LOG2E;
+            if (tail && (k0 + 32 * kk + kr >= L)) v = -INFINITY;
+            st[kk][r] = v;
+            mx = fmaxf(mx, v);
+          }
         }
       }
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       const float mn = fmaxf(m2, mx);
-      const float alpha = exp2f(m2 - mn);
+      const float alpha = fexp2(m2 - mn);
       m2 = mn;
       float ps = 0.f;
+      if (plain) {
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk)
+        for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { const float pv = exp2f(st[kk][r] - mn); st[kk][r] = pv; ps += pv; }
+          for (int r = 0; r < 16; ++r) { const float pv = fexp2(fmaf(st[kk][r], c2, -mn)); st[kk][r] = pv; ps += pv; }
+      } else {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { const float pv = fexp2(st[kk][r] - mn); st[kk][r] = pv; ps += pv; }
+      }
       lsum = lsum * alpha + ps;          // the normaliser sums the UNdropped probabilities
       if (a.drop.thr) {
         const size_t bh = (size_t)b * a.A + head;
@@ -269,8 +298,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_mfma_kernel(AttnArgs a) {
               if (!mv_keep(hh, e, a.drop.thr)) st[kk][4 * g + e] = 0.f;
           }
       }
+      if (!__all(alpha == 1.0f)) {      // the running maximum rarely moves after the first tiles
 #pragma unroll
-      for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
+        for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
+      }
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
@@ -324,7 +355,20 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_mfma_kernel(AttnArgs a) {
   }
   const size_t sidx = ((size_t)b * a.A + head) * L + (q_ok ? q : 0);
   const float lse2 = q_ok ? a.lse_in[sidx] * LOG2E : INFINITY;
-  const float dlt = q_ok ? a.delta[sidx] : 0.f;
+  // delta[q] = sum_d dO[q,d] * O[q,d], computed here (each lane holds 32 of the 64 d of its query) and published for
+  // the dK/dV kernel that runs next
+  float dlt = 0.f;
+  {
+    __amdgpu_buffer_rsrc_t rsc = __builtin_amdgcn_make_buffer_rsrc((void*)a.ctx, 0, a.bytes_ctx, 0x00020000);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const bf16x8 of = load_rowfrag_global(rsc, a.bytes_ctx, rowbase + q, q_ok, H, head * 64 + 16 * s + 8 * h);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dlt = fmaf((float)of[j], (float)dof[s][j], dlt);
+    }
+    dlt += __shfl_xor(dlt, 32, 64);
+    if (q_ok && h == 0) a.delta_out[sidx] = dlt;
+  }
   const float c2 = a.scale * LOG2E;
   f32x16 dq[2];
 #pragma unroll
@@ -375,7 +419,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_mfma_kernel(AttnArgs a) {
           const int kr = acc_row(r, h);
           float v = st[r] * c2;
           if (cls != 1) v += ((w >> kr) & 1u) ? 0.f : MASK_ADD * LOG2E;
-          float pv = exp2f(v - lse2);
+          float pv = fexp2(v - lse2);
           if (tail && (k0 + 32 * kk + kr >= L)) pv = 0.f;
           float dpr = dp[r];
           if (a.drop.thr) {
@@ -497,6 +541,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_mfma_kernel(AttnArgs a) {
           const int qr0 = 32 * qq + 8 * g + 4 * h;      // 4 consecutive query rows of this register quad
           const f32x4 l4 = *(const f32x4*)(s_lse + qr0);
           const f32x4 d4 = *(const f32x4*)(s_dl + qr0);
+          unsigned hq = 0;
+          if (a.drop.thr)
+            hq = attn_drop_hash(a.drop, (size_t)b * a.A + head, L, a.Lp, min(cur * 64 + qr0 + (l31 & 3), L - 1), min(key, L - 1) & ~3);
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const int r = 4 * g + e;
@@ -505,12 +552,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_mfma_kernel(AttnArgs a) {
               const uint32_t w = s_w[(qr0 + e) * 4 + wid];
               v += ((w >> l31) & 1u) ? 0.f : MASK_ADD * LOG2E;
             }
-            const float p = exp2f(v - l4[e]);     // rows q >= L carry lse = +inf -> p = 0
+            const float p = fexp2(v - l4[e]);     // rows q >= L carry lse = +inf -> p = 0
             float keepf = 1.0f;
             if (a.drop.thr) {
-              const int qg = min(cur * 64 + qr0 + e, L - 1), kg = min(key, L - 1);
-              const unsigned hh = attn_drop_hash(a.drop, (size_t)b * a.A + head, L, a.Lp, qg, kg & ~3);
-              keepf = mv_keep(hh, kg & 3, a.drop.thr) ? a.drop.inv_keep : 0.f;
+              // the 4 lanes of a quad hold keys 4j..4j+3 = ONE mask group per query: lane e' of the quad hashed query
+              // qr0+e' (hq below); fetch the hash of query qr0+e from lane e of the quad (DPP quad broadcast)
+              const unsigned hh = quad_bcast(hq, e);
+              keepf = mv_keep(hh, l31 & 3, a.drop.thr) ? a.drop.inv_keep : 0.f;
             }
             pv[r] = p * keepf;
             sc[r] = p * (keepf * dp[r] - d4[e]) * a.scale;
@@ -814,13 +862,9 @@ extern "C" int mv_attn_bwd(int dtype, const void* qkv, const void* ctx, const vo
     if (dh != 64) return MV_E_SHAPE;
     const size_t bq = (size_t)B * L * 3 * H * 2, bc = (size_t)B * L * H * 2;
     if (bq >= 0x7fffffffULL || (((uintptr_t)qkv) & 15) || (((uintptr_t)dctx) & 15) || (((uintptr_t)dqkv) & 7)) return MV_E_SHAPE;
-    const long long waves = (long long)B * A * L;
-    hipLaunchKernelGGL(attn_delta_kernel<bf16_t>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream, (const bf16_t*)ctx,
-                       (const bf16_t*)dctx, delta, B, L, A, H, dh);
-    MV_CHECK_LAUNCH();
     AttnArgs a{};
     a.qkv = (const bf16_t*)qkv; a.ctx = (const bf16_t*)ctx; a.dctx = (const bf16_t*)dctx; a.dqkv = (bf16_t*)dqkv;
-    a.bits = bits; a.info = tileinfo; a.lse_in = lse; a.delta = delta;
+    a.bits = bits; a.info = tileinfo; a.lse_in = lse; a.delta = delta; a.delta_out = delta;
     a.B = B; a.L = L; a.A = A; a.H = H; a.W = (L + 31) / 32; a.T = (L + 63) / 64;
     a.scale = 1.0f / sqrtf((float)dh);
     a.bytes_qkv = (unsigned)bq; a.bytes_ctx = (unsigned)bc;

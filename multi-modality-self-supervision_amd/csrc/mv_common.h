@@ -88,11 +88,10 @@ struct DropCfg {
   float inv_keep;
 };
 __device__ __forceinline__ unsigned mv_hash32(unsigned x, unsigned k0, unsigned k1) {
-  x = (x ^ k0) * 0x9E3779B1u;
+  x = (x ^ k0) * 0x9E3779B1u;      // two full 32-bit multiplies + three xor-shifts per 4 mask bytes
   x ^= x >> 15;
   x = (x ^ k1) * 0x85EBCA6Bu;
   x ^= x >> 13;
-  x *= 0xC2B2AE35u;
   x ^= x >> 16;
   return x;
 }
@@ -119,6 +118,8 @@ static inline DropCfg mv_make_drop(float p, unsigned long long key) {
   d.inv_keep = 1.0f / (1.0f - (float)thr / 256.0f);
   return d;
 }
+
+__device__ __forceinline__ float fexp2(float x) { return __builtin_amdgcn_exp2f(x); }   // bare v_exp_f32
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
