@@ -188,6 +188,40 @@ __device__ __forceinline__ bool tile_needed_k(const uint8_t* info, int b, int T,
   return need;
 }
 
+// tile classes of the block's two 64-row tiles, fetched ONCE (lane t holds tile t) and turned into wave-uniform bit
+// masks: the K loop then walks set bits instead of issuing dependent global loads per tile
+struct TileMasks { unsigned long long need, w_nz, w_is1; };
+__device__ __forceinline__ TileMasks load_tile_masks_q(const uint8_t* info, int b, int T, int ta, int tq_wave, int lane) {
+  uint8_t c0 = 0, c1 = 0;
+  if (lane < T) {
+    c0 = info[((size_t)b * T + ta) * T + lane];
+    if (ta + 1 < T) c1 = info[((size_t)b * T + ta + 1) * T + lane];
+  }
+  const uint8_t cw = (tq_wave == ta) ? c0 : c1;
+  TileMasks m;
+  m.need = __ballot(c0 != 0 || c1 != 0);
+  m.w_nz = __ballot(cw != 0);
+  m.w_is1 = __ballot(cw == 1);
+  return m;
+}
+__device__ __forceinline__ TileMasks load_tile_masks_k(const uint8_t* info, int b, int T, int ka, int tk_wave, int lane) {
+  uint8_t c0 = 0, c1 = 0;
+  if (lane < T) {
+    c0 = info[((size_t)b * T + lane) * T + ka];
+    if (ka + 1 < T) c1 = info[((size_t)b * T + lane) * T + ka + 1];
+  }
+  const uint8_t cw = (tk_wave == ka) ? c0 : c1;
+  TileMasks m;
+  m.need = __ballot(c0 != 0 || c1 != 0);
+  m.w_nz = __ballot(cw != 0);
+  m.w_is1 = __ballot(cw == 1);
+  return m;
+}
+__device__ __forceinline__ int next_tile(unsigned long long need, int after, int n) {   // first set bit > after, else n
+  const unsigned long long rem = (after >= 63) ? 0ull : (need >> (after + 1));
+  return rem ? after + 1 + (int)__builtin_ctzll(rem) : n;
+}
+
 // ---- forward --------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 2) void attn_fwd_mfma_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 stages x (K 8 KiB + V 8 KiB)
@@ -211,8 +245,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_mfma_kernel(AttnArgs a) {
 
   const int nkt = (L + 63) / 64;
   const int ta = qb0 >> 6;
-  int cur = 0;
-  while (cur < nkt && !tile_needed_q(a.info, b, T, ta, cur)) ++cur;
+  const TileMasks tmk = load_tile_masks_q(a.info, b, T, ta, min(q0 >> 6, T - 1), lane);
+  int cur = next_tile(tmk.need, -1, nkt);
   u32x4 rk[2], rv[2];
   if (cur < nkt) {
     tile_load(rk, rs, a.bytes_qkv, rowbase, cur * 64, L, ld, H + head * 64, tid);
@@ -224,15 +258,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_mfma_kernel(AttnArgs a) {
   int buf = 0;
   const uint32_t* myw = a.bits + (rowbase + (q_ok ? q : 0)) * a.W;
   while (cur < nkt) {
-    int nxt = cur + 1;
-    while (nxt < nkt && !tile_needed_q(a.info, b, T, ta, nxt)) ++nxt;
+    const int nxt = next_tile(tmk.need, cur, nkt);
     if (nxt < nkt) {
       tile_load(rk, rs, a.bytes_qkv, rowbase, nxt * 64, L, ld, H + head * 64, tid);
       tile_load(rv, rs, a.bytes_qkv, rowbase, nxt * 64, L, ld, 2 * H + head * 64, tid);
     }
     const char* tK = smem + buf * 16384;
     const char* tV = tK + 8192;
-    const int cls = wave_on ? a.info[((size_t)b * T + (q0 >> 6)) * T + cur] : 0;
+    const int cls = !wave_on ? 0 : (((tmk.w_is1 >> cur) & 1) ? 1 : (((tmk.w_nz >> cur) & 1) ? 2 : 0));
     if (wave_on && cls != 0) {
       const int k0 = cur * 64;
       f32x16 st[2];
@@ -376,8 +409,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_mfma_kernel(AttnArgs a) {
 
   const int nkt = (L + 63) / 64;
   const int ta = qb0 >> 6;
-  int cur = 0;
-  while (cur < nkt && !tile_needed_q(a.info, b, T, ta, cur)) ++cur;
+  const TileMasks tmk = load_tile_masks_q(a.info, b, T, ta, min(q0 >> 6, T - 1), lane);
+  int cur = next_tile(tmk.need, -1, nkt);
   u32x4 rk[2], rv[2];
   if (cur < nkt) {
     tile_load(rk, rs, a.bytes_qkv, rowbase, cur * 64, L, ld, H + head * 64, tid);
@@ -389,15 +422,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_mfma_kernel(AttnArgs a) {
   int buf = 0;
   const uint32_t* myw = a.bits + (rowbase + (q_ok ? q : 0)) * a.W;
   while (cur < nkt) {
-    int nxt = cur + 1;
-    while (nxt < nkt && !tile_needed_q(a.info, b, T, ta, nxt)) ++nxt;
+    const int nxt = next_tile(tmk.need, cur, nkt);
     if (nxt < nkt) {
       tile_load(rk, rs, a.bytes_qkv, rowbase, nxt * 64, L, ld, H + head * 64, tid);
       tile_load(rv, rs, a.bytes_qkv, rowbase, nxt * 64, L, ld, 2 * H + head * 64, tid);
     }
     const char* tK = smem + buf * 16384;
     const char* tV = tK + 8192;
-    const int cls = wave_on ? a.info[((size_t)b * T + (q0 >> 6)) * T + cur] : 0;
+    const int cls = !wave_on ? 0 : (((tmk.w_is1 >> cur) & 1) ? 1 : (((tmk.w_nz >> cur) & 1) ? 2 : 0));
     if (wave_on && cls != 0) {
       const int k0 = cur * 64;
       const bool tail = (k0 + 64 > L);
@@ -508,14 +540,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_mfma_kernel(AttnArgs a) {
     ((uint32_t*)(st + 16384 + 512))[tid] = r_w;
   };
 
-  int cur = 0;
-  while (cur < nqt && !tile_needed_k(a.info, b, T, ka, cur)) ++cur;
+  const TileMasks tmk = load_tile_masks_k(a.info, b, T, ka, min(k0w >> 6, T - 1), lane);
+  int cur = next_tile(tmk.need, -1, nqt);
   if (cur < nqt) { stage_load_all(cur); stage_store_all(smem); }
   __syncthreads();
   int buf = 0;
   while (cur < nqt) {
-    int nxt = cur + 1;
-    while (nxt < nqt && !tile_needed_k(a.info, b, T, ka, nxt)) ++nxt;
+    const int nxt = next_tile(tmk.need, cur, nqt);
     if (nxt < nqt) stage_load_all(nxt);
     const char* st = smem + buf * KV_STAGE;
     const char* tQ = st;
@@ -523,7 +554,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_mfma_kernel(AttnArgs a) {
     const float* s_lse = (const float*)(st + 16384);
     const float* s_dl = (const float*)(st + 16384 + 256);
     const uint32_t* s_w = (const uint32_t*)(st + 16384 + 512);
-    const int cls = wave_on ? a.info[((size_t)b * T + cur) * T + (k0w >> 6)] : 0;
+    const int cls = !wave_on ? 0 : (((tmk.w_is1 >> cur) & 1) ? 1 : (((tmk.w_nz >> cur) & 1) ? 2 : 0));
     if (wave_on && cls != 0) {
 #pragma unroll
       for (int qq = 0; qq < 2; ++qq) {
