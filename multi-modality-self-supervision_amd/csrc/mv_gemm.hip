@@ -307,7 +307,7 @@ __device__ __forceinline__ int t2_off(int kr, int ch) { return kr * 512 + ((ch ^
 // contraction-major image, 256-B rows ([32 k][128 cols]): tr_img_off() of the 128x128 kernel
 
 // PITCH512: contraction-major image with 512-B rows (tile width 192/256) or 256-B rows (tile width 128)
-template <bool TR, bool PITCH512, int NPIECE, int NW>
+template <bool TR, bool PITCH512, int NPIECE, int NW, int KS>
 __device__ __forceinline__ void g2_issue(__amdgpu_buffer_rsrc_t rs, unsigned bytes, int ld, int row0, int rows_total,
                                          int tile_rows, int k0, int kend, char* region, int wid, int lane, int dbg = 0) {
 #pragma unroll
@@ -315,7 +315,12 @@ __device__ __forceinline__ void g2_issue(__amdgpu_buffer_rsrc_t rs, unsigned byt
     const int pc = wid + NW * q;                // 1-KiB piece of the operand image
     unsigned off;
     bool ok;
-    if (!TR) {
+    if (!TR && KS == 2) {       // 8 rows x 128 B per piece: whole cache lines
+      const int r = 8 * pc + (lane >> 3), c = (lane & 7) ^ ((r >> 1) & 7);
+      const int gr = row0 + r, gk = k0 + c * 8;
+      ok = (r < tile_rows) && (gr < rows_total) && (gk < kend);
+      off = ((unsigned)gr * (unsigned)ld + (unsigned)gk) * 2u;
+    } else if (!TR) {
       const int r = 16 * pc + (lane >> 2), c = (lane & 3) ^ r2_f(16 * pc + (lane >> 2));
       const int gr = row0 + r, gk = k0 + c * 8;
       ok = (r < tile_rows) && (gr < rows_total) && (gk < kend);
@@ -336,12 +341,13 @@ __device__ __forceinline__ void g2_issue(__amdgpu_buffer_rsrc_t rs, unsigned byt
   }
 }
 
-template <bool TR, bool PITCH512>
-__device__ __forceinline__ bf16x8 g2_frag(const char* tile, int base, int l15, int lq) {
+template <bool TR, bool PITCH512, int KS>
+__device__ __forceinline__ bf16x8 g2_frag(const char* tile, int base, int l15, int lq, int ks = 0) {
   if (!TR) {
+    if (KS == 2) return *(const bf16x8*)(tile + row_img_off(base + l15, ks * 4 + lq));
     return *(const bf16x8*)(tile + r2_off(base + l15, lq));
   } else {
-    const int kr = 8 * lq + (l15 >> 2);
+    const int kr = ks * 32 + 8 * lq + (l15 >> 2);
     const int ch = (base >> 3) + ((l15 & 3) >> 1);
     const int sub = (l15 & 1) * 8;
     const int o0 = PITCH512 ? t2_off(kr, ch) : tr_img_off(kr, ch);
@@ -354,14 +360,15 @@ __device__ __forceinline__ bf16x8 g2_frag(const char* tile, int base, int l15, i
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <bool TA, bool TB, int NJ, int WN, int NSTAGE>
-__global__ __launch_bounds__(128 * WN, (WN == 2 ? 2 : 2)) void gemm_ring_kernel(GemmArgs p) {
+template <bool TA, bool TB, int NJ, int WN, int NSTAGE, int KS>
+__global__ __launch_bounds__(128 * WN, 2) void gemm_ring_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NW = 2 * WN;                      // waves per block
   constexpr int BN = WN * 16 * NJ;
   constexpr bool BP512 = BN > 128;                // pitch of a contraction-major B image
-  constexpr int A_BYTES = 16384;
-  constexpr int B_BYTES = BP512 ? 16384 : 8192;
+  constexpr int BKS = G2_BK * KS;                 // contraction depth of one stage (32 or 64)
+  constexpr int A_BYTES = 16384 * KS;
+  constexpr int B_BYTES = (BP512 ? 16384 : 8192) * KS;
   constexpr int STAGE = A_BYTES + B_BYTES;
   constexpr int LPS = (A_BYTES + B_BYTES) / 1024 / NW;   // LDS-DMA instructions per wave per stage
   const int tid = threadIdx.x, lane = tid & 63;
@@ -390,7 +397,7 @@ __global__ __launch_bounds__(128 * WN, (WN == 2 ? 2 : 2)) void gemm_ring_kernel(
   const int split = blockIdx.y;
   const int kbeg = split * p.kchunk;
   const int kend = min(p.K, kbeg + p.kchunk);
-  const int nst = (kend - kbeg + G2_BK - 1) / G2_BK;
+  const int nst = (kend - kbeg + BKS - 1) / BKS;
 
   __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, p.bytesA, 0x00020000);
   __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, p.bytesB, 0x00020000);
@@ -404,9 +411,9 @@ __global__ __launch_bounds__(128 * WN, (WN == 2 ? 2 : 2)) void gemm_ring_kernel(
 #define G2_ISSUE(S_)                                                                                        \
   do {                                                                                                      \
     char* st__ = smem + ((S_) % NSTAGE) * STAGE;                                                            \
-    const int k0__ = kbeg + (S_) * G2_BK;                                                                   \
-    g2_issue<TA, true, A_BYTES / 1024, NW>(rsA, p.bytesA, p.lda, m0, p.M, G2_BM, k0__, kend, st__, wid, lane, p.dbg); \
-    g2_issue<TB, BP512, B_BYTES / 1024, NW>(rsB, p.bytesB, p.ldb, n0, p.N, BN, k0__, kend, st__ + A_BYTES, wid, lane, p.dbg); \
+    const int k0__ = kbeg + (S_) * BKS;                                                                     \
+    g2_issue<TA, true, A_BYTES / 1024, NW, KS>(rsA, p.bytesA, p.lda, m0, p.M, G2_BM, k0__, kend, st__, wid, lane, p.dbg); \
+    g2_issue<TB, BP512, B_BYTES / 1024, NW, KS>(rsB, p.bytesB, p.ldb, n0, p.N, BN, k0__, kend, st__ + A_BYTES, wid, lane, p.dbg); \
   } while (0)
 
   const bool do_load = !(p.dbg & 2), do_mma = !(p.dbg & 4);
@@ -416,7 +423,7 @@ __global__ __launch_bounds__(128 * WN, (WN == 2 ? 2 : 2)) void gemm_ring_kernel(
   // that buffer with stage s+NSTAGE.
   // (The second fragment set does not fit in 256 registers next to the transposed-read addresses, so the kernels
   // with a contraction-major operand keep the simpler schedule: read the fragments after the barrier, then MFMA.)
-  constexpr bool PF = !TA && !TB;
+  constexpr bool PF = !TA && !TB && KS == 1;
   if (do_load) {
 #pragma unroll
     for (int s = 0; s < (PF ? NSTAGE : NSTAGE - 1); ++s)
@@ -430,13 +437,14 @@ __global__ __launch_bounds__(128 * WN, (WN == 2 ? 2 : 2)) void gemm_ring_kernel(
     else if (y__ == 2) wait_vmcnt<2 * LPS>();                       \
     else wait_vmcnt<3 * LPS>();                                     \
   } while (0)
-#define G2_FRAGS(FA_, FB_, S_)                                                                   \
+#define G2_FRAGS_K(FA_, FB_, S_, KS_)                                                            \
   do {                                                                                           \
     const char* tA__ = smem + ((S_) % NSTAGE) * STAGE;                                           \
     const char* tB__ = tA__ + A_BYTES;                                                           \
-    _Pragma("unroll") for (int j = 0; j < NJ; ++j) FB_[j] = g2_frag<TB, BP512>(tB__, wn + j * 16, l15, lq); \
-    _Pragma("unroll") for (int i = 0; i < 8; ++i) FA_[i] = g2_frag<TA, true>(tA__, wm + i * 16, l15, lq);   \
+    _Pragma("unroll") for (int j = 0; j < NJ; ++j) FB_[j] = g2_frag<TB, BP512, KS>(tB__, wn + j * 16, l15, lq, KS_); \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i) FA_[i] = g2_frag<TA, true, KS>(tA__, wm + i * 16, l15, lq, KS_);   \
   } while (0)
+#define G2_FRAGS(FA_, FB_, S_) G2_FRAGS_K(FA_, FB_, S_, 0)
 #define G2_MMA(FA_, FB_)                                                                         \
   do {                                                                                           \
     _Pragma("unroll") for (int i = 0; i < 8; ++i)                                                \
@@ -475,14 +483,18 @@ __global__ __launch_bounds__(128 * WN, (WN == 2 ? 2 : 2)) void gemm_ring_kernel(
       __builtin_amdgcn_sched_barrier(0);
       if (do_load && s + NSTAGE - 1 < nst) G2_ISSUE(s + NSTAGE - 1);   // refills the buffer everyone finished reading
       if (!do_mma) continue;
-      bf16x8 fa[8], fb[NJ];
-      G2_FRAGS(fa, fb, s);
-      G2_MMA(fa, fb);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        bf16x8 fa[8], fb[NJ];
+        G2_FRAGS_K(fa, fb, s, ks);
+        G2_MMA(fa, fb);
+      }
     }
   }
 #undef G2_STEP
 #undef G2_MMA
 #undef G2_FRAGS
+#undef G2_FRAGS_K
 #undef G2_WAIT
 #undef G2_ISSUE
 
@@ -656,7 +668,9 @@ extern "C" int mv_gemm(int dtype, int ta, int tb, int M, int N, int K, const voi
                     t128 = (long long)tm2 * ((N + 127) / 128);
     // measured on the model's shapes (profiles/r01_gemm_variants.txt): the ring kernels win for y = x.W^T and
     // dW = dy^T.x, the 128x128 register-staged kernel for dx = dy.W
-    const bool big = (g_mv_gemm_force == 2) || (g_mv_gemm_force == 0 && M >= 256 && N >= 128 && (K & 7) == 0 && !(!ta && tb) &&
+    // (ring kernel with 64-deep stages for wide outputs and for dW; 128x128 register-staged for N <= 1024 and dX)
+    const bool wide_nt = !ta && !tb && N >= 1024;
+    const bool big = (g_mv_gemm_force == 2) || (g_mv_gemm_force == 0 && M >= 256 && N >= 128 && (K & 7) == 0 && (wide_nt || ta) &&
                                                (t128 >= 128 || (K >= 4096 && splitk != 1)));
     if (big) {
       long long sk = splitk;
@@ -672,31 +686,36 @@ extern "C" int mv_gemm(int dtype, int ta, int tb, int M, int N, int K, const voi
                       r128 = (t128 * sk + 511) / 512 * 256;
       int variant = g_mv_gemm_nj;           // 4: 256x256, 3: 256x192, 2: 256x128
       if (variant == 0) {
-        variant = 2;                        // 256x128, 2 blocks / CU: best or tied on every shape measured
+        variant = 14;                       // 256x256, 64-deep stages (whole 128-B lines per LDS-DMA row): best measured
         (void)r256; (void)r192; (void)r128;
       }
       int kchunk = (int)((K + sk - 1) / sk);
-      kchunk = (kchunk + G2_BK - 1) / G2_BK * G2_BK;
+      kchunk = (kchunk + 63) / 64 * 64;
       p.kchunk = kchunk;
       p.splitk = splitk = (K + kchunk - 1) / kchunk;
-      const int tiles = (int)(variant == 4 ? t256 : (variant == 3 ? t192 : t128));
+      // variants: 4 = 256x256 (32-deep stages x4), 3 = 256x192, 2 = 256x128 (x3, 2 blocks/CU),
+      //           14 = 256x256 with 64-deep stages x2 (128-B lines), 12 / 13 = 256x128 with 64-deep stages x2 / x3
+      const int tiles = (int)((variant == 4 || variant == 14) ? t256 : (variant == 3 ? t192 : t128));
       dim3 grid(tiles, splitk);
-#define LAUNCH_RING(TA_, TB_, NJ_, WN_, NS_)                                                                         \
+#define LAUNCH_RING(TA_, TB_, NJ_, WN_, NS_, KS_)                                                                    \
   do {                                                                                                               \
-    constexpr size_t shm = (size_t)(NS_) * (16384 + ((WN_) * 16 * (NJ_) > 128 ? 16384 : 8192));                       \
+    constexpr size_t shm = (size_t)(NS_) * (KS_) * (16384 + ((WN_) * 16 * (NJ_) > 128 ? 16384 : 8192));               \
     static bool attr_set = false;                                                                                    \
     if (!attr_set) {                                                                                                 \
-      (void)hipFuncSetAttribute((const void*)gemm_ring_kernel<TA_, TB_, NJ_, WN_, NS_>,                              \
+      (void)hipFuncSetAttribute((const void*)gemm_ring_kernel<TA_, TB_, NJ_, WN_, NS_, KS_>,                         \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);                               \
       attr_set = true;                                                                                               \
     }                                                                                                                \
-    hipLaunchKernelGGL((gemm_ring_kernel<TA_, TB_, NJ_, WN_, NS_>), grid, dim3(128 * (WN_)), shm, stream, p);         \
+    hipLaunchKernelGGL((gemm_ring_kernel<TA_, TB_, NJ_, WN_, NS_, KS_>), grid, dim3(128 * (WN_)), shm, stream, p);    \
   } while (0)
 #define LAUNCH_RING_V(TA_, TB_)                                  \
   do {                                                           \
-    if (variant == 4) LAUNCH_RING(TA_, TB_, 4, 4, 4);            \
-    else if (variant == 3) LAUNCH_RING(TA_, TB_, 3, 4, 4);       \
-    else LAUNCH_RING(TA_, TB_, 4, 2, 3);                         \
+    if (variant == 4) LAUNCH_RING(TA_, TB_, 4, 4, 4, 1);         \
+    else if (variant == 3) LAUNCH_RING(TA_, TB_, 3, 4, 4, 1);    \
+    else if (variant == 14) LAUNCH_RING(TA_, TB_, 4, 4, 2, 2);   \
+    else if (variant == 12) LAUNCH_RING(TA_, TB_, 4, 2, 2, 2);   \
+    else if (variant == 13) LAUNCH_RING(TA_, TB_, 4, 2, 3, 2);   \
+    else LAUNCH_RING(TA_, TB_, 4, 2, 3, 1);                      \
   } while (0)
       if (!ta && !tb) LAUNCH_RING_V(false, false);
       else if (!ta && tb) LAUNCH_RING_V(false, true);
