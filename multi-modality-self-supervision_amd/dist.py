@@ -44,6 +44,7 @@ class GradAllReducer:
         self.stream = torch.cuda.Stream(device=flat_g.device) if self.cuda else None
         self.works = []
         self._pending_hi = None
+        self._pending_ev = []
 
     def global_counts(self, n_labelled: int, batch: int, device):
         """-> f32[2] device tensor (n_labelled_global, B_global); one small all-reduce."""
@@ -52,7 +53,7 @@ class GradAllReducer:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t
 
-    def _launch(self, s, e):
+    def _launch(self, s, e, events=()):
         if self.world == 1 or e <= s:
             return
         view = self.flat_g[s:e]
@@ -61,12 +62,16 @@ class GradAllReducer:
             ev.record(torch.cuda.current_stream())
             with torch.cuda.stream(self.stream):
                 self.stream.wait_event(ev)
+                for x in events:                 # gradients produced on the engine's side stream
+                    if x is not None:
+                        self.stream.wait_event(x)
                 self.works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         else:
             self.works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
-    def hook(self, name: str):
-        """Called by Engine.encoder_backward when the gradients of bucket `name` are final."""
+    def hook(self, name: str, event=None):
+        """Called by Engine.encoder_backward when the gradients of bucket `name` are final (`event`: side-stream
+        event after the bucket's weight-gradient GEMMs, or None when everything is on the current stream)."""
         if name == "heads":
             # mlm.predictions.* / pooler / itm are final; the tied E gradient is NOT (embedding scatter comes last)
             self._launch(*self.ranges["heads"])
@@ -74,8 +79,10 @@ class GradAllReducer:
             l = int(name[5:])
             if self._pending_hi is None:
                 self._pending_hi = self.ranges[name][1]
+                self._pending_ev = []
+            self._pending_ev.append(event)
             if l % self.merge == 0 or l == 0:
-                self._launch(self.ranges[name][0], self._pending_hi)
+                self._launch(self.ranges[name][0], self._pending_hi, self._pending_ev)
                 self._pending_hi = None
         elif name == "embeddings":
             self._launch(*self.ranges["embeddings"])

@@ -127,6 +127,7 @@ class Engine:
         self.shadow_dirty = True
         self._ws = {}
         self._gemm_ws = None
+        self._side = None             # side HIP stream for the weight-gradient GEMMs of the backward
         self.training = False         # dropout is active only when True (CXRBERT.train() / TrainStep(train=True))
         self.drop_seed = 0x5DEECE66D
         self.drop_counter = 0         # advanced once per forward: every step draws fresh masks
@@ -462,23 +463,41 @@ class Engine:
     # ------------------------------------------------------------------ encoder backward
     def encoder_backward(self, bucket_hook=None):
         """Consumes S['dhidden'] (grad w.r.t. the last hidden states); fills the flat gradient.
-        bucket_hook(name) is called when the gradients of a contiguous parameter range are final
-        ('heads', 'layer<l>', 'embeddings') so a data-parallel driver can start its all-reduce."""
+
+        Two HIP streams: the MAIN stream carries the dependency chain of the backward (LayerNorm backward -> dX GEMMs
+        -> attention backward ...); every weight / bias gradient (dW = dy^T.x, column sums), which nothing downstream
+        needs before the optimizer, is enqueued on a SIDE stream behind an event, so those MFMA-bound GEMMs fill the
+        CUs that the VALU- or HBM-bound kernels of the main chain leave idle.  Per-layer gradient scratch (no buffer is
+        rewritten while the side stream may still read it; ~6.6 GB at B=64, L=512).
+
+        bucket_hook(name, event) is called when the gradients of a contiguous parameter range are final on the side
+        stream ('heads', 'layer<l>', 'embeddings') so a data-parallel driver can start its all-reduce."""
         cfg, S = self.cfg, self.S
         H, A, I, D = cfg.hidden, cfg.heads, cfg.intermediate, cfg.img_hidden
         dh = H // A
         B, Lq, M, N, T = S["B"], S["L"], S["M"], S["N"], S["T"]
         adt, g = self.adt, self.g
         dy = S["dhidden"]
+        main = torch.cuda.current_stream()
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        side = self._side
+        side.wait_stream(main)              # the heads' gradients and the zeroed flat gradient are ordered before us
+
+        def fork():
+            ev = torch.cuda.Event()
+            ev.record(main)
+            side.wait_event(ev)
+
+        def side_done():
+            ev = torch.cuda.Event()
+            ev.record(side)
+            return ev
+
         if bucket_hook:
-            bucket_hook("heads")
+            bucket_hook("heads", None)
         pd, dk = S["p_drop"], S["drop_keys"]
-        dpre = self._buf("bw_dpre", (M, H), adt)
-        # with dropout the projection branch sees dpre * mask / (1-p) while the residual branch sees dpre itself
-        dprd = self._buf("bw_dprd", (M, H), adt) if pd > 0 else None
-        dz = self._buf("bw_dz", (M, I), adt)
         dctx = self._buf("bw_dctx", (M, H), adt)
-        dqkv = self._buf("bw_dqkv", (M, 3 * H), adt)
         delta = self._buf("bw_delta", (B, A, Lq), torch.float32)
         da = self._buf("bw_da", (M, H), adt)
         dxb = [self._buf("bw_dx0", (M, H), adt), self._buf("bw_dx1", (M, H), adt)]
@@ -486,32 +505,50 @@ class Engine:
             p = f"enc.encoder.layer.{l}."
             a_ = S["layers"][l]
             Wqkv, _, gWqkv, gbqkv = self.qkv_views(l)
+            # with dropout the projection branch sees dpre * mask / (1-p) while the residual branch sees dpre itself
+            dpre2 = self._buf(f"bw_dpre2_{l}", (M, H), adt)
+            dprd2 = self._buf(f"bw_dprd2_{l}", (M, H), adt) if pd > 0 else None
+            dpre1 = self._buf(f"bw_dpre1_{l}", (M, H), adt)
+            dprd1 = self._buf(f"bw_dprd1_{l}", (M, H), adt) if pd > 0 else None
+            dz = self._buf(f"bw_dz_{l}", (M, I), adt)
+            dqkv = self._buf(f"bw_dqkv_{l}", (M, 3 * H), adt)
             # LN2 backward (+ bias grad of output.dense)
-            ops.layernorm_bwd(dy, a_["pre2"], a_["mean2"], a_["rstd2"], self.p[p + "output.LayerNorm.weight"], dpre,
+            ops.layernorm_bwd(dy, a_["pre2"], a_["mean2"], a_["rstd2"], self.p[p + "output.LayerNorm.weight"], dpre2,
                               g[p + "output.LayerNorm.weight"], g[p + "output.LayerNorm.bias"], g[p + "output.dense.bias"], M, H,
-                              dx_drop=dprd, p_drop=pd, drop_key=dk[(self.SITE_OUT2, l)])
-            dproj = dprd if dprd is not None else dpre
-            self._dW(dproj, a_["i"], g[p + "output.dense.weight"], H, I, M, lda=H, ldb=I)
-            ops.gemm(dproj, self.w[p + "output.dense.weight"], dz, tb=True, M=M, N=I, K=H, epi=EPI_DGELU, r=a_["z"])
-            ops.colsum(dz, I, M, I, g[p + "intermediate.dense.bias"], accumulate=True)
-            self._dW(dz, a_["a"], g[p + "intermediate.dense.weight"], I, H, M, lda=I, ldb=H)
-            ops.gemm(dz, self.w[p + "intermediate.dense.weight"], da, tb=True, M=M, N=H, K=I, epi=EPI_RES, r=dpre)
+                              dx_drop=dprd2, p_drop=pd, drop_key=dk[(self.SITE_OUT2, l)])
+            dproj2 = dprd2 if dprd2 is not None else dpre2
+            fork()
+            with torch.cuda.stream(side):
+                self._dW(dproj2, a_["i"], g[p + "output.dense.weight"], H, I, M, lda=H, ldb=I)
+            ops.gemm(dproj2, self.w[p + "output.dense.weight"], dz, tb=True, M=M, N=I, K=H, epi=EPI_DGELU, r=a_["z"])
+            fork()
+            with torch.cuda.stream(side):
+                ops.colsum(dz, I, M, I, g[p + "intermediate.dense.bias"], accumulate=True)
+                self._dW(dz, a_["a"], g[p + "intermediate.dense.weight"], I, H, M, lda=I, ldb=H)
+            ops.gemm(dz, self.w[p + "intermediate.dense.weight"], da, tb=True, M=M, N=H, K=I, epi=EPI_RES, r=dpre2)
             # LN1 backward (+ bias grad of attention.output.dense)
-            ops.layernorm_bwd(da, a_["pre1"], a_["mean1"], a_["rstd1"], self.p[p + "attention.output.LayerNorm.weight"], dpre,
+            ops.layernorm_bwd(da, a_["pre1"], a_["mean1"], a_["rstd1"], self.p[p + "attention.output.LayerNorm.weight"], dpre1,
                               g[p + "attention.output.LayerNorm.weight"], g[p + "attention.output.LayerNorm.bias"],
-                              g[p + "attention.output.dense.bias"], M, H, dx_drop=dprd, p_drop=pd,
+                              g[p + "attention.output.dense.bias"], M, H, dx_drop=dprd1, p_drop=pd,
                               drop_key=dk[(self.SITE_OUT1, l)])
-            self._dW(dproj, a_["ctx"], g[p + "attention.output.dense.weight"], H, H, M, lda=H, ldb=H)
-            ops.gemm(dproj, self.w[p + "attention.output.dense.weight"], dctx, tb=True, M=M, N=H, K=H)
+            dproj1 = dprd1 if dprd1 is not None else dpre1
+            fork()
+            with torch.cuda.stream(side):
+                self._dW(dproj1, a_["ctx"], g[p + "attention.output.dense.weight"], H, H, M, lda=H, ldb=H)
+            ops.gemm(dproj1, self.w[p + "attention.output.dense.weight"], dctx, tb=True, M=M, N=H, K=H)
             ops.attn_bwd(a_["qkv"], a_["ctx"], dctx, a_["lse"], S["bits"], S["tinfo"], dqkv, delta, B, Lq, A, dh, p_drop=pd,
                          drop_key=dk[(self.SITE_ATTN, l)])
-            ops.colsum(dqkv, 3 * H, M, 3 * H, gbqkv, accumulate=True)
-            self._dW(dqkv, a_["x"], gWqkv, 3 * H, H, M, lda=3 * H, ldb=H)
+            fork()
+            with torch.cuda.stream(side):
+                ops.colsum(dqkv, 3 * H, M, 3 * H, gbqkv, accumulate=True)
+                self._dW(dqkv, a_["x"], gWqkv, 3 * H, H, M, lda=3 * H, ldb=H)
+                ev_layer = side_done()
             dx = dxb[l & 1]          # never the buffer dy currently lives in
-            ops.gemm(dqkv, Wqkv, dx, tb=True, M=M, N=H, K=3 * H, epi=EPI_RES, r=dpre)
+            ops.gemm(dqkv, Wqkv, dx, tb=True, M=M, N=H, K=3 * H, epi=EPI_RES, r=dpre1)
             dy = dx
             if bucket_hook:
-                bucket_hook(f"layer{l}")
+                # LayerNorm / bias gradients of the layer were written on the main stream, the weights on the side stream
+                bucket_hook(f"layer{l}", ev_layer)
         e = "enc.txt_embeddings."
         dimg = self._buf("bw_dimg", (B * N, H), adt)
         ops.embed_bwd(self.dt, dy, self._ws["pre0"][:M * H].view(M, H), self._ws["mean0"][:M], self._ws["rstd0"][:M],
@@ -519,11 +556,12 @@ class Engine:
                       g[e + "word_embeddings.weight"], g[e + "position_embeddings.weight"], g[e + "token_type_embeddings.weight"],
                       g[e + "LayerNorm.weight"], g[e + "LayerNorm.bias"], dimg, B, N, T, H, cfg.vocab_size, cfg.max_pos,
                       pad_token_id=0, p_drop=pd, drop_key=dk[(self.SITE_EMB, 0)])
+        main.wait_stream(side)              # every weight gradient is final; the split-K workspace is ours again
         if N > 0:
             ops.colsum(dimg, H, B * N, H, g["enc.img_embeddings.img_embeddings.bias"], accumulate=True)
             self._dW(dimg, S["feats"], g["enc.img_embeddings.img_embeddings.weight"], H, D, B * N, lda=H, ldb=D)
         if bucket_hook:
-            bucket_hook("embeddings")
+            bucket_hook("embeddings", None)
 
     # ------------------------------------------------------------------ optimizer
     def adamw_step(self, step, lr=1e-5, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.0, correct_bias=True, grad_scale=1.0):

@@ -29,10 +29,10 @@ def _worker(rank, world, port, out):
     red = GradAllReducer(g, lay, n, cfg.layers, merge_layers=2)
     cnt = red.global_counts(10 + rank, 4, "cpu")
     # the order Engine.encoder_backward reports finished buckets in
-    red.hook("heads")
+    red.hook("heads", None)
     for l in reversed(range(cfg.layers)):
-        red.hook(f"layer{l}")
-    red.hook("embeddings")
+        red.hook(f"layer{l}", None)
+    red.hook("embeddings", None)
     red.finish()
     expect = torch.arange(n, dtype=torch.float32) * sum(r + 1 for r in range(world))
     ok = bool(torch.equal(g, expect)) and cnt.tolist() == [float(sum(10 + r for r in range(world))), 4.0 * world]
