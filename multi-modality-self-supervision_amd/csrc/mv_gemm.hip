@@ -694,8 +694,9 @@ extern "C" int mv_gemm(int dtype, int ta, int tb, int M, int N, int K, const voi
       p.kchunk = kchunk;
       p.splitk = splitk = (K + kchunk - 1) / kchunk;
       // variants: 4 = 256x256 (32-deep stages x4), 3 = 256x192, 2 = 256x128 (x3, 2 blocks/CU),
-      //           14 = 256x256 with 64-deep stages x2 (128-B lines), 12 / 13 = 256x128 with 64-deep stages x2 / x3
-      const int tiles = (int)((variant == 4 || variant == 14) ? t256 : (variant == 3 ? t192 : t128));
+      //           14 = 256x256 with 64-deep stages x2 (128-B lines), 15 = 256x192 likewise, 12 / 13 = 256x128 with
+      //           64-deep stages x2 / x3
+      const int tiles = (int)((variant == 4 || variant == 14) ? t256 : ((variant == 3 || variant == 15) ? t192 : t128));
       dim3 grid(tiles, splitk);
 #define LAUNCH_RING(TA_, TB_, NJ_, WN_, NS_, KS_)                                                                    \
   do {                                                                                                               \
@@ -713,6 +714,7 @@ extern "C" int mv_gemm(int dtype, int ta, int tb, int M, int N, int K, const voi
     if (variant == 4) LAUNCH_RING(TA_, TB_, 4, 4, 4, 1);         \
     else if (variant == 3) LAUNCH_RING(TA_, TB_, 3, 4, 4, 1);    \
     else if (variant == 14) LAUNCH_RING(TA_, TB_, 4, 4, 2, 2);   \
+    else if (variant == 15) LAUNCH_RING(TA_, TB_, 3, 4, 2, 2);   \
     else if (variant == 12) LAUNCH_RING(TA_, TB_, 4, 2, 2, 2);   \
     else if (variant == 13) LAUNCH_RING(TA_, TB_, 4, 2, 3, 2);   \
     else LAUNCH_RING(TA_, TB_, 4, 2, 3, 1);                      \

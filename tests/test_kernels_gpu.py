@@ -40,11 +40,11 @@ def dgelu(z):
 GEMM_SHAPES = [(256, 256, 256), (130, 70, 200), (1024, 768, 768), (64, 2, 768), (96, 1000, 128), (517, 264, 3072)]
 
 
-VARIANT = {"mfma": (1, 0), "mfma256": (2, 4), "mfma192": (2, 3), "mfma128r": (2, 2), "mfma256k64": (2, 14), "mfma128k64": (2, 12),
+VARIANT = {"mfma": (1, 0), "mfma256": (2, 4), "mfma192": (2, 3), "mfma128r": (2, 2), "mfma256k64": (2, 14), "mfma128k64": (2, 12), "mfma192k64": (2, 15),
            "mfma128k64s3": (2, 13), "mfma_auto": (0, 0)}   # mv_set_gemm_variant(force, nj)
 
 
-@pytest.mark.parametrize("impl", ["mfma", "mfma256", "mfma192", "mfma128r", "mfma256k64", "mfma128k64", "mfma128k64s3", "simple_bf16", "f32"])
+@pytest.mark.parametrize("impl", ["mfma", "mfma256", "mfma192", "mfma128r", "mfma256k64", "mfma128k64", "mfma128k64s3", "mfma192k64", "simple_bf16", "f32"])
 @pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 1), (1, 0)])
 @pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
 def test_gemm_layouts(impl, ta, tb, M, N, K):
@@ -74,7 +74,7 @@ def test_gemm_layouts(impl, ta, tb, M, N, K):
         ops.set_gemm_variant(0, 0)
 
 
-@pytest.mark.parametrize("impl", ["mfma", "mfma256", "mfma192", "mfma128r", "mfma256k64", "mfma128k64", "mfma128k64s3", "f32"])
+@pytest.mark.parametrize("impl", ["mfma", "mfma256", "mfma192", "mfma128r", "mfma256k64", "mfma128k64", "mfma128k64s3", "mfma192k64", "f32"])
 @pytest.mark.parametrize("epi", [EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RES, EPI_DGELU, EPI_RES, EPI_BIAS_TANH])
 @pytest.mark.parametrize("M,N,K,cdt", [(256, 384, 128, "bf16"), (200, 130, 72, "f32"), (128, 768, 768, "f32")])
 def test_gemm_epilogues(impl, epi, M, N, K, cdt):
@@ -109,7 +109,7 @@ def test_gemm_epilogues(impl, epi, M, N, K, cdt):
     assert relerr(c, ref) < (2e-5 if cd == torch.float32 else 1e-2)
 
 
-@pytest.mark.parametrize("impl", ["mfma", "mfma256", "mfma192", "mfma128r", "mfma256k64", "mfma128k64", "mfma128k64s3", "f32"])
+@pytest.mark.parametrize("impl", ["mfma", "mfma256", "mfma192", "mfma128r", "mfma256k64", "mfma128k64", "mfma128k64s3", "mfma192k64", "f32"])
 def test_gemm_splitk_and_accumulate(impl):
     dt = torch.float32 if impl == "f32" else torch.bfloat16
     Mt, No, Ko = 4096, 200, 136
