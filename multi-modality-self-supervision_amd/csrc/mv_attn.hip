@@ -449,9 +449,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_mfma_kernel(AttnArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int kr = acc_row(r, h);
-          float v = st[r] * c2;
-          if (cls != 1) v += ((w >> kr) & 1u) ? 0.f : MASK_ADD * LOG2E;
-          float pv = fexp2(v - lse2);
+          float pv;
+          if (cls == 1) {
+            pv = fexp2(fmaf(st[r], c2, -lse2));
+          } else {
+            const float v = fmaf(st[r], c2, ((w >> kr) & 1u) ? 0.f : MASK_ADD * LOG2E);
+            pv = fexp2(v - lse2);
+          }
           if (tail && (k0 + 32 * kk + kr >= L)) pv = 0.f;
           float dpr = dp[r];
           if (a.drop.thr) {
@@ -578,12 +582,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_mfma_kernel(AttnArgs a) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const int r = 4 * g + e;
-            float v = sc[r] * c2;
-            if (cls != 1) {
+            float p;                              // rows q >= L carry lse = +inf -> p = 0
+            if (cls == 1) {
+              p = fexp2(fmaf(sc[r], c2, -l4[e]));
+            } else {
               const uint32_t w = s_w[(qr0 + e) * 4 + wid];
-              v += ((w >> l31) & 1u) ? 0.f : MASK_ADD * LOG2E;
+              p = fexp2(fmaf(sc[r], c2, ((w >> l31) & 1u) ? 0.f : MASK_ADD * LOG2E) - l4[e]);
             }
-            const float p = fexp2(v - l4[e]);     // rows q >= L carry lse = +inf -> p = 0
             float keepf = 1.0f;
             if (a.drop.thr) {
               // the 4 lanes of a quad hold keys 4j..4j+3 = ONE mask group per query: lane e' of the quad hashed query

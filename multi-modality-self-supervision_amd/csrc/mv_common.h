@@ -72,11 +72,19 @@ __device__ __forceinline__ float fast_erf(float x) {
   return copysignf(r, x);
 }
 __device__ __forceinline__ float gelu_erf(float z) { return z * 0.5f * (1.0f + fast_erf(z * 0.70710678118654752440f)); }
-// d/dz [ z * Phi(z) ] = Phi(z) + z * phi(z)
+// d/dz [ z * Phi(z) ] = Phi(z) + z * phi(z).  The erf approximation's exp(-(z/sqrt2)^2) IS the Gaussian pdf's
+// exp(-z^2/2): one exponential and one reciprocal serve both terms.
 __device__ __forceinline__ float dgelu_erf(float z) {
-  const float cdf = 0.5f * (1.0f + fast_erf(z * 0.70710678118654752440f));
-  const float pdf = 0.39894228040143267794f * __expf(-0.5f * z * z);
-  return cdf + z * pdf;
+  const float u = z * 0.70710678118654752440f, au = fabsf(u);
+  const float t = __frcp_rn(fmaf(0.3275911f, au, 1.0f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float e = __expf(-au * au);
+  const float erf_abs = 1.0f - p * t * e;
+  const float cdf = 0.5f * (1.0f + copysignf(erf_abs, u));
+  return fmaf(z * 0.39894228040143267794f, e, cdf);
 }
 
 // ---- dropout: counter-based mask, regenerated (never stored) in the backward kernels --------------------------
