@@ -112,6 +112,12 @@ int mv_gemm(int dtype, int ta, int tb, int M, int N, int K,
 int mv_mask_pack(const int64_t* mask, int mask_ndim, int B, int L,
                  uint32_t* bits, uint8_t* tileinfo, void* stream);
 
+/* Same outputs built on the device from per-sample descriptors instead of a materialised [B,L,L] int64 matrix
+ * (the reference ships 2 MB / sample at L = 512 from its DataLoader workers, dataset_origin.py:138-176):
+ * desc int32 [B,3] = {family, n2, vl}; family 0 full (j < vl), 1 seq2seq, 2 BAR, 3 non-cross, 4 1-D (j < vl);
+ * n2 = num_image_embeds + 2; vl = n2 + #text ids incl. [SEP].  Closed forms: SURVEY.md Appendix B.             */
+int mv_mask_build(const int32_t* desc, int B, int L, uint32_t* bits, uint8_t* tileinfo, void* stream);
+
 /* ---- fused-mask multi-head attention --------------------------------------------------------
  * Replaces HF BertSelfAttention's scores/softmax/context (spec:
  * Downstream_task/report_generation_and_vqa/sc/pytorch_pretrained_bert/model.py:301-320):

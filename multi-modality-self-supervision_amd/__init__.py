@@ -8,6 +8,7 @@ on top of hand-written HIP kernels reached through the C ABI of include/medvill.
 from .engine import Engine, ModelConfig, param_layout  # noqa: F401
 from .cxrbert import CXRBERT  # noqa: F401
 from .trainer import CXRBERT_Trainer, TrainStep  # noqa: F401
+from .retrieval import CXRBertForRetrieval  # noqa: F401
 from . import data  # noqa: F401
 
-__all__ = ["Engine", "ModelConfig", "param_layout", "CXRBERT", "CXRBERT_Trainer", "TrainStep", "data"]
+__all__ = ["Engine", "ModelConfig", "param_layout", "CXRBERT", "CXRBERT_Trainer", "TrainStep", "CXRBertForRetrieval", "data"]

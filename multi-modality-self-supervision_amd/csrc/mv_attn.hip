@@ -79,6 +79,46 @@ __global__ void mask_tileinfo_kernel(const uint32_t* __restrict__ bits, int B, i
   }
 }
 
+// bits straight from per-sample descriptors {family, n2, vl}: the closed forms of SURVEY Appendix B
+// (data/dataset_origin.py:138-176).  family: 0 full, 1 s2s, 2 BAR, 3 non-cross, 4 1-D (== full as a [L,L] matrix)
+__global__ void mask_build_kernel(const int32_t* __restrict__ desc, int B, int L, int W, uint32_t* __restrict__ bits) {
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (wave >= B * L) return;
+  const int b = wave / L, i = wave - b * L;
+  const int fam = desc[3 * b], n2 = desc[3 * b + 1], vl = desc[3 * b + 2];
+  uint32_t* out = bits + ((size_t)b * L + i) * W;
+  for (int j0 = 0; j0 < L; j0 += 64) {
+    const int j = j0 + lane;
+    bool v;
+    switch (fam) {
+      case 1: v = (j < n2) || (i >= n2 && j >= n2 && j <= i); break;
+      case 2: v = (i < n2) || (j < n2) || (j <= i); break;
+      case 3: v = (i < n2) == (j < n2); break;
+      default: v = j < vl; break;
+    }
+    v = v && (j < L);
+    const unsigned long long bal = __ballot(v);
+    if (lane == 0) {
+      out[j0 >> 5] = (uint32_t)bal;
+      if ((j0 >> 5) + 1 < W) out[(j0 >> 5) + 1] = (uint32_t)(bal >> 32);
+    }
+  }
+}
+
+extern "C" int mv_mask_build(const int32_t* desc, int B, int L, uint32_t* bits, uint8_t* tileinfo, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!desc || !bits || !tileinfo || B <= 0 || L <= 0) return MV_E_ARG;
+  const int W = (L + 31) / 32, T = (L + 63) / 64;
+  if (T > 64) return MV_E_SHAPE;
+  const long long waves = (long long)B * L;
+  hipLaunchKernelGGL(mask_build_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream, desc, B, L, W, bits);
+  MV_CHECK_LAUNCH();
+  hipLaunchKernelGGL(mask_tileinfo_kernel, dim3(B * T), dim3(64), 0, stream, bits, B, L, W, T, tileinfo);
+  MV_CHECK_LAUNCH();
+  return MV_OK;
+}
+
 extern "C" int mv_mask_pack(const int64_t* mask, int mask_ndim, int B, int L, uint32_t* bits, uint8_t* tileinfo, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!mask || !bits || !tileinfo || B <= 0 || L <= 0) return MV_E_ARG;

@@ -16,6 +16,35 @@ PAD, UNK, CLS, SEP, MASK = 0, 100, 101, 102, 103
 FAMILIES = ("full", "s2s", "bar", "noncross", "1d")
 
 
+FAMILY_ID = {"full": 0, "s2s": 1, "bar": 2, "noncross": 3, "1d": 4}
+
+
+class MaskDesc:
+    """Per-sample mask descriptors {family, n2, vl} (int32 [B,3]): what the attention kernels need instead of the
+    reference's materialised int64 [B,L,L] matrices.  Accepted wherever `attn_mask` is (CXRBERT.forward, TrainStep)."""
+
+    def __init__(self, desc: torch.Tensor, L: int):
+        self.desc, self.L = desc.to(torch.int32), int(L)
+
+    @classmethod
+    def make(cls, family, N: int, S: int, n_ids, device="cpu"):
+        """family: one name for the whole batch or a per-sample sequence of names (Mixed)."""
+        n_ids = torch.as_tensor(n_ids, dtype=torch.int32).view(-1)
+        B = n_ids.numel()
+        fam = [family] * B if isinstance(family, str) else list(family)
+        d = torch.empty((B, 3), dtype=torch.int32)
+        d[:, 0] = torch.tensor([FAMILY_ID[f] for f in fam], dtype=torch.int32)
+        d[:, 1] = N + 2
+        d[:, 2] = N + 2 + n_ids
+        return cls(d.to(device), S + N + 3)
+
+    def dim(self):
+        return 3
+
+    def to(self, device, *a, **k):
+        return MaskDesc(self.desc.to(device), self.L)
+
+
 def build_mask(family: str, N: int, S: int, n_ids, device="cpu") -> torch.Tensor:
     """int64 [B,L,L] (or [B,L] for '1d') for per-sample text lengths n_ids (incl. the text [SEP])."""
     n_ids = torch.as_tensor(n_ids, device=device, dtype=torch.int64).view(-1)
@@ -97,13 +126,17 @@ def synthetic_batch(vocab: int, B: int, N: int, S: int, family: str, seed: int, 
     if family == "mixed":
         choose = torch.rand((B,), generator=gen, device=dev) < 0.75
         mask = mixed_mask(N, S, n_ids, choose, dev)
+        fams = ["s2s" if c else "full" for c in choose.tolist()]
     else:
         mask = build_mask(family, N, S, n_ids, dev)
+        fams = family
+    desc = MaskDesc.make(fams, N, S, n_ids.cpu(), dev)
     flat = labels.view(-1)
     rows = torch.nonzero(flat != -100).view(-1)
     return dict(cls_tok=torch.full((B, 1), CLS, dtype=torch.int64, device=dev), input_txt=txt, attn_mask=mask, segment=segment,
                 img_feats=feats, img_pos=pos, sep_tok=torch.full((B, 1), SEP, dtype=torch.int64, device=dev), txt_labels=labels,
-                is_aligned=is_aligned, n_ids=n_ids, label_rows=rows.to(torch.int32), label_ids=flat[rows].to(torch.int32))
+                is_aligned=is_aligned, n_ids=n_ids, label_rows=rows.to(torch.int32), label_ids=flat[rows].to(torch.int32),
+                attn_desc=desc)
 
 
 def label_index(txt_labels: torch.Tensor):

@@ -245,7 +245,11 @@ class Engine:
         N = img_feats.shape[1]
         Lq = N + T + 2
         M = B * Lq
-        if attn_mask.shape[0] != B or attn_mask.shape[-1] != Lq:
+        from .data import MaskDesc
+        if isinstance(attn_mask, MaskDesc):
+            if attn_mask.desc.shape[0] != B or attn_mask.L != Lq:
+                raise ValueError(f"mask descriptors (B={attn_mask.desc.shape[0]}, L={attn_mask.L}) do not match B={B}, L={Lq}")
+        elif attn_mask.shape[0] != B or attn_mask.shape[-1] != Lq:
             raise ValueError(f"attn_mask shape {tuple(attn_mask.shape)} does not match L = N+T+2 = {Lq}")
         if self.shadow_dirty:
             self.sync_shadow()
@@ -274,7 +278,10 @@ class Engine:
         W32, Tt = (Lq + 31) // 32, (Lq + 63) // 64
         bits = self._buf("bits", (B, Lq, W32), torch.int32)
         tinfo = self._buf("tinfo", (B, Tt, Tt), torch.uint8)
-        ops.mask_pack(attn_mask.to(dev), bits, tinfo)
+        if isinstance(attn_mask, MaskDesc):
+            ops.mask_build(attn_mask.desc.to(dev), B, Lq, bits, tinfo)       # synthesised on the device, no [B,L,L] input
+        else:
+            ops.mask_pack(attn_mask.to(dev), bits, tinfo)
         S["bits"], S["tinfo"] = bits, tinfo
         # image projection + embeddings
         e = "enc.txt_embeddings."

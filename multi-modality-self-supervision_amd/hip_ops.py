@@ -45,6 +45,15 @@ def mask_pack(mask, bits, tileinfo):
     L.check(rc, "mv_mask_pack")
 
 
+def mask_build(desc, B, Lq, bits, tileinfo):
+    """bits / tile classes from int32 [B,3] descriptors {family, n2, vl} (see mv_mask_build)."""
+    L.require_cuda(desc, bits, tileinfo)
+    if desc.dtype != torch.int32 or tuple(desc.shape) != (B, 3):
+        raise TypeError("desc must be int32 [B,3]")
+    rc = _lib().mv_mask_build(L.ptr(desc.contiguous()), B, Lq, L.ptr(bits), L.ptr(tileinfo), L.stream_ptr())
+    L.check(rc, "mv_mask_build")
+
+
 def attn_fwd(qkv, bits, tileinfo, ctx, lse, B, Lq, A, dh, p_drop=0.0, drop_key=0):
     rc = _lib().mv_attn_fwd(L.dt_of(qkv), L.ptr(qkv), L.ptr(bits), L.ptr(tileinfo), L.ptr(ctx), L.ptr(lse), B, Lq, A, dh,
                             float(p_drop), int(drop_key), L.stream_ptr())

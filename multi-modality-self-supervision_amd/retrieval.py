@@ -1,0 +1,35 @@
+"""Mirror of the reference's retrieval head (Downstream_task/Retrieval/retrieval.py:12-32): ITM-style matching on
+top of CXRBERT.enc + .itm with 1-D attention masks (the `attn_mask.dim() == 2` branch, cxrbert_origin.py:76-77).
+Encoder-only inference / fine-tuning through the same HIP kernels."""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from .cxrbert import CXRBERT
+
+
+class CXRBertForRetrieval(nn.Module):
+    def __init__(self, config, args=None, **kw):
+        super().__init__()
+        self.bert = CXRBERT(config, args, **kw)
+        self.enc, self.itm = self.bert.enc, self.bert.itm
+
+    @classmethod
+    def from_pretrained(cls, path, args=None, **kw):
+        m = cls.__new__(cls)
+        nn.Module.__init__(m)
+        m.bert = CXRBERT.from_pretrained(path, args=args, **kw)
+        m.enc, m.itm = m.bert.enc, m.bert.itm
+        return m
+
+    def forward(self, cls_tok, input_txt, attn_mask, segment, input_img, sep_tok):
+        """-> ITM logits [B,2] (retrieval.py:26-31: `_, cls, _ = self.enc(...); return self.itm(cls)`)."""
+        _, pooled, _ = self.enc(cls_tok, input_txt, attn_mask, segment, input_img, sep_tok)
+        w, b = self.bert.get_parameter("itm.linear.weight"), self.bert.get_parameter("itm.linear.bias")
+        return torch.nn.functional.linear(pooled.float(), w, b)      # [B,H] x [H,2]: plumbing-sized
+
+    @torch.no_grad()
+    def score(self, *batch):
+        """P(aligned) per pair, as full_dset_retrieval.py:461-510 ranks candidates."""
+        return torch.softmax(self.forward(*batch), dim=-1)[:, 1]

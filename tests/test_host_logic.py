@@ -96,6 +96,11 @@ def test_synthetic_batch_follows_the_dataset_contract():
         assert any(np.array_equal(m, D.build_mask(f, N, S, n)) for f in ("full", "s2s"))
     pos = b["img_pos"]
     assert (pos[0] == pos[-1]).all() and (pos[0][1:] > pos[0][:-1]).all() and pos.max() < 256   # image.py:63-68
+    d = b["attn_desc"]                                                   # {family, n2, vl} per sample
+    assert d.L == L and (d.desc[:, 1] == N + 2).all() and torch.equal(d.desc[:, 2].long(), N + 2 + b["n_ids"])
+    for i in range(B):
+        fam = {0: "full", 1: "s2s"}[int(d.desc[i, 0])]
+        assert np.array_equal(b["attn_mask"][i].numpy(), D.build_mask(fam, N, S, int(b["n_ids"][i])))
     rows, ids = mv.data.label_index(b["txt_labels"])
     assert torch.equal(rows, b["label_rows"]) and torch.equal(ids, b["label_ids"])
     frac = float((b["txt_labels"] != -100).sum()) / float((b["n_ids"] - 1).sum())

@@ -261,6 +261,26 @@ def test_mask_pack_bits_and_tile_classes():
                     assert ti[b, tq, tk] == c, (fam, b, tq, tk)
 
 
+def test_mask_build_from_descriptors_equals_packed_reference_matrices():
+    """On-device synthesis {family, n2, vl} -> bits must be bit-identical to packing the Dataset-style matrices."""
+    B, N, S = 5, 36, 90
+    Lq = N + S + 3
+    W, T = (Lq + 31) // 32, (Lq + 63) // 64
+    n_ids = torch.tensor([1, 2, 46, 90, 91])
+    fams = ["full", "s2s", "bar", "noncross", "1d"]
+    for fam in fams + ["per-sample"]:
+        per = fams if fam == "per-sample" else [fam] * B
+        mats = torch.stack([(D.build_mask(f, N, S, n_ids[b:b + 1])[0] if f != "1d" else
+                             D.build_mask("1d", N, S, n_ids[b:b + 1])[0][None, :].expand(Lq, Lq)) for b, f in enumerate(per)])
+        b1 = torch.zeros((B, Lq, W), dtype=torch.int32, device=DEV)
+        t1 = torch.zeros((B, T, T), dtype=torch.uint8, device=DEV)
+        ops.mask_pack(mats.contiguous().to(DEV), b1, t1)
+        b2, t2 = torch.zeros_like(b1), torch.zeros_like(t1)
+        desc = D.MaskDesc.make(per, N, S, n_ids, DEV)
+        ops.mask_build(desc.desc, B, Lq, b2, t2)
+        assert torch.equal(b1, b2) and torch.equal(t1, t2), fam
+
+
 # ------------------------------------------------------------------------------------------ row kernels
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("M,H", [(37, 128), (513, 768), (64, 1024), (10, 2048)])

@@ -233,6 +233,45 @@ def test_dropout_training_step_against_oracle_with_the_same_masks(golden_dir):
     assert float((g16 - g32).norm() / g32.norm()) < 3e-2
 
 
+def test_mask_descriptors_equal_materialised_masks(golden_dir):
+    """masks synthesised on the device from {family, n2, vl} give bit-identical outputs to the
+    reference-style int64 [B,L,L] input, for every family incl. the per-sample Mixed choice."""
+    z, meta, cfg, P, b = load_case(golden_dir, "c1_s2s")
+    model = make_model(cfg, P, torch.bfloat16)
+    N, S = meta["N"], meta["S"]
+    for fam in ("full", "s2s", "bar", "noncross", "1d", "mixed"):
+        per = ["s2s", "full", "full", "s2s"] if fam == "mixed" else fam
+        n_ids = torch.from_numpy(z["in_n_ids"])
+        if fam == "mixed":
+            mask = mv.data.mixed_mask(N, S, n_ids, [True, False, False, True])
+        else:
+            mask = mv.data.build_mask(fam, N, S, n_ids)
+        desc = mv.data.MaskDesc.make(per, N, S, n_ids)
+        with torch.no_grad():
+            a = fwd(model, dict(b, attn_mask=mask))
+            c = model(b["cls_tok"].to(DEV), b["input_txt"].to(DEV), desc, b["segment"].to(DEV),
+                      (b["img_feats"].to(DEV), b["img_pos"].to(DEV)), b["sep_tok"].to(DEV))
+        assert torch.equal(a[0], c[0]) and torch.equal(a[1], c[1]), fam
+
+
+def test_retrieval_head_with_1d_masks(golden_dir):
+    """CXRBertForRetrieval = enc + itm with the [B,L] mask branch (cxrbert_origin.py:76-77)."""
+    z, meta, cfg, P, b = load_case(golden_dir, "c1_1d")
+    for dtype, tol in ((torch.float32, FP32_TOL), (torch.bfloat16, BF16_TOL)):
+        r = mv.CXRBertForRetrieval(cfg_dict(cfg), None, dtype=dtype, device=DEV)
+        r.bert.load_state_dict(P)
+        r.eval()
+        assert b["attn_mask"].dim() == 2
+        with torch.no_grad():
+            itm = r(b["cls_tok"].to(DEV), b["input_txt"].to(DEV), b["attn_mask"].to(DEV), b["segment"].to(DEV),
+                    (b["img_feats"].to(DEV), b["img_pos"].to(DEV)), b["sep_tok"].to(DEV))
+            sc = r.score(b["cls_tok"].to(DEV), b["input_txt"].to(DEV), b["attn_mask"].to(DEV), b["segment"].to(DEV),
+                         (b["img_feats"].to(DEV), b["img_pos"].to(DEV)), b["sep_tok"].to(DEV))
+        assert float(np.abs(itm.float().cpu().numpy() - z["itm"]).max()) < tol
+        ref = torch.softmax(torch.from_numpy(z["itm"]), -1)[:, 1]
+        assert float((sc.cpu() - ref).abs().max()) < tol
+
+
 def test_half_batches_sum_to_full_batch_gradient():
     """Size-independent linearity property at BERT-base scale (bf16 MFMA path): the gradients of two
     half mini-batches, each normalised by the GLOBAL label / batch counts (what every DP rank
