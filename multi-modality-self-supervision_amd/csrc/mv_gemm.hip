@@ -476,6 +476,18 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_ring_kernel(GemmArgs p) {
       G2_STEP(s, fa0, fb0, fa1, fb1);
       if (s + 1 < nst) G2_STEP(s + 1, fa1, fb1, fa0, fb0);
     }
+  } else if (p.dbg & 96) {
+    // timing experiments only: 32 = no barrier, 64 = fragments read once (MFMA issue rate alone)
+    bf16x8 fa[8], fb[NJ];
+    G2_FRAGS_K(fa, fb, 0, 0);
+    for (int s = 0; s < nst; ++s) {
+      if (!(p.dbg & 32)) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        if (!(p.dbg & 64)) G2_FRAGS_K(fa, fb, s, ks);
+        G2_MMA(fa, fb);
+      }
+    }
   } else {
     for (int s = 0; s < nst; ++s) {
       G2_WAIT(min(nst - 1 - s, NSTAGE - 2));            // stage s landed

@@ -16,8 +16,8 @@ def bench(fn, reps=10):
     for _ in range(reps): fn()
     e1.record(); e1.synchronize()
     return e0.elapsed_time(e1)/reps*1e3
-for nj in (4,2):
-  for dbg,name in ((0,"full"),(1,"no C store"),(3,"no loads, no store"),(5,"loads only no store"),(13,"loads only no store, 128B lines"),(9, "no store, 128B lines (wrong data)")):
+for nj in (14,):
+  for dbg,name in ((19,"compute only lock-step"),(3+32,"compute only, no barrier"),(3+64,"MFMA only + barrier (no frag reads)"),(3+96,"MFMA only, no barrier")):
     ops.set_gemm_variant(2 | (dbg<<8), nj)
     t1=bench(lambda: ops.gemm(x,W1,oI,M=M,N=I,K=H,bias=b1,epi=EPI_BIAS))
     t2=bench(lambda: ops.gemm(xi,W2,oH,M=M,N=H,K=I,bias=bh,epi=EPI_BIAS))
