@@ -451,6 +451,83 @@ __global__ __launch_bounds__(256) void ce_kernel(const TL* __restrict__ logits, 
   }
 }
 
+// Vector form: every lane owns 4 consecutive columns per step (16-byte logit loads, 8/16-byte gradient stores).
+// Used when ld, ldd are multiples of 4 and the bases are 16-byte aligned (the MLM head's padded [R, Vp] buffers).
+template <typename TL, typename TD, int MAXV>
+__global__ __launch_bounds__(256) void ce_vec_kernel(const TL* __restrict__ logits, int ld, const int32_t* __restrict__ labels,
+                                                     int R, int V, float* __restrict__ out, TD* __restrict__ dlogits, int ldd,
+                                                     const float* __restrict__ gs_dev, float gs_host) {
+  __shared__ float smax[4];
+  __shared__ int sarg[4];
+  __shared__ float ssum[4];
+  const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wl = tid >> 6;
+  const int label = labels[row];
+  TD* drow = dlogits ? dlogits + (size_t)row * ldd : nullptr;
+  if (label < 0 || label >= V) {
+    if (drow) for (int c = tid * 4; c < ldd; c += 1024) st4<TD>(drow + c, (f32x4){0.f, 0.f, 0.f, 0.f});
+    return;
+  }
+  const TL* lr = logits + (size_t)row * ld;
+  f32x4 v[MAXV];
+  float mx = -INFINITY;
+  int am = 0x7fffffff;
+#pragma unroll
+  for (int n = 0; n < MAXV; ++n) {
+    const int c = (tid + 256 * n) * 4;
+    v[n] = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    if (c < V) {
+      f32x4 x = ld4<TL>(lr + c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (c + e >= V) x[e] = -INFINITY;                 // padding columns of the last vector
+        if (x[e] > mx) { mx = x[e]; am = c + e; }         // first maximum wins (torch.argmax tie rule)
+      }
+      v[n] = x;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float om = __shfl_xor(mx, o, 64);
+    const int oa = __shfl_xor(am, o, 64);
+    if (om > mx || (om == mx && oa < am)) { mx = om; am = oa; }
+  }
+  if (lane == 0) { smax[wl] = mx; sarg[wl] = am; }
+  __syncthreads();
+  mx = smax[0]; am = sarg[0];
+  for (int w = 1; w < 4; ++w) if (smax[w] > mx || (smax[w] == mx && sarg[w] < am)) { mx = smax[w]; am = sarg[w]; }
+  float s = 0.f;
+  const float mxl = mx * 1.4426950408889634f;
+#pragma unroll
+  for (int n = 0; n < MAXV; ++n) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[n][e] = fexp2(fmaf(v[n][e], 1.4426950408889634f, -mxl)); s += v[n][e]; }
+  }
+  s = wave_sum(s);
+  if (lane == 0) ssum[wl] = s;
+  __syncthreads();
+  s = ssum[0] + ssum[1] + ssum[2] + ssum[3];
+  if (tid == 0) {
+    const float xl = ldf<TL>(lr + label);
+    atomicAdd(out + 0, (mx + logf(s)) - xl);
+    atomicAdd(out + 1, 1.0f);
+    if (am == label) atomicAdd(out + 2, 1.0f);
+  }
+  if (drow) {
+    const float gs = gs_dev ? *gs_dev : gs_host;
+    const float inv = gs / s;
+#pragma unroll
+    for (int n = 0; n < MAXV; ++n) {
+      const int c = (tid + 256 * n) * 4;
+      if (c < ldd) {
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (c + e < V) ? v[n][e] * inv - ((c + e) == label ? gs : 0.f) : 0.f;
+        st4<TD>(drow + c, o);
+      }
+    }
+  }
+}
+
 extern "C" int mv_ce_fwd_bwd(const void* logits, int l_dtype, int ld, const int32_t* labels, int R, int V, float* out, void* dlogits,
                              int d_dtype, int ldd, const float* grad_scale_dev, float grad_scale_host, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
@@ -458,6 +535,19 @@ extern "C" int mv_ce_fwd_bwd(const void* logits, int l_dtype, int ld, const int3
   if (V > 256 * CE_MAXPER) return MV_E_SHAPE;
   if (dlogits && ldd < V) return MV_E_SHAPE;
   dim3 grid(R), block(256);
+  const bool vec_ok = ((ld & 3) == 0) && (!dlogits || (ldd & 3) == 0) && ((((uintptr_t)logits) & 15) == 0) &&
+                      (!dlogits || (((uintptr_t)dlogits) & 15) == 0) && V > 2048 && ldd <= 1024 * 32 && V <= 1024 * 32;
+  if (vec_ok) {
+#define CEV_LAUNCH(TL, TD) hipLaunchKernelGGL((ce_vec_kernel<TL, TD, 32>), grid, block, 0, stream, (const TL*)logits, ld, labels, R, V, out, (TD*)dlogits, ldd, grad_scale_dev, grad_scale_host)
+    if (l_dtype == MV_F32 && d_dtype == MV_F32) CEV_LAUNCH(float, float);
+    else if (l_dtype == MV_F32 && d_dtype == MV_BF16) CEV_LAUNCH(float, bf16_t);
+    else if (l_dtype == MV_BF16 && d_dtype == MV_BF16) CEV_LAUNCH(bf16_t, bf16_t);
+    else if (l_dtype == MV_BF16 && d_dtype == MV_F32) CEV_LAUNCH(bf16_t, float);
+    else return MV_E_DTYPE;
+#undef CEV_LAUNCH
+    MV_CHECK_LAUNCH();
+    return MV_OK;
+  }
 #define CE_LAUNCH(TL, TD)                                                                                              \
   do {                                                                                                                 \
     if (V <= 256 * 8) hipLaunchKernelGGL((ce_kernel<TL, TD, 8>), grid, block, 0, stream, (const TL*)logits, ld, labels, R, V, out, (TD*)dlogits, ldd, grad_scale_dev, grad_scale_host); \
