@@ -41,6 +41,12 @@ class MaskDesc:
     def dim(self):
         return 3
 
+    def __getitem__(self, idx):          # batch slicing, like a [B, ...] tensor
+        return MaskDesc(self.desc[idx].reshape(-1, 3), self.L)
+
+    def __len__(self):
+        return int(self.desc.shape[0])
+
     def to(self, device, *a, **k):
         return MaskDesc(self.desc.to(device), self.L)
 
