@@ -102,7 +102,11 @@ def time_dominant_kernel(eng, B, L):
     e1.synchronize()
     ms = e0.elapsed_time(e1) / reps
     fl = 2.0 * M * H * I
-    return dict(kernel="gemm_mfma_kernel<NT> 32768x3072x768 +bias+GELU", ms=ms, tflops=fl / ms / 1e9)
+    return dict(kernel="gemm_ring_kernel<NT, 256x256x64> 32768x3072x768 +bias+GELU (writes z and gelu(z))", ms=ms,
+                tflops=fl / ms / 1e9, algorithmic_flop=fl,
+                hbm_traffic_pmc_bytes=4.22e8,
+                traffic_note="FETCH_SIZE x2 + WRITE_SIZE of the same kernel with the bias-only epilogue (one bf16 output), "
+                             "profiles/r01_gemm_pmc.txt; the GELU epilogue writes a second 201 MB tensor")
 
 
 def main():
