@@ -216,18 +216,6 @@ __device__ __forceinline__ bf16x8 load_rowfrag_global(__amdgpu_buffer_rsrc_t rs,
   return __builtin_bit_cast(bf16x8, v);
 }
 
-// block-uniform: is K/Q tile `t` needed by the 128-row block starting at row tile `ta` (and ta+1)?
-__device__ __forceinline__ bool tile_needed_q(const uint8_t* info, int b, int T, int ta, int t) {
-  bool need = info[((size_t)b * T + ta) * T + t] != 0;
-  if (ta + 1 < T) need |= info[((size_t)b * T + ta + 1) * T + t] != 0;
-  return need;
-}
-__device__ __forceinline__ bool tile_needed_k(const uint8_t* info, int b, int T, int ka, int t) {
-  bool need = info[((size_t)b * T + t) * T + ka] != 0;
-  if (ka + 1 < T) need |= info[((size_t)b * T + t) * T + ka + 1] != 0;
-  return need;
-}
-
 // tile classes of the block's two 64-row tiles, fetched ONCE (lane t holds tile t) and turned into wave-uniform bit
 // masks: the K loop then walks set bits instead of issuing dependent global loads per tile
 struct TileMasks { unsigned long long need, w_nz, w_is1; };

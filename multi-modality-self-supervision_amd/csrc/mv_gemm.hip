@@ -101,7 +101,6 @@ __device__ __forceinline__ void epilogue4t(const GemmArgs& p, int m, int n, f32x
     st4<bf16_t>((bf16_t*)p.C + co, o);
   }
 }
-__device__ __forceinline__ void epilogue4(const GemmArgs& p, int m, int n, f32x4 v) { epilogue4_slow(p, m, n, v); }
 
 // run BODY(E) with the run-time epilogue selector turned into a compile-time constant
 #define MV_EPI_SWITCH(epi_, BODY)                          \
@@ -596,7 +595,7 @@ __global__ __launch_bounds__(256) void gemm_simple_kernel(GemmArgs p, int ta, in
     const int m = m0 + ty * 4 + i, n = n0 + tx * 4;
     f32x4 v = {acc[i][0], acc[i][1], acc[i][2], acc[i][3]};
     if (p.splitk > 1) store_partial4(p, split, m, n, v);
-    else epilogue4(p, m, n, v);
+    else epilogue4_slow(p, m, n, v);
   }
 }
 
@@ -609,7 +608,7 @@ __global__ void splitk_reduce_kernel(GemmArgs p) {
       f32x4 s = {0.f, 0.f, 0.f, 0.f};
       for (int k = 0; k < p.splitk; ++k) s += *(const f32x4*)(p.ws + k * mn + e);
       const int m = (int)(e / p.N), n = (int)(e - (size_t)m * p.N);
-      epilogue4(p, m, n, s);
+      epilogue4_slow(p, m, n, s);
     } else {
       for (int j = 0; j < 4 && e + j < mn; ++j) {
         float s = 0.f;

@@ -17,7 +17,7 @@ def bench(fn, reps=10):
     e1.record(); e1.synchronize()
     return e0.elapsed_time(e1)/reps*1e3
 for nj in (14,):
-  for dbg,name in ((19,"compute only lock-step"),(3+32,"compute only, no barrier"),(3+64,"MFMA only + barrier (no frag reads)"),(3+96,"MFMA only, no barrier")):
+  for dbg,name in ((0,"full"),(128+(1<<8),"desync 3.4us"),(128+(2<<8),"desync 6.8us"),(128+(3<<8),"desync 10us"),(128+(4<<8),"desync 13.6us"),(0,"full again")):
     ops.set_gemm_variant(2 | (dbg<<8), nj)
     t1=bench(lambda: ops.gemm(x,W1,oI,M=M,N=I,K=H,bias=b1,epi=EPI_BIAS))
     t2=bench(lambda: ops.gemm(xi,W2,oH,M=M,N=H,K=I,bias=bh,epi=EPI_BIAS))

@@ -115,3 +115,19 @@ def test_dp_buckets_tile_the_flat_buffer():
     assert r[order[0]][0] == 0 and r[order[-1]][1] == n
     assert all(r[a][1] == r[b][0] for a, b in zip(order, order[1:]))
     assert r["layer0"][1] - r["layer0"][0] == r["layer5"][1] - r["layer5"][0]
+
+
+def test_downstream_checkpoint_key_maps():
+    """the renames finetune.py:338-339 / generation_decode.py:385-388 apply, and their inverse."""
+    m = mv.CXRBERT(TINY, None, device="cpu")
+    sd = m.state_dict()
+    ft = mv.checkpoint.to_finetune_keys(sd)
+    assert "txt_embeddings.word_embeddings.weight" in ft and "cls.predictions.decoder.weight" in ft
+    assert "encoder.layer.0.attention.self.query.weight" in ft and "itm.linear.weight" in ft
+    assert not any(k.startswith(("enc.", "mlm.")) for k in ft)
+    back = mv.checkpoint.from_finetune_keys(ft)
+    assert set(back) == set(sd) and all(torch.equal(back[k], sd[k]) for k in sd)
+    dec = mv.checkpoint.to_decode_keys(ft)
+    assert "bert.txt_embeddings.word_embeddings.weight" in dec and "bert.encoder.layer.1.output.dense.bias" in dec
+    assert "bert.img_embeddings.img_embeddings.weight" in dec and "bert.pooler.dense.weight" in dec
+    assert "cls.predictions.bias" in dec
