@@ -302,3 +302,36 @@ def test_half_batches_sum_to_full_batch_gradient():
     rel = float((acc - g_full).norm() / g_full.norm())
     print("half+half vs full gradient, relative L2:", rel)
     assert torch.isfinite(g_full).all() and rel < 2e-2
+
+
+def test_trainer_mirror_runs_an_epoch_and_saves(tmp_path):
+    """CXRBERT_Trainer(args, train_dl, test_dl).train(epoch) / .save(epoch, path) as main_origin.py:57-62 drives it,
+    fed with the reference's 9-tuple batches (dataset_origin.py:181) on the host."""
+    from types import SimpleNamespace
+    V, B, N, S = 2048, 4, 6, 25
+    cfgd = dict(vocab_size=V, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=512,
+                max_position_embeddings=64)
+
+    def batches(seed0, n):
+        out = []
+        for i in range(n):
+            b = mv.data.synthetic_batch(V, B, N, S, "bar", seed=seed0 + i, device="cpu")
+            out.append((b["cls_tok"], b["input_txt"], b["txt_labels"], b["attn_mask"], (b["img_feats"], b["img_pos"]),
+                        b["segment"], b["is_aligned"], b["sep_tok"], torch.zeros(B)))
+        return out
+
+    args = SimpleNamespace(with_cuda=True, weight_load=False, bert_model="custom", lr=1e-3, log_freq=10, mlm_task=True,
+                           itm_task=True, cuda_devices=[0], dropout_prob=0.1)
+    logged = []
+    tr = mv.CXRBERT_Trainer(args, batches(1, 6) * 4, batches(100, 2), config=cfgd, dtype=torch.bfloat16,
+                            logger=lambda d, step: logged.append((step, d)))
+    r0 = tr.train(0)
+    r1 = tr.train(1)
+    assert {"avg_loss", "avg_mlm_loss", "avg_itm_loss", "itm_acc", "mlm_acc", "eval_avg_loss", "eval_mlm_loss", "eval_itm_loss",
+            "eval_itm_acc", "eval_mlm_acc"} <= set(r0)
+    assert np.isfinite(r0["avg_loss"]) and r1["avg_mlm_loss"] < r0["avg_mlm_loss"]        # it learns the 24 repeated batches
+    assert len(logged) == 4
+    tr.save(1, str(tmp_path))
+    m2 = mv.CXRBERT.from_pretrained(str(tmp_path / "1"), device=DEV)
+    a, c = tr.model.state_dict(), m2.state_dict()
+    assert all(torch.equal(a[k].cpu(), c[k].cpu()) for k in a)
