@@ -272,15 +272,16 @@ def test_retrieval_head_with_1d_masks(golden_dir):
         assert float((sc.cpu() - ref).abs().max()) < tol
 
 
-def test_half_batches_sum_to_full_batch_gradient():
-    """Size-independent linearity property at BERT-base scale (bf16 MFMA path): the gradients of two
-    half mini-batches, each normalised by the GLOBAL label / batch counts (what every DP rank
-    computes), sum to the gradient of the full mini-batch."""
+@pytest.mark.parametrize("B", [8, 64])
+def test_half_batches_sum_to_full_batch_gradient(B):
+    """Size-independent linearity property at BERT-base scale, up to BASELINE.json's full size (B = 64, L = 512,
+    bf16 MFMA path): the gradients of two half mini-batches, each normalised by the GLOBAL label / batch counts
+    (what every DP rank computes), sum to the gradient of the full mini-batch."""
     cfg = mv.ModelConfig()
     model = mv.CXRBERT(cfg, None, dtype=torch.bfloat16, device=DEV)
     model.reset_parameters(seed=3)
     model.eval()                   # linearity holds for a fixed function: dropout off
-    B, N, S = 8, 36, 473
+    N, S = 36, 473
     full = mv.data.synthetic_batch(cfg.vocab_size, B, N, S, "mixed", seed=77, device=DEV)
     ts = mv.TrainStep(model, lr=0.0)
     ts(full, train=True)
@@ -291,7 +292,7 @@ def test_half_batches_sum_to_full_batch_gradient():
     for h in range(2):
         sl = slice(h * B // 2, (h + 1) * B // 2)
         half = {k: (v[sl] if torch.is_tensor(v) and v.shape[:1] == (B,) else v) for k, v in full.items()
-                if k not in ("label_rows", "label_ids")}
+                if k not in ("label_rows", "label_ids", "attn_desc")}
         rows, ids = mv.data.label_index(half["txt_labels"])
         eng.flat_g.zero_()
         eng.encoder_forward(half["cls_tok"], half["input_txt"], half["attn_mask"], half["segment"], half["img_feats"],
@@ -335,3 +336,84 @@ def test_trainer_mirror_runs_an_epoch_and_saves(tmp_path):
     m2 = mv.CXRBERT.from_pretrained(str(tmp_path / "1"), device=DEV)
     a, c = tr.model.state_dict(), m2.state_dict()
     assert all(torch.equal(a[k].cpu(), c[k].cpu()) for k in a)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, FP32_TOL), (torch.bfloat16, BF16_TOL)])
+def test_reference_default_geometry_and_ragged_text_lengths(dtype, tol):
+    """main_origin.py's default shape (180 regions + 253 text -> L = 436, BAR mask; L is no multiple of any tile size)
+    with the extreme text lengths in one batch: no text at all (only [SEP]), one token, and the full 253 tokens.
+    Checked against the CPU oracle on the same inputs (forward logits + both losses + gradient of the fused step)."""
+    cfg = O.OracleConfig(vocab_size=1024, hidden=128, layers=2, heads=2, intermediate=512, max_pos=256)
+    N, S, B = 180, 253, 3
+    P = O.make_params(cfg, seed=31)
+    b = {k: torch.from_numpy(v) for k, v in synth.make_batch(cfg, B, N, S, "bar", seed=31).items()}
+    from oracle import data_oracle as Dd
+    for i, n_txt in enumerate((0, 1, S)):                      # overwrite the sampled lengths with the extremes
+        toks = [10 + (300 + 7 * t) % 1000 for t in range(n_txt)]
+        lab = [-100] * n_txt
+        if n_txt:
+            lab[0], toks[0] = toks[0], Dd.MASK
+        ids, labels, seg, n_ids = Dd.assemble_sample(toks, lab, N, S)
+        b["input_txt"][i], b["txt_labels"][i], b["segment"][i] = torch.from_numpy(ids), torch.from_numpy(labels), torch.from_numpy(seg)
+        b["attn_mask"][i] = torch.from_numpy(Dd.build_mask("bar", N, S, n_ids))
+    with torch.no_grad():
+        mlm_o, itm_o = O.forward(P, cfg, b["cls_tok"], b["input_txt"], b["attn_mask"], b["segment"], b["img_feats"],
+                                 b["img_pos"], b["sep_tok"])
+        ml_o, il_o = O.losses(mlm_o, itm_o, b["txt_labels"], b["is_aligned"])
+    model = make_model(cfg, P, dtype)
+    with torch.no_grad():
+        mlm, itm = fwd(model, b)
+    assert mlm.shape == (B, 436, cfg.vocab_size)
+    assert float((mlm.float().cpu() - mlm_o).abs().max()) < tol and float((itm.float().cpu() - itm_o).abs().max()) < tol
+    stats = mv.TrainStep(model, lr=0.0)(dict(b), train=True).cpu()
+    assert int(stats[1]) == 2                                   # sample 0 has no label at all
+    assert abs(float(stats[0] / stats[1]) - float(ml_o)) < tol and abs(float(stats[3] / stats[4]) - float(il_o)) < tol
+    assert bool(torch.isfinite(model.engine.flat_g).all())
+
+
+def test_single_sample_batch_and_repeatability():
+    """B = 1 (every per-batch reduction degenerates) and bit-repeatability of the forward on identical inputs."""
+    cfg = O.CONFIGS["c1"]
+    P = O.make_params(cfg, seed=8)
+    b = {k: torch.from_numpy(v) for k, v in synth.make_batch(cfg, 1, 16, 45, "s2s", seed=8).items()}
+    with torch.no_grad():
+        mlm_o, itm_o = O.forward(P, cfg, b["cls_tok"], b["input_txt"], b["attn_mask"], b["segment"], b["img_feats"],
+                                 b["img_pos"], b["sep_tok"])
+    model = make_model(cfg, P, torch.bfloat16)
+    with torch.no_grad():
+        a1 = fwd(model, b)
+        a2 = fwd(model, b)
+    assert torch.equal(a1[0], a2[0]) and torch.equal(a1[1], a2[1])
+    assert float((a1[0].float().cpu() - mlm_o).abs().max()) < BF16_TOL
+
+
+def test_full_size_step_is_finite_repeatable_and_masks_pack_exactly():
+    """BASELINE.json configs[1] at full size (B = 64, L = 512): mask packing bit-exact against numpy, forward
+    bit-repeatable, a training step with dropout finite, loss near ln(V) for random-init weights."""
+    from medvill_amd import hip_ops as ops
+    cfg = mv.ModelConfig()
+    model = mv.CXRBERT(cfg, None, dtype=torch.bfloat16, device=DEV)
+    model.reset_parameters(seed=4)
+    B, N, S = 64, 36, 473
+    L = N + S + 3
+    b = mv.data.synthetic_batch(cfg.vocab_size, B, N, S, "mixed", seed=9, device=DEV)
+    bits = torch.zeros((B, L, L // 32), dtype=torch.int32, device=DEV)
+    tinfo = torch.zeros((B, L // 64, L // 64), dtype=torch.uint8, device=DEV)
+    ops.mask_pack(b["attn_mask"], bits, tinfo)
+    m = b["attn_mask"].cpu().numpy() != 0
+    want = (m.reshape(B, L, L // 32, 32).astype(np.uint64) << np.arange(32, dtype=np.uint64)).sum(-1).astype(np.uint32)
+    assert np.array_equal(bits.cpu().numpy().view(np.uint32), want)
+    model.eval()
+    eng = model.engine
+    with torch.no_grad():
+        h1, p1 = eng.encoder_forward(b["cls_tok"], b["input_txt"], b["attn_desc"], b["segment"], b["img_feats"], b["img_pos"],
+                                     b["sep_tok"])
+        h1, p1 = h1.clone(), p1.clone()
+        h2, p2 = eng.encoder_forward(b["cls_tok"], b["input_txt"], b["attn_mask"], b["segment"], b["img_feats"], b["img_pos"],
+                                     b["sep_tok"])
+    assert torch.equal(h1, h2) and torch.equal(p1, p2)          # descriptors == matrices, and repeatable
+    model.train()
+    ts = mv.TrainStep(model, lr=1e-5)
+    st = ts(b, train=True).cpu()
+    assert bool(torch.isfinite(eng.flat_p).all()) and bool(torch.isfinite(eng.flat_g).all())
+    assert abs(float(st[0] / st[1]) - np.log(cfg.vocab_size)) < 0.5 and int(st[4]) == B
