@@ -124,12 +124,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs a torch.distributed launch with WORLD_SIZE={args.gpus} (got {world})")
+    # rehearsal hooks for a 1-GPU box: MV_DIST_BACKEND=gloo MV_SINGLE_DEVICE=1 run every rank on cuda:0 over gloo
+    if os.environ.get("MV_SINGLE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("MV_DIST_BACKEND", "nccl")          # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     import medvill_amd as mv
     c = CONFIGS[args.config]
