@@ -118,6 +118,30 @@ int mv_mask_pack(const int64_t* mask, int mask_ndim, int B, int L,
  * n2 = num_image_embeds + 2; vl = n2 + #text ids incl. [SEP].  Closed forms: SURVEY.md Appendix B.             */
 int mv_mask_build(const int32_t* desc, int B, int L, uint32_t* bits, uint8_t* tileinfo, void* stream);
 
+/* ---- on-device mini-batch assembly (MLM corruption, labels, descriptors) ---------------------------
+ * Replaces the per-sample python of data/dataset_origin.py:102-135 and CXRDataset.random_word (:183-209).
+ * mv_mlm_draws: the two random sources of random_word for every token, from a counter-based hash of `key`:
+ *   u   f32   [B,S]  stand-in for random.random(), on a 2^-24 grid in [0,1)
+ *   rnd int32 [B,S]  stand-in for random.randrange(vocab)
+ * mv_mlm_corrupt consumes draws (these or the caller's own) and raw, un-corrupted ids:
+ *   ids     int64 [B,S]   token ids; row b is valid for t < lengths[b] (1 <= lengths[b] <= S; out-of-range is clamped)
+ *   family  int32 [B]     attention-mask family per sample for `desc` (see mv_mask_build); NULL = 0 (full)
+ * outputs, in the reference's batch protocol (dataset_origin.py:181):
+ *   input_txt  int64 [B,T]  T = S+1: corrupted ids, [SEP]=102 at t = lengths[b], [PAD]=0 after
+ *   segment    int64 [B,T]  all 1
+ *   txt_labels int64 [B,L]  L = S+N+3: -100 except the selected text positions (offset N+2), which carry the original id
+ *   n_ids      int32 [B]    lengths[b] + 1
+ *   desc       int32 [B,3]  {family, N+2, N+2+n_ids} for mv_mask_build / the attention kernels (nullable)
+ *   counts     int32 [B]    labels per sample (scratch the index pass reads)
+ *   label_rows / label_ids int32 [>= B*S], n_labels int32 [1] (device): row-major compact index of the labelled
+ *                           positions (row = b*L + i) and their ids -- all three NULL to skip.
+ * Selection rule per valid token, evaluated in double like the python: u < 0.15 selects; then u/0.15 < 0.8 -> [MASK]=103,
+ * < 0.9 -> rnd, else unchanged; a sample with no selection gets token 0 masked and labelled (":204-207").        */
+int mv_mlm_draws(unsigned long long key, int B, int S, int vocab, float* u, int32_t* rnd, void* stream);
+int mv_mlm_corrupt(const int64_t* ids, const int32_t* lengths, const float* u, const int32_t* rnd, const int32_t* family,
+                   int B, int N, int S, int64_t* input_txt, int64_t* segment, int64_t* txt_labels, int32_t* n_ids,
+                   int32_t* desc, int32_t* counts, int32_t* label_rows, int32_t* label_ids, int32_t* n_labels, void* stream);
+
 /* ---- fused-mask multi-head attention --------------------------------------------------------
  * Replaces HF BertSelfAttention's scores/softmax/context (spec:
  * Downstream_task/report_generation_and_vqa/sc/pytorch_pretrained_bert/model.py:301-320):

@@ -32,6 +32,8 @@ PROTOTYPES = {
                 i32, f32, u64, vp],
     "mv_mask_pack": [vp, i32, i32, i32, vp, vp, vp],
     "mv_mask_build": [vp, i32, i32, vp, vp, vp],
+    "mv_mlm_draws": [u64, i32, i32, i32, vp, vp, vp],
+    "mv_mlm_corrupt": [vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "mv_attn_fwd": [i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, u64, vp],
     "mv_attn_bwd": [i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, u64, vp],
     "mv_layernorm_fwd": [i32, vp, i32, vp, vp, vp, vp, vp, i32, i32, f32, vp],

@@ -83,9 +83,27 @@ def mixed_mask(N: int, S: int, n_ids, choose_s2s, device="cpu"):
     return torch.where(sel, s2s, full)
 
 
+def assemble_batch(ids: torch.Tensor, lengths: torch.Tensor, N: int, vocab: int, key: int, family="full", draws=None) -> dict:
+    """Device-side sample assembly from RAW token ids (HIP kernels mv_mlm_draws / mv_mlm_corrupt): the MLM corruption
+    of random_word (dataset_origin.py:183-209), [SEP]/[PAD]/label/segment layout (:105-135), mask descriptors and the
+    labelled-row index.  ids int64 [B,S] on the GPU, valid for t < lengths[b].  `draws` = (u f32 [B,S], rnd int32 [B,S])
+    overrides the hash-generated random sources.  One host sync (the label count)."""
+    from . import hip_ops as ops
+    B, S = ids.shape
+    dev = ids.device
+    u, rnd = draws if draws is not None else ops.mlm_draws(key, B, S, vocab, dev)
+    fams = [family] * B if isinstance(family, str) else list(family)
+    fam_t = torch.tensor([FAMILY_ID[f] for f in fams], dtype=torch.int32).to(dev)
+    out = ops.mlm_corrupt(ids, lengths.to(torch.int32), u, rnd, N, family=fam_t)
+    n = int(out["n_labels"].item())
+    return dict(input_txt=out["input_txt"], segment=out["segment"], txt_labels=out["txt_labels"], n_ids=out["n_ids"].to(torch.int64),
+                label_rows=out["label_rows"][:n], label_ids=out["label_ids"][:n], attn_desc=MaskDesc(out["desc"], S + N + 3))
+
+
 def corrupt_tokens(ids: torch.Tensor, lengths: torch.Tensor, vocab: int, gen: torch.Generator):
-    """Vectorised random_word: ids [B,S] (valid for t < lengths[b]).  Returns (ids', labels) with
-    labels = original id where selected else -100; guarantees >= 1 label per sample."""
+    """Host-side (torch) vectorised random_word for CPU-only tooling and tests; the GPU path is `assemble_batch`.
+    ids [B,S] (valid for t < lengths[b]).  Returns (ids', labels) with labels = original id where selected
+    else -100; guarantees >= 1 label per sample."""
     B, S = ids.shape
     dev = ids.device
     t = torch.arange(S, device=dev).view(1, S)
@@ -116,15 +134,21 @@ def synthetic_batch(vocab: int, B: int, N: int, S: int, family: str, seed: int, 
     lo = 1000 if vocab > 2000 else 200
     lengths = torch.randint((S + 1) // 2, S + 1, (B,), generator=gen, device=dev)
     ids = torch.randint(lo, vocab, (B, S), generator=gen, device=dev)
-    ids_c, lab = corrupt_tokens(ids, lengths, vocab, gen)
-    t = torch.arange(T, device=dev).view(1, T)
     n_ids = lengths + 1
-    txt = torch.zeros((B, T), dtype=torch.int64, device=dev)
-    txt[:, :S] = torch.where(t[:, :S] < lengths.view(B, 1), ids_c, torch.zeros_like(ids_c))
-    txt[torch.arange(B, device=dev), lengths] = SEP
-    labels = torch.full((B, L), -100, dtype=torch.int64, device=dev)
-    labels[:, N + 2:N + 2 + S] = torch.where(t[:, :S] < lengths.view(B, 1), lab, torch.full_like(lab, -100))
-    segment = torch.ones((B, T), dtype=torch.int64, device=dev)
+    if dev.type == "cuda":
+        asm = assemble_batch(ids, lengths, N, vocab, key=0x5EED0000 + seed)     # family descriptors are filled in below
+        txt, labels, segment = asm["input_txt"], asm["txt_labels"], asm["segment"]
+        rows, lids = asm["label_rows"], asm["label_ids"]
+    else:
+        ids_c, lab = corrupt_tokens(ids, lengths, vocab, gen)
+        t = torch.arange(T, device=dev).view(1, T)
+        txt = torch.zeros((B, T), dtype=torch.int64, device=dev)
+        txt[:, :S] = torch.where(t[:, :S] < lengths.view(B, 1), ids_c, torch.zeros_like(ids_c))
+        txt[torch.arange(B, device=dev), lengths] = SEP
+        labels = torch.full((B, L), -100, dtype=torch.int64, device=dev)
+        labels[:, N + 2:N + 2 + S] = torch.where(t[:, :S] < lengths.view(B, 1), lab, torch.full_like(lab, -100))
+        segment = torch.ones((B, T), dtype=torch.int64, device=dev)
+        rows, lids = label_index(labels)
     perm = torch.randperm(M_regions, generator=gen, device=dev)[:N]
     pos = torch.sort(perm)[0].view(1, N).expand(B, N).contiguous()
     feats = torch.randn((B, N, img_hidden), generator=gen, device=dev, dtype=torch.float32).to(feat_dtype)
@@ -137,12 +161,9 @@ def synthetic_batch(vocab: int, B: int, N: int, S: int, family: str, seed: int, 
         mask = build_mask(family, N, S, n_ids, dev)
         fams = family
     desc = MaskDesc.make(fams, N, S, n_ids.cpu(), dev)
-    flat = labels.view(-1)
-    rows = torch.nonzero(flat != -100).view(-1)
     return dict(cls_tok=torch.full((B, 1), CLS, dtype=torch.int64, device=dev), input_txt=txt, attn_mask=mask, segment=segment,
                 img_feats=feats, img_pos=pos, sep_tok=torch.full((B, 1), SEP, dtype=torch.int64, device=dev), txt_labels=labels,
-                is_aligned=is_aligned, n_ids=n_ids, label_rows=rows.to(torch.int32), label_ids=flat[rows].to(torch.int32),
-                attn_desc=desc)
+                is_aligned=is_aligned, n_ids=n_ids, label_rows=rows, label_ids=lids, attn_desc=desc)
 
 
 def label_index(txt_labels: torch.Tensor):

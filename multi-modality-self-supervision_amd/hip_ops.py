@@ -54,6 +54,47 @@ def mask_build(desc, B, Lq, bits, tileinfo):
     L.check(rc, "mv_mask_build")
 
 
+def mlm_draws(key, B, S, vocab, device):
+    """(u f32 [B,S], rnd int32 [B,S]): the counter-based stand-ins for random_word's two random sources."""
+    u = torch.empty((B, S), dtype=torch.float32, device=device)
+    rnd = torch.empty((B, S), dtype=torch.int32, device=device)
+    L.require_cuda(u)
+    rc = _lib().mv_mlm_draws(int(key) & 0xFFFFFFFFFFFFFFFF, B, S, vocab, L.ptr(u), L.ptr(rnd), L.stream_ptr())
+    L.check(rc, "mv_mlm_draws")
+    return u, rnd
+
+
+def mlm_corrupt(ids, lengths, u, rnd, N, family=None, want_index=True):
+    """On-device sample assembly (see mv_mlm_corrupt).  Returns a dict of device tensors; `n_labels` stays on the
+    device (one int32) so the caller decides when to synchronise."""
+    L.require_cuda(ids, lengths, u, rnd, family)
+    B, S = ids.shape
+    T, Lq = S + 1, S + N + 3
+    if ids.dtype != torch.int64 or lengths.dtype != torch.int32 or u.dtype != torch.float32 or rnd.dtype != torch.int32:
+        raise TypeError("mlm_corrupt: ids int64, lengths int32, u f32, rnd int32")
+    if tuple(lengths.shape) != (B,) or tuple(u.shape) != (B, S) or tuple(rnd.shape) != (B, S):
+        raise ValueError("mlm_corrupt: shape mismatch")
+    if family is not None and (family.dtype != torch.int32 or tuple(family.shape) != (B,)):
+        raise TypeError("mlm_corrupt: family must be int32 [B]")
+    dev = ids.device
+    out = dict(input_txt=torch.empty((B, T), dtype=torch.int64, device=dev),
+               segment=torch.empty((B, T), dtype=torch.int64, device=dev),
+               txt_labels=torch.empty((B, Lq), dtype=torch.int64, device=dev),
+               n_ids=torch.empty((B,), dtype=torch.int32, device=dev),
+               desc=torch.empty((B, 3), dtype=torch.int32, device=dev),
+               counts=torch.empty((B,), dtype=torch.int32, device=dev))
+    if want_index:
+        out["label_rows"] = torch.empty((B * S,), dtype=torch.int32, device=dev)
+        out["label_ids"] = torch.empty((B * S,), dtype=torch.int32, device=dev)
+        out["n_labels"] = torch.empty((1,), dtype=torch.int32, device=dev)
+    rc = _lib().mv_mlm_corrupt(L.ptr(ids.contiguous()), L.ptr(lengths.contiguous()), L.ptr(u.contiguous()), L.ptr(rnd.contiguous()),
+                               L.ptr(family), B, N, S, L.ptr(out["input_txt"]), L.ptr(out["segment"]), L.ptr(out["txt_labels"]),
+                               L.ptr(out["n_ids"]), L.ptr(out["desc"]), L.ptr(out["counts"]), L.ptr(out.get("label_rows")),
+                               L.ptr(out.get("label_ids")), L.ptr(out.get("n_labels")), L.stream_ptr())
+    L.check(rc, "mv_mlm_corrupt")
+    return out
+
+
 def attn_fwd(qkv, bits, tileinfo, ctx, lse, B, Lq, A, dh, p_drop=0.0, drop_key=0):
     rc = _lib().mv_attn_fwd(L.dt_of(qkv), L.ptr(qkv), L.ptr(bits), L.ptr(tileinfo), L.ptr(ctx), L.ptr(lse), B, Lq, A, dh,
                             float(p_drop), int(drop_key), L.stream_ptr())

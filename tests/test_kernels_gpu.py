@@ -281,6 +281,92 @@ def test_mask_build_from_descriptors_equals_packed_reference_matrices():
         assert torch.equal(b1, b2) and torch.equal(t1, t2), fam
 
 
+# ------------------------------------------------------------------------------------------ batch assembly
+class _Replay:
+    """python `random` stand-in replaying per-token draws: random() -> u[i] for token i, randrange() -> rnd[i]."""
+
+    def __init__(self, u, r):
+        self.u, self.r, self.i = u, r, -1
+
+    def random(self):
+        self.i += 1
+        return float(self.u[self.i])
+
+    def randrange(self, n):
+        return int(self.r[self.i])
+
+
+@pytest.mark.parametrize("B,N,S,V", [(7, 6, 40, 1024), (64, 36, 473, 30522), (3, 0, 5, 30522), (5, 100, 665, 30522)])
+def test_mlm_corrupt_equals_random_word_bit_exact(B, N, S, V):
+    """mv_mlm_corrupt against the numpy restatement of dataset_origin.py:102-135,183-209 on shared draws."""
+    from oracle import data_oracle as DO
+    g = torch.Generator().manual_seed(B * 1000 + S)
+    lengths = torch.randint(1, S + 1, (B,), generator=g).to(torch.int32)
+    lengths[0], lengths[-1] = 1, S
+    ids = torch.randint(1000 if V > 2000 else 200, V, (B, S), generator=g)
+    u, r = ops.mlm_draws(0xABCDEF12345 + B, B, S, V, DEV)
+    u = u.cpu()
+    # decision boundaries in the float32 neighbourhood of 0.15, 0.15*0.8 and 0.15*0.9, and one sample with no selection
+    edge = torch.tensor([0.15, 0.12, 0.135], dtype=torch.float64)
+    edge32 = torch.cat([edge.to(torch.float32), torch.nextafter(edge.to(torch.float32), torch.tensor(0.0)),
+                        torch.nextafter(edge.to(torch.float32), torch.tensor(1.0)), torch.tensor([0.0, 0.99999994])])
+    k = min(S, edge32.numel())
+    u[1 % B, :k] = edge32[:k]
+    u[2 % B] = 0.5                                          # nothing selected -> token 0 forced
+    fam = torch.tensor([b % 5 for b in range(B)], dtype=torch.int32)
+    out = ops.mlm_corrupt(ids.to(DEV), lengths.to(DEV), u.to(DEV), r, N, family=fam.to(DEV))
+    torch.cuda.synchronize()
+    r = r.cpu()
+    n_tot, rows_ref, ids_ref = 0, [], []
+    Lq = S + N + 3
+    for b in range(B):
+        n = int(lengths[b])
+        toks, labs = DO.random_word(ids[b, :n].tolist(), _Replay(u[b].numpy(), r[b].numpy()), V)
+        t_ref, l_ref, s_ref, n_ids = DO.assemble_sample(toks, labs, N, S)
+        assert np.array_equal(out["input_txt"][b].cpu().numpy(), t_ref), b
+        assert np.array_equal(out["txt_labels"][b].cpu().numpy(), l_ref), b
+        assert np.array_equal(out["segment"][b].cpu().numpy(), s_ref), b
+        assert int(out["n_ids"][b]) == n_ids
+        assert out["desc"][b].tolist() == [int(fam[b]), N + 2, N + 2 + n_ids]
+        nz = np.nonzero(l_ref != -100)[0]
+        assert int(out["counts"][b]) == len(nz) >= 1
+        rows_ref += [b * Lq + int(i) for i in nz]
+        ids_ref += [int(l_ref[i]) for i in nz]
+        n_tot += len(nz)
+    assert int(out["n_labels"]) == n_tot
+    assert out["label_rows"][:n_tot].tolist() == rows_ref and out["label_ids"][:n_tot].tolist() == ids_ref
+
+
+def test_mlm_draws_are_counter_based_and_well_distributed():
+    B, S, V = 64, 473, 30522
+    u1, r1 = ops.mlm_draws(11, B, S, V, DEV)
+    u2, r2 = ops.mlm_draws(11, B, S, V, DEV)
+    u3, r3 = ops.mlm_draws(12, B, S, V, DEV)
+    assert torch.equal(u1, u2) and torch.equal(r1, r2) and not torch.equal(u1, u3) and not torch.equal(r1, r3)
+    assert float(u1.min()) >= 0.0 and float(u1.max()) < 1.0 and int(r1.min()) >= 0 and int(r1.max()) < V
+    n = B * S
+    assert abs(float((u1 < 0.15).float().mean()) - 0.15) < 4 * math.sqrt(0.15 * 0.85 / n)
+    assert abs(float(u1.mean()) - 0.5) < 4 * math.sqrt(1 / 12 / n) and abs(float(r1.float().mean()) / V - 0.5) < 0.02
+    # a prefix of a larger batch is the same stream (index = b*S + t only through the linear counter)
+    u4, _ = ops.mlm_draws(11, 2 * B, S, V, DEV)
+    assert torch.equal(u4[:B], u1)
+
+
+def test_assemble_batch_feeds_the_fused_step_contract():
+    """data.assemble_batch output == label_index / MaskDesc.make on the same tensors (host restatements)."""
+    B, N, S, V = 9, 6, 40, 1024
+    g = torch.Generator().manual_seed(3)
+    lengths = torch.randint(1, S + 1, (B,), generator=g)
+    ids = torch.randint(200, V, (B, S), generator=g)
+    fams = ["full", "s2s", "bar", "noncross", "full", "s2s", "s2s", "full", "bar"]
+    a = D.assemble_batch(ids.to(DEV), lengths.to(DEV), N, V, key=99, family=fams)
+    rows, lids = D.label_index(a["txt_labels"])
+    assert torch.equal(rows, a["label_rows"]) and torch.equal(lids, a["label_ids"])
+    want = D.MaskDesc.make(fams, N, S, lengths + 1, DEV)
+    assert torch.equal(want.desc, a["attn_desc"].desc) and a["attn_desc"].L == S + N + 3
+    assert torch.equal(a["n_ids"].cpu(), lengths + 1)
+
+
 # ------------------------------------------------------------------------------------------ row kernels
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("M,H", [(37, 128), (513, 768), (64, 1024), (10, 2048)])
