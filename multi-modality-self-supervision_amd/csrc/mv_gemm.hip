@@ -102,6 +102,50 @@ __device__ __forceinline__ void epilogue4t(const GemmArgs& p, int m, int n, f32x
   }
 }
 
+// The same fast path with its global loads taken out: bias (b4, one load per tile: a lane keeps its 4 columns for all
+// rows) and the residual operand (r4) are fetched by the caller AHEAD of the stores of the previous rows.  gfx9 retires
+// loads and stores through one in-order counter (vmcnt), so a load issued after a store cannot be waited for without
+// waiting for that store's round trip to L2 as well; with the loads one row-group ahead, the stores stream out
+// back-to-back.
+template <int E>
+__device__ __forceinline__ f32x4 epi_load_res4(const GemmArgs& p, int m, int n) {
+  f32x4 r = {0.f, 0.f, 0.f, 0.f};
+  if (m >= p.M) return r;
+  if (E == MV_EPI_BIAS_RES || E == MV_EPI_DGELU || E == MV_EPI_RES) {
+    const size_t ro = (size_t)m * p.ldr + n;
+    r = (p.r_dtype == MV_F32) ? ld4<float>((const float*)p.R + ro) : ld4<bf16_t>((const bf16_t*)p.R + ro);
+  } else if (E == MV_EPI_NONE) {
+    if (p.c_dtype == MV_F32 && p.accumulate) r = *(const f32x4*)((const float*)p.C + (size_t)m * p.ldc + n);
+  }
+  return r;
+}
+template <int E>
+__device__ __forceinline__ void epilogue4v(const GemmArgs& p, int m, int n, f32x4 v, f32x4 b4, f32x4 r) {
+  if (m >= p.M) return;
+  const size_t co = (size_t)m * p.ldc + n;
+  f32x4 o = v;
+  if (E == MV_EPI_BIAS || E == MV_EPI_BIAS_GELU || E == MV_EPI_BIAS_RES || E == MV_EPI_BIAS_TANH) o += b4;
+  if (E == MV_EPI_BIAS_RES && p.drop.thr) o = mv_drop4(o, (size_t)m * p.N + n, p.drop);
+  if (E == MV_EPI_DGELU) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] *= dgelu_erf(r[i]);
+  } else if (E == MV_EPI_BIAS_RES || E == MV_EPI_RES || E == MV_EPI_NONE) {
+    o += r;
+  }
+  if (E == MV_EPI_BIAS_TANH) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = tanhf(o[i]);
+  }
+  if (E == MV_EPI_BIAS_GELU) {
+    const size_t c2 = (size_t)m * p.ldc2 + n;
+    if (p.c_dtype == MV_F32) st4<float>((float*)p.C2 + c2, o); else st4<bf16_t>((bf16_t*)p.C2 + c2, o);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = gelu_erf(o[i]);
+  }
+  if (p.c_dtype == MV_F32) st4<float>((float*)p.C + co, o);
+  else st4<bf16_t>((bf16_t*)p.C + co, o);
+}
+
 // run BODY(E) with the run-time epilogue selector turned into a compile-time constant
 #define MV_EPI_SWITCH(epi_, BODY)                          \
   switch (epi_) {                                          \
@@ -274,10 +318,35 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmArgs p) {
       for (int j = 0; j < 4; ++j) store_partial4(p, split, m0 + wm + i * 16 + l15, n0 + wn + j * 16 + 4 * lq, acc[i][j]);
     return;
   }
+  // bias once per tile, residual rows one 16-row group ahead of the stores (see epilogue4v)
 #define EPI_BODY(E_)                                                                                          \
-  _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                               \
-  _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                               \
-      epilogue4t<E_>(p, m0 + wm + i * 16 + l15, n0 + wn + j * 16 + 4 * lq, acc[i][j]);
+  {                                                                                                           \
+    f32x4 b4[4], rc[4], rn[4];                                                                                \
+    bool fast[4];                                                                                             \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                           \
+      const int n = n0 + wn + j * 16 + 4 * lq;                                                                \
+      fast[j] = p.vec_ok && (p.N - n >= 4);                                                                   \
+      b4[j] = (f32x4){0.f, 0.f, 0.f, 0.f}; rc[j] = b4[j]; rn[j] = b4[j];                                      \
+      if (fast[j]) {                                                                                          \
+        if (E_ == MV_EPI_BIAS || E_ == MV_EPI_BIAS_GELU || E_ == MV_EPI_BIAS_RES || E_ == MV_EPI_BIAS_TANH)    \
+          b4[j] = *(const f32x4*)(p.bias + n);                                                                \
+        rc[j] = epi_load_res4<E_>(p, m0 + wm + l15, n);                                                       \
+      }                                                                                                       \
+    }                                                                                                         \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                           \
+      const int m = m0 + wm + i * 16 + l15;                                                                   \
+      if (i + 1 < 4) {                                                                                        \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                         \
+          if (fast[j]) rn[j] = epi_load_res4<E_>(p, m + 16, n0 + wn + j * 16 + 4 * lq);                       \
+      }                                                                                                       \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                         \
+        const int n = n0 + wn + j * 16 + 4 * lq;                                                              \
+        if (fast[j]) epilogue4v<E_>(p, m, n, acc[i][j], b4[j], rc[j]);                                        \
+        else epilogue4_slow(p, m, n, acc[i][j]);                                                              \
+      }                                                                                                       \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j) rc[j] = rn[j];                                            \
+    }                                                                                                         \
+  }
   MV_EPI_SWITCH(p.epi, EPI_BODY)
 #undef EPI_BODY
 }
@@ -357,9 +426,43 @@ __device__ __forceinline__ bf16x8 g2_frag(const char* tile, int base, int l15, i
   }
 }
 
+// Epilogue of the 256-row kernels, through LDS: an accumulator tile holds 4 columns x 16 rows per lane, which would
+// store as sixteen 32-byte fragments per instruction (measured: ~1 TB/s).  Each wave transposes 16 rows at a time
+// through its own 4.25-KiB scratch (272-B row pitch: conflict-free both ways) so that 16 lanes cover one full output
+// row: whole 128/256-byte lines per store.  Loads run one row-group ahead of the stores (see epilogue4v).
+// Expects in scope: p, acc, scr, split, m0, n0, wm, wn, l15, lq, rrow, c4, col_on, NJ.
+#define G2_EPI_BODY(E_)                                                                                        \
+  {                                                                                                            \
+    constexpr int EE = (E_) < 0 ? 0 : (E_);                                                                    \
+    const int ncol = n0 + wn + c4 * 4;                                                                         \
+    const bool lane_fast = ((E_) >= 0) && col_on && p.vec_ok && (p.N - ncol >= 4);                             \
+    f32x4 b4 = {0.f, 0.f, 0.f, 0.f}, rcur = {0.f, 0.f, 0.f, 0.f};                                              \
+    if (lane_fast) {                                                                                           \
+      if (EE == MV_EPI_BIAS || EE == MV_EPI_BIAS_GELU || EE == MV_EPI_BIAS_RES || EE == MV_EPI_BIAS_TANH)      \
+        b4 = *(const f32x4*)(p.bias + ncol);                                                                   \
+      rcur = epi_load_res4<EE>(p, m0 + wm + rrow, ncol);                                                       \
+    }                                                                                                          \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                            \
+      _Pragma("unroll") for (int j = 0; j < NJ; ++j) *(f32x4*)(scr + l15 * 272 + j * 64 + lq * 16) = acc[i][j]; \
+      _Pragma("unroll 1") for (int rr = 0; rr < 4; ++rr) {                                                     \
+        const int row = rr * 4 + rrow, mcur = m0 + wm + i * 16 + row;                                          \
+        const int fn = i * 4 + rr + 1;                                                                         \
+        f32x4 rnext = {0.f, 0.f, 0.f, 0.f};                                                                    \
+        if (lane_fast && fn < 32) rnext = epi_load_res4<EE>(p, m0 + wm + (fn >> 2) * 16 + (fn & 3) * 4 + rrow, ncol); \
+        const f32x4 v = *(const f32x4*)(scr + row * 272 + c4 * 16);                                            \
+        if (col_on) {                                                                                          \
+          if ((E_) < 0) store_partial4(p, split, mcur, ncol, v);                                               \
+          else if (lane_fast) epilogue4v<EE>(p, mcur, ncol, v, b4, rcur);                                      \
+          else epilogue4_slow(p, mcur, ncol, v);                                                               \
+        }                                                                                                      \
+        rcur = rnext;                                                                                          \
+      }                                                                                                        \
+    }                                                                                                          \
+  }
+
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <bool TA, bool TB, int NJ, int WN, int NSTAGE, int KS>
+template <bool TA, bool TB, int NJ, int WN, int NSTAGE, int KS, bool XA = false>
 __global__ __launch_bounds__(128 * WN, 2) void gemm_ring_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NW = 2 * WN;                      // waves per block
@@ -423,7 +526,7 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_ring_kernel(GemmArgs p) {
   // (The second fragment set does not fit in 256 registers next to the transposed-read addresses, so the kernels
   // with a contraction-major operand keep the simpler schedule: read the fragments after the barrier, then MFMA.)
   constexpr bool PF = !TA && !TB && KS == 1;
-  if (do_load) {
+  if (do_load && !XA) {
 #pragma unroll
     for (int s = 0; s < (PF ? NSTAGE : NSTAGE - 1); ++s)
       if (s < nst) G2_ISSUE(s);
@@ -463,7 +566,43 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_ring_kernel(GemmArgs p) {
     if (do_mma) G2_MMA(FA_, FB_);                                                                \
   } while (0)
 
-  if constexpr (PF) {
+  if constexpr (XA) {
+    // Asymmetric ring for 64-deep stages in the full 160 KiB of LDS: three A slots and two B slots.  With the plain
+    // two-stage ring a stage is requested one K-tile (~1.3 us of MFMAs) before it is needed, which is less than the
+    // ~1.8 us an operand stage takes to arrive under load -- every K-tile then ends in a wait.  Here the A operand
+    // (the big streaming one) is requested TWO K-tiles ahead and only the B half-stage keeps the one-tile lead.
+    // Issue order per K-tile is B(s+1) then A(s+2), so the wait for {A(s), B(s)} may leave A(s+1) outstanding.
+    static_assert(!XA || (NSTAGE == 2 && KS == 2), "XA: 64-deep stages, 3 A + 2 B slots");
+    constexpr int LPA = A_BYTES / 1024 / NW;
+    char* const baseB = smem + 3 * A_BYTES;
+#define XA_ISSUE_A(S_) g2_issue<TA, true, A_BYTES / 1024, NW, KS>(rsA, p.bytesA, p.lda, m0, p.M, G2_BM, kbeg + (S_) * BKS, kend, smem + ((S_) % 3) * A_BYTES, wid, lane)
+#define XA_ISSUE_B(S_) g2_issue<TB, BP512, B_BYTES / 1024, NW, KS>(rsB, p.bytesB, p.ldb, n0, p.N, BN, kbeg + (S_) * BKS, kend, baseB + ((S_) % 2) * B_BYTES, wid, lane)
+    if (nst > 0) { XA_ISSUE_B(0); XA_ISSUE_A(0); }
+    if (nst > 1) XA_ISSUE_A(1);
+    for (int s = 0; s < nst; ++s) {
+      if (s + 1 < nst) wait_vmcnt<LPA>(); else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      if (s + 1 < nst) XA_ISSUE_B(s + 1);
+      if (s + 2 < nst) XA_ISSUE_A(s + 2);
+      const char* tA = smem + (s % 3) * A_BYTES;
+      const char* tB = baseB + (s % 2) * B_BYTES;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        bf16x8 fa[8], fb[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) fb[j] = g2_frag<TB, BP512, KS>(tB, wn + j * 16, l15, lq, ks);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) fa[i] = g2_frag<TA, true, KS>(tA, wm + i * 16, l15, lq, ks);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+      }
+    }
+#undef XA_ISSUE_A
+#undef XA_ISSUE_B
+  } else if constexpr (PF) {
     bf16x8 fa0[8], fb0[NJ], fa1[8], fb1[NJ];
     if (nst > 0) {
       G2_WAIT(min(nst - 1, NSTAGE - 1));
@@ -526,21 +665,143 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_ring_kernel(GemmArgs p) {
   char* scr = smem + wid * 4608;
   const int rrow = lane >> 4, c4 = lane & 15;
   const bool col_on = (c4 * 4) < 16 * NJ;
-#define EPI_BODY(E_)                                                                                          \
-  _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                             \
-    _Pragma("unroll") for (int j = 0; j < NJ; ++j) *(f32x4*)(scr + l15 * 272 + j * 64 + lq * 16) = acc[i][j]; \
-    _Pragma("unroll 1") for (int rr = 0; rr < 4; ++rr) {                                                      \
-      const int row = rr * 4 + rrow;                                                                          \
-      const f32x4 v = *(const f32x4*)(scr + row * 272 + c4 * 16);                                             \
-      if (col_on) {                                                                                           \
-        if (E_ < 0) store_partial4(p, split, m0 + wm + i * 16 + row, n0 + wn + c4 * 4, v);                    \
-        else epilogue4t<(E_ < 0 ? 0 : E_)>(p, m0 + wm + i * 16 + row, n0 + wn + c4 * 4, v);                   \
-      }                                                                                                       \
-    }                                                                                                         \
+  if (p.splitk > 1) { G2_EPI_BODY(-1) return; }
+  MV_EPI_SWITCH(p.epi, G2_EPI_BODY)
+}
+
+// ------------------------------------------------------------------------------------------
+// Persistent form of the ring kernel with 64-deep stages: one block per CU walks its share of the (tile, K-slice)
+// units, and the operand ring never drains between them -- the first stage(s) of the next unit are issued during the
+// last K-tile of the current one and land while the epilogue runs.  The epilogue's stores are not waited for either:
+// the first wait of the next unit is a COUNTED vmcnt that only requires the ring stage (older than the stores) to be
+// complete (gfx9 vmcnt retires loads and stores in issue order), so a tile's 128 KiB of output drains to HBM under
+// the next tile's MFMAs instead of in a chip-wide burst at the end of every round of tiles.
+template <bool TA, bool TB, int NJ, int WN, int NSTAGE>
+__global__ __launch_bounds__(128 * WN, 1) void gemm_pring_kernel(GemmArgs p, int units, int tiles) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int KS = 2;
+  constexpr int NW = 2 * WN;
+  constexpr int BN = WN * 16 * NJ;
+  constexpr bool BP512 = BN > 128;
+  constexpr int BKS = G2_BK * KS;
+  constexpr int A_BYTES = 16384 * KS;
+  constexpr int B_BYTES = (BP512 ? 16384 : 8192) * KS;
+  constexpr int STAGE = A_BYTES + B_BYTES;
+  constexpr int LPS = STAGE / 1024 / NW;
+  constexpr int EPI_OPS = 28;                     // lower bound of the VMEM ops a wave issues in a full-tile epilogue (32 stores)
+  static_assert(NW * 4608 <= STAGE, "epilogue scratch must fit in one ring stage");
+  static_assert((NSTAGE - 2) * LPS + EPI_OPS < 64, "vmcnt is a 6-bit counter");
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, lq = lane >> 4;
+  const int wm = (wid / WN) * 128, wn = (wid % WN) * (16 * NJ);
+  const int G = gridDim.x;
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int tiles_m = (p.M + G2_BM - 1) / G2_BM;
+
+  // unit -> (tile origin, K-slice).  Units that run at the same time on one XCD (blocks b, b+8, ... share an L2) are
+  // neighbours in the grouped raster: 8 row-panels x consecutive column-panels.
+  auto decode = [&](int u, int& m0, int& n0, int& kbeg, int& kend, int& split) {
+    const int q = units >> 3, r = units & 7, xcd = u & 7, in = u >> 3;
+    const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + in;
+    split = v / tiles;
+    const int bid = v - split * tiles;
+    const int GM = 8;
+    const int per_group = GM * tiles_n;
+    const int group = bid / per_group, rem = bid - group * per_group;
+    const int gm = min(GM, tiles_m - group * GM);
+    m0 = (group * GM + rem % gm) * G2_BM;
+    n0 = (rem / gm) * BN;
+    kbeg = split * p.kchunk;
+    kend = min(p.K, kbeg + p.kchunk);
+  };
+
+  __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, p.bytesA, 0x00020000);
+  __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, p.bytesB, 0x00020000);
+
+  // issue cursor: runs NSTAGE-1 stages ahead of the compute cursor, across unit boundaries
+  int iu = blockIdx.x, is = 0, im0 = 0, in0 = 0, ikbeg = 0, ikend = 0, isplit = 0, inst = 0;
+  unsigned ifs = 0, cfs = 0;                      // flat stage counters (ring slot = counter % NSTAGE)
+  if (iu < units) { decode(iu, im0, in0, ikbeg, ikend, isplit); inst = (ikend - ikbeg + BKS - 1) / BKS; }
+  auto issue_one = [&]() {
+    if (iu >= units) return;
+    char* st = smem + (ifs % NSTAGE) * STAGE;
+    const int k0 = ikbeg + is * BKS;
+    g2_issue<TA, true, A_BYTES / 1024, NW, KS>(rsA, p.bytesA, p.lda, im0, p.M, G2_BM, k0, ikend, st, wid, lane);
+    g2_issue<TB, BP512, B_BYTES / 1024, NW, KS>(rsB, p.bytesB, p.ldb, in0, p.N, BN, k0, ikend, st + A_BYTES, wid, lane);
+    ++ifs;
+    if (++is == inst) {
+      iu += G; is = 0;
+      if (iu < units) { decode(iu, im0, in0, ikbeg, ikend, isplit); inst = (ikend - ikbeg + BKS - 1) / BKS; }
+    }
+  };
+#pragma unroll
+  for (int i = 0; i < NSTAGE - 1; ++i) issue_one();
+
+  int epi_ops = 0;                                // VMEM ops this wave is known to have issued after its last ring load
+  for (int cu = blockIdx.x; cu < units; cu += G) {
+    int m0, n0, kbeg, kend, split;
+    decode(cu, m0, n0, kbeg, kend, split);
+    const int nst = (kend - kbeg + BKS - 1) / BKS;
+    f32x4 acc[8][NJ];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int s = 0; s < nst; ++s) {
+      // stage cfs must have landed: everything older than the (ifs - cfs - 1) younger stages and, right after an
+      // epilogue, older than its stores
+      const int younger = (int)(ifs - cfs) - 1;
+      const bool after_epi = (s == 0) && epi_ops > 0;
+      if (after_epi) {
+        if (NSTAGE > 2 && younger >= 1) wait_vmcnt<(NSTAGE > 2 ? LPS : 0) + EPI_OPS>();
+        else wait_vmcnt<EPI_OPS>();
+      } else {
+        if (NSTAGE > 2 && younger >= 1) wait_vmcnt<(NSTAGE > 2 ? LPS : 0)>();
+        else wait_vmcnt<0>();
+      }
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      issue_one();                                // refills the slot everyone finished reading (or used as scratch)
+      const char* tA = smem + (cfs % NSTAGE) * STAGE;
+      const char* tB = tA + A_BYTES;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        bf16x8 fa[8], fb[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) fb[j] = g2_frag<TB, BP512, KS>(tB, wn + j * 16, l15, lq, ks);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) fa[i] = g2_frag<TA, true, KS>(tA, wm + i * 16, l15, lq, ks);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+      }
+      ++cfs;
+    }
+
+    if (p.dbg & 1) {
+      float t = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+      if (t == 123.456f) ((float*)p.C)[0] = t;
+      epi_ops = 0;
+      continue;
+    }
+    // epilogue through the ring slot of the stage just consumed (see gemm_ring_kernel): 16 rows at a time per wave
+    __builtin_amdgcn_s_barrier();
+    char* scr = smem + ((cfs + NSTAGE - 1) % NSTAGE) * STAGE + wid * 4608;
+    const int rrow = lane >> 4, c4 = lane & 15;
+    const bool col_on = (c4 * 4) < 16 * NJ;
+    if (p.splitk > 1) { G2_EPI_BODY(-1) }
+    else { MV_EPI_SWITCH(p.epi, G2_EPI_BODY) }
+    // whole tile inside the matrix and vector stores: every one of the 32 row-group stores above was issued
+    const bool full = (m0 + G2_BM <= p.M) && (n0 + BN <= p.N) && ((p.N & 3) == 0) && (p.splitk > 1 || p.vec_ok);
+    epi_ops = full ? EPI_OPS : 0;
   }
-  if (p.splitk > 1) { EPI_BODY(-1) return; }
-  MV_EPI_SWITCH(p.epi, EPI_BODY)
-#undef EPI_BODY
 }
 
 // ------------------------------------------------------------------------------------------
@@ -697,7 +958,9 @@ extern "C" int mv_gemm(int dtype, int ta, int tb, int M, int N, int K, const voi
                       r128 = (t128 * sk + 511) / 512 * 256;
       int variant = g_mv_gemm_nj;           // 4: 256x256, 3: 256x192, 2: 256x128
       if (variant == 0) {
-        variant = 14;                       // 256x256, 64-deep stages (whole 128-B lines per LDS-DMA row): best measured
+        // 256x256 with 64-deep stages (whole 128-B lines per LDS-DMA row): best measured.  Weight gradients (split-K
+        // units, f32 partial tiles) gain 5-8 % from the persistent form; y = x.W^T does not (profiles/r01_gemm_variants.txt)
+        variant = ta ? 24 : 14;
         (void)r256; (void)r192; (void)r128;
       }
       int kchunk = (int)((K + sk - 1) / sk);
@@ -707,22 +970,47 @@ extern "C" int mv_gemm(int dtype, int ta, int tb, int M, int N, int K, const voi
       // variants: 4 = 256x256 (32-deep stages x4), 3 = 256x192, 2 = 256x128 (x3, 2 blocks/CU),
       //           14 = 256x256 with 64-deep stages x2 (128-B lines), 15 = 256x192 likewise, 12 / 13 = 256x128 with
       //           64-deep stages x2 / x3
-      const int tiles = (int)((variant == 4 || variant == 14) ? t256 : ((variant == 3 || variant == 15) ? t192 : t128));
+      const int tiles = (int)((variant == 4 || variant == 14 || variant == 24 || variant == 34) ? t256 : ((variant == 3 || variant == 15) ? t192 : t128));
       dim3 grid(tiles, splitk);
-#define LAUNCH_RING(TA_, TB_, NJ_, WN_, NS_, KS_)                                                                    \
+      static int n_cu = 0;
+      if (n_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+        if (n_cu <= 0) n_cu = 256;
+      }
+#define LAUNCH_PRING(TA_, TB_, NJ_, WN_, NS_)                                                                        \
   do {                                                                                                               \
-    constexpr size_t shm = (size_t)(NS_) * (KS_) * (16384 + ((WN_) * 16 * (NJ_) > 128 ? 16384 : 8192));               \
+    constexpr size_t shm = (size_t)(NS_) * 2 * (16384 + ((WN_) * 16 * (NJ_) > 128 ? 16384 : 8192));                  \
     static bool attr_set = false;                                                                                    \
     if (!attr_set) {                                                                                                 \
-      (void)hipFuncSetAttribute((const void*)gemm_ring_kernel<TA_, TB_, NJ_, WN_, NS_, KS_>,                         \
+      (void)hipFuncSetAttribute((const void*)gemm_pring_kernel<TA_, TB_, NJ_, WN_, NS_>,                             \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);                               \
       attr_set = true;                                                                                               \
     }                                                                                                                \
-    hipLaunchKernelGGL((gemm_ring_kernel<TA_, TB_, NJ_, WN_, NS_, KS_>), grid, dim3(128 * (WN_)), shm, stream, p);    \
+    const int units = tiles * splitk;                                                                                \
+    hipLaunchKernelGGL((gemm_pring_kernel<TA_, TB_, NJ_, WN_, NS_>), dim3(units < n_cu ? units : n_cu),              \
+                       dim3(128 * (WN_)), shm, stream, p, units, tiles);                                             \
   } while (0)
+#define LAUNCH_RING_X(TA_, TB_, NJ_, WN_, NS_, KS_, XA_)                                                             \
+  do {                                                                                                               \
+    constexpr size_t shm = (size_t)(NS_) * (KS_) * (16384 + ((WN_) * 16 * (NJ_) > 128 ? 16384 : 8192)) +             \
+                           ((XA_) ? (size_t)16384 * (KS_) : 0);                                                      \
+    static bool attr_set = false;                                                                                    \
+    if (!attr_set) {                                                                                                 \
+      (void)hipFuncSetAttribute((const void*)gemm_ring_kernel<TA_, TB_, NJ_, WN_, NS_, KS_, XA_>,                    \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);                               \
+      attr_set = true;                                                                                               \
+    }                                                                                                                \
+    hipLaunchKernelGGL((gemm_ring_kernel<TA_, TB_, NJ_, WN_, NS_, KS_, XA_>), grid, dim3(128 * (WN_)), shm, stream, p); \
+  } while (0)
+#define LAUNCH_RING(TA_, TB_, NJ_, WN_, NS_, KS_) LAUNCH_RING_X(TA_, TB_, NJ_, WN_, NS_, KS_, false)
 #define LAUNCH_RING_V(TA_, TB_)                                  \
   do {                                                           \
-    if (variant == 4) LAUNCH_RING(TA_, TB_, 4, 4, 4, 1);         \
+    if (variant == 24) LAUNCH_PRING(TA_, TB_, 4, 4, 2);          \
+    else if (variant == 34) LAUNCH_RING_X(TA_, TB_, 4, 4, 2, 2, true); \
+    else if (variant == 22) LAUNCH_PRING(TA_, TB_, 4, 2, 3);     \
+    else if (variant == 4) LAUNCH_RING(TA_, TB_, 4, 4, 4, 1);    \
     else if (variant == 3) LAUNCH_RING(TA_, TB_, 3, 4, 4, 1);    \
     else if (variant == 14) LAUNCH_RING(TA_, TB_, 4, 4, 2, 2);   \
     else if (variant == 15) LAUNCH_RING(TA_, TB_, 3, 4, 2, 2);   \
@@ -736,6 +1024,8 @@ extern "C" int mv_gemm(int dtype, int ta, int tb, int M, int N, int K, const voi
       else LAUNCH_RING_V(true, false);
 #undef LAUNCH_RING_V
 #undef LAUNCH_RING
+#undef LAUNCH_RING_X
+#undef LAUNCH_PRING
     } else {
       if (splitk == 0) {
         const int tiles = ((M + GT_BM - 1) / GT_BM) * ((N + GT_BN - 1) / GT_BN);

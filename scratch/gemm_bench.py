@@ -18,12 +18,12 @@ def bench1(fn, reps=20):
     return e0.elapsed_time(e1) / reps
 def bench(name, fn, flops, reps=20):
     out = []
-    for force, nj in ((0, 0), (2, 4), (2, 14), (2, 15), (2, 12), (2, 13), (1, 0)):
+    for force, nj in ((0, 0), (2, 24), (2, 14), (2, 34), (2, 12), (2, 13), (1, 0)):
         ops.set_gemm_variant(force, nj)
         out.append(bench1(fn, reps))
     ops.set_gemm_variant(0, 0)
     ms = out[0]
-    print(f"{name:38s} auto {ms*1e3:7.1f} us {flops/ms/1e9:6.0f} TF/s | 256:{out[1]*1e3:5.0f} 256k64:{out[2]*1e3:5.0f} 192k64:{out[3]*1e3:5.0f} 128k64:{out[4]*1e3:5.0f} 128k64s3:{out[5]*1e3:5.0f} old128:{out[6]*1e3:5.0f}", flush=True)
+    print(f"{name:38s} auto {ms*1e3:7.1f} us {flops/ms/1e9:6.0f} TF/s | p256:{out[1]*1e3:5.0f} 256k64:{out[2]*1e3:5.0f} 3a2b:{out[3]*1e3:5.0f} 128k64:{out[4]*1e3:5.0f} 128k64s3:{out[5]*1e3:5.0f} old128:{out[6]*1e3:5.0f}", flush=True)
     return ms
 H, I = 768, 3072
 x = rnd(M, H); xi = rnd(M, I); x3 = rnd(M, 3*H)

@@ -41,10 +41,10 @@ GEMM_SHAPES = [(256, 256, 256), (130, 70, 200), (1024, 768, 768), (64, 2, 768), 
 
 
 VARIANT = {"mfma": (1, 0), "mfma256": (2, 4), "mfma192": (2, 3), "mfma128r": (2, 2), "mfma256k64": (2, 14), "mfma128k64": (2, 12), "mfma192k64": (2, 15),
-           "mfma128k64s3": (2, 13), "mfma_auto": (0, 0)}   # mv_set_gemm_variant(force, nj)
+           "mfma128k64s3": (2, 13), "pring256": (2, 24), "pring128": (2, 22), "ring3a2b": (2, 34), "mfma_auto": (0, 0)}   # mv_set_gemm_variant(force, nj)
 
 
-@pytest.mark.parametrize("impl", ["mfma", "mfma256", "mfma192", "mfma128r", "mfma256k64", "mfma128k64", "mfma128k64s3", "mfma192k64", "simple_bf16", "f32"])
+@pytest.mark.parametrize("impl", ["mfma", "mfma256", "mfma192", "mfma128r", "mfma256k64", "mfma128k64", "mfma128k64s3", "mfma192k64", "pring256", "pring128", "ring3a2b", "simple_bf16", "f32"])
 @pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 1), (1, 0)])
 @pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
 def test_gemm_layouts(impl, ta, tb, M, N, K):
@@ -74,7 +74,7 @@ def test_gemm_layouts(impl, ta, tb, M, N, K):
         ops.set_gemm_variant(0, 0)
 
 
-@pytest.mark.parametrize("impl", ["mfma", "mfma256", "mfma192", "mfma128r", "mfma256k64", "mfma128k64", "mfma128k64s3", "mfma192k64", "f32"])
+@pytest.mark.parametrize("impl", ["mfma", "mfma256", "mfma192", "mfma128r", "mfma256k64", "mfma128k64", "mfma128k64s3", "mfma192k64", "pring256", "pring128", "ring3a2b", "f32"])
 @pytest.mark.parametrize("epi", [EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RES, EPI_DGELU, EPI_RES, EPI_BIAS_TANH])
 @pytest.mark.parametrize("M,N,K,cdt", [(256, 384, 128, "bf16"), (200, 130, 72, "f32"), (128, 768, 768, "f32")])
 def test_gemm_epilogues(impl, epi, M, N, K, cdt):
@@ -109,7 +109,7 @@ def test_gemm_epilogues(impl, epi, M, N, K, cdt):
     assert relerr(c, ref) < (2e-5 if cd == torch.float32 else 1e-2)
 
 
-@pytest.mark.parametrize("impl", ["mfma", "mfma256", "mfma192", "mfma128r", "mfma256k64", "mfma128k64", "mfma128k64s3", "mfma192k64", "f32"])
+@pytest.mark.parametrize("impl", ["mfma", "mfma256", "mfma192", "mfma128r", "mfma256k64", "mfma128k64", "mfma128k64s3", "mfma192k64", "pring256", "pring128", "ring3a2b", "f32"])
 def test_gemm_splitk_and_accumulate(impl):
     dt = torch.float32 if impl == "f32" else torch.bfloat16
     Mt, No, Ko = 4096, 200, 136
@@ -139,6 +139,41 @@ def test_gemm_auto_dispatch_large(ta, tb, M, N, K):
     A = (a.t() if ta else a).double()
     Bm = (b if tb else b.t()).double()
     assert relerr(c, A @ Bm) < 2e-5 * math.sqrt(K)
+
+
+@pytest.mark.parametrize("impl", ["pring256", "pring128", "ring3a2b"])
+@pytest.mark.parametrize("ta,tb,M,N,K,epi", [(0, 0, 8200, 3000, 768, EPI_BIAS_GELU), (0, 0, 8192, 3072, 264, EPI_BIAS_RES),
+                                             (0, 1, 9000, 2304, 520, EPI_DGELU), (0, 0, 16384, 768, 3072, EPI_BIAS),
+                                             (1, 1, 768, 3072, 8192, EPI_NONE), (1, 1, 2304, 776, 4104, EPI_NONE),
+                                             (1, 0, 1000, 2048, 1032, EPI_RES)])
+def test_gemm_persistent_many_units_per_block(impl, ta, tb, M, N, K, epi):
+    """More (tile, K-slice) units than CUs: every block of the persistent kernel walks several units, with the ring
+    carried across them, ragged tiles at both edges and the fused epilogues / split-K partial stores in between."""
+    a = rnd((K, M) if ta else (M, K), torch.bfloat16, 21, 0.5)
+    b = rnd((K, N) if tb else (N, K), torch.bfloat16, 22, 0.5)
+    bias, r = rnd((N,), torch.float32, 23), rnd((M, N), torch.bfloat16, 24)
+    split = epi == EPI_NONE
+    cd = torch.float32 if split else torch.bfloat16
+    c, c2 = torch.zeros((M, N), dtype=cd, device=DEV), torch.zeros((M, N), dtype=cd, device=DEV)
+    ws = torch.empty(16 * M * N, dtype=torch.float32, device=DEV) if split else None
+    ops.set_gemm_variant(*VARIANT[impl])
+    try:
+        for _ in range(2):                       # twice: the second launch must not depend on state left in LDS / ws
+            ops.gemm(a, b, c, ta=bool(ta), tb=bool(tb), M=M, N=N, K=K, bias=bias, epi=epi, r=r, c2=c2, splitk=0 if split else 1, ws=ws)
+    finally:
+        ops.set_gemm_variant(0, 0)
+    y = (a.t() if ta else a).double() @ (b if tb else b.t()).double()
+    rr = r.double()
+    if epi == EPI_BIAS_GELU:
+        assert relerr(c2, y + bias) < 1e-2
+        ref = gelu(y + bias)
+    else:
+        ref = {EPI_BIAS: y + bias, EPI_BIAS_RES: y + bias + rr, EPI_DGELU: y * dgelu(rr), EPI_RES: y + rr, EPI_NONE: y}[epi]
+    assert relerr(c, ref) < (2e-5 * math.sqrt(K) if split else 1e-2)
+    # element-wise: a misplaced or stale tile would hide in a max-norm test of a smooth matrix; compare tile by tile
+    err = (c.double() - ref).abs()
+    tol = (2e-5 * math.sqrt(K) if split else 1e-2) * float(ref.abs().max())
+    assert float(err.max()) < tol
 
 
 def test_gemm_vocab_sized_tails():
