@@ -55,7 +55,10 @@ enum {
   MV_EPI_BIAS_RES = 3,  /* C = A.B + bias[n] + R[m,n]   (HF BertSelfOutput / BertOutput before LayerNorm) */
   MV_EPI_DGELU = 4,     /* C = (A.B) * gelu_erf'(R[m,n])   (backward of MV_EPI_BIAS_GELU; R = saved Z)  */
   MV_EPI_RES = 5,       /* C = A.B + R[m,n]             (backward: add the residual-branch gradient)    */
-  MV_EPI_BIAS_TANH = 6  /* C = tanh(A.B + bias)         HF BertPooler, cxrbert_origin.py:130            */
+  MV_EPI_BIAS_TANH = 6, /* C = tanh(A.B + bias)         HF BertPooler, cxrbert_origin.py:130            */
+  MV_EPI_BIAS_GELU_D = 7, /* Z = A.B + bias; C = gelu_erf(Z); C2 = gelu_erf'(Z): the derivative shares the forward's exp and
+                             reciprocal, so the backward GEMM only multiplies (MV_EPI_MUL) and Z itself is never stored */
+  MV_EPI_MUL = 8        /* C = (A.B) * R[m,n]           (backward of MV_EPI_BIAS_GELU_D; R = saved gelu')  */
 };
 
 /* implementation selector (test hook): 0 = auto (MFMA for bf16, VALU for f32), 1 = force the
@@ -242,6 +245,11 @@ int mv_dact(int dtype, int mode, const void* dy, const void* z, void* out, size_
  * to a leading dimension the MFMA GEMM accepts). */
 int mv_cast2d(const void* src, int src_dtype, long long lds, void* dst, int dst_dtype, long long ldd,
               int rows, int cols, void* stream);
+
+/* dst[c, r] = src[r, c] for r < rows, c < cols (leading dimensions lds >= cols, ldd >= rows; same dtype both sides).
+ * The engine keeps k-contiguous (transposed) bf16 copies of the FFN and QKV weights so that the input-gradient
+ * GEMMs dX = dY.W run in the same y = x.W'^T form as the forward. */
+int mv_transpose(int dtype, const void* src, long long lds, void* dst, long long ldd, int rows, int cols, void* stream);
 
 /* dst(dst_dtype) = src(src_dtype), n elements */
 int mv_cast(const void* src, int src_dtype, void* dst, int dst_dtype, size_t n, void* stream);

@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libmedvill_hip.so")
 
 MV_F32, MV_BF16 = 0, 1
-EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RES, EPI_DGELU, EPI_RES, EPI_BIAS_TANH = range(7)
+EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RES, EPI_DGELU, EPI_RES, EPI_BIAS_TANH, EPI_BIAS_GELU_D, EPI_MUL = range(9)
 _ERR = {-1: "MV_E_ARG (null pointer / bad size)", -2: "MV_E_SHAPE (unsupported shape or alignment)",
         -3: "MV_E_DTYPE", -4: "MV_E_WORKSPACE (workspace too small)"}
 
@@ -51,6 +51,7 @@ PROTOTYPES = {
     "mv_dact": [i32, i32, vp, vp, vp, sz, vp],
     "mv_cast2d": [vp, i32, i64, vp, i32, i64, i32, i32, vp],
     "mv_cast": [vp, i32, vp, i32, sz, vp],
+    "mv_transpose": [i32, vp, i64, vp, i64, i32, i32, vp],
     "mv_adamw_step": [vp, vp, vp, vp, vp, sz, f32, f32, f32, f32, f32, i32, i32, f32, vp],
 }
 _RESTYPE = {"mv_set_impl": None, "mv_set_gemm_variant": None, "mv_build_info": C.c_char_p}

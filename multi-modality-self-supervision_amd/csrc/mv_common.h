@@ -87,6 +87,21 @@ __device__ __forceinline__ float dgelu_erf(float z) {
   return fmaf(z * 0.39894228040143267794f, e, cdf);
 }
 
+// gelu(z) and gelu'(z) from one exponential and one reciprocal (forward epilogue MV_EPI_BIAS_GELU_D)
+__device__ __forceinline__ void gelu_erf_and_grad(float z, float& g, float& d) {
+  const float u = z * 0.70710678118654752440f, au = fabsf(u);
+  const float t = __frcp_rn(fmaf(0.3275911f, au, 1.0f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float e = __expf(-au * au);
+  const float erf_abs = 1.0f - p * t * e;
+  const float cdf = 0.5f * (1.0f + copysignf(erf_abs, u));
+  g = z * cdf;
+  d = fmaf(z * 0.39894228040143267794f, e, cdf);
+}
+
 // ---- dropout: counter-based mask, regenerated (never stored) in the backward kernels --------------------------
 // One 32-bit hash per group of 4 consecutive elements (linear index >> 2), one byte per element; an element is
 // dropped when its byte < thr, i.e. with probability thr/256 (p = 0.1 -> thr = 26 -> 0.1016; survivors are scaled by

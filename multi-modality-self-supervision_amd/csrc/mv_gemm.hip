@@ -41,11 +41,13 @@ __device__ __forceinline__ void epilogue4_slow(const GemmArgs& p, int m, int n, 
     float x = v[i];
     const int e = p.epi;
     float b = 0.f, r = 0.f;
-    if (e == MV_EPI_BIAS || e == MV_EPI_BIAS_GELU || e == MV_EPI_BIAS_RES || e == MV_EPI_BIAS_TANH) b = p.bias[n + i];
-    if (e == MV_EPI_BIAS_RES || e == MV_EPI_DGELU || e == MV_EPI_RES) r = ld_any(p.R, (size_t)m * p.ldr + n + i, p.r_dtype);
+    if (e == MV_EPI_BIAS || e == MV_EPI_BIAS_GELU || e == MV_EPI_BIAS_RES || e == MV_EPI_BIAS_TANH || e == MV_EPI_BIAS_GELU_D) b = p.bias[n + i];
+    if (e == MV_EPI_BIAS_RES || e == MV_EPI_DGELU || e == MV_EPI_RES || e == MV_EPI_MUL) r = ld_any(p.R, (size_t)m * p.ldr + n + i, p.r_dtype);
     switch (e) {
       case MV_EPI_BIAS: x += b; break;
       case MV_EPI_BIAS_GELU: x += b; break;
+      case MV_EPI_BIAS_GELU_D: x += b; break;
+      case MV_EPI_MUL: x *= r; break;
       case MV_EPI_BIAS_RES:
         x += b;
         if (p.drop.thr) x = mv_drop1(x, (size_t)m * p.N + n + i, p.drop);
@@ -60,49 +62,19 @@ __device__ __forceinline__ void epilogue4_slow(const GemmArgs& p, int m, int n, 
       st_any(p.C2, (size_t)m * p.ldc2 + n + i, p.c_dtype, x);
       x = gelu_erf(x);
     }
+    if (e == MV_EPI_BIAS_GELU_D) {
+      float g_, d_;
+      gelu_erf_and_grad(x, g_, d_);
+      st_any(p.C2, (size_t)m * p.ldc2 + n + i, p.c_dtype, d_);
+      x = g_;
+    }
     if (p.c_dtype == MV_F32 && p.accumulate) x += ((const float*)p.C)[co + i];
     st_any(p.C, co + i, p.c_dtype, x);
   }
 }
 
-// Fast path: compile-time epilogue, 16-byte bias / residual loads, 8- or 16-byte stores.
-template <int E>
-__device__ __forceinline__ void epilogue4t(const GemmArgs& p, int m, int n, f32x4 v) {
-  if (!p.vec_ok || p.N - n < 4) { epilogue4_slow(p, m, n, v); return; }
-  if (m >= p.M) return;
-  const size_t co = (size_t)m * p.ldc + n;
-  f32x4 o = v;
-  if (E == MV_EPI_BIAS || E == MV_EPI_BIAS_GELU || E == MV_EPI_BIAS_RES || E == MV_EPI_BIAS_TANH) o += *(const f32x4*)(p.bias + n);
-  if (E == MV_EPI_BIAS_RES && p.drop.thr) o = mv_drop4(o, (size_t)m * p.N + n, p.drop);
-  if (E == MV_EPI_BIAS_RES || E == MV_EPI_DGELU || E == MV_EPI_RES) {
-    const size_t ro = (size_t)m * p.ldr + n;
-    const f32x4 r = (p.r_dtype == MV_F32) ? ld4<float>((const float*)p.R + ro) : ld4<bf16_t>((const bf16_t*)p.R + ro);
-    if (E == MV_EPI_DGELU) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) o[i] *= dgelu_erf(r[i]);
-    } else {
-      o += r;
-    }
-  }
-  if (E == MV_EPI_BIAS_TANH) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) o[i] = tanhf(o[i]);
-  }
-  if (E == MV_EPI_BIAS_GELU) {
-    const size_t c2 = (size_t)m * p.ldc2 + n;
-    if (p.c_dtype == MV_F32) st4<float>((float*)p.C2 + c2, o); else st4<bf16_t>((bf16_t*)p.C2 + c2, o);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) o[i] = gelu_erf(o[i]);
-  }
-  if (p.c_dtype == MV_F32) {
-    if (E == MV_EPI_NONE && p.accumulate) o += *(const f32x4*)((const float*)p.C + co);
-    st4<float>((float*)p.C + co, o);
-  } else {
-    st4<bf16_t>((bf16_t*)p.C + co, o);
-  }
-}
-
-// The same fast path with its global loads taken out: bias (b4, one load per tile: a lane keeps its 4 columns for all
+// Fast path: compile-time epilogue, 16-byte bias / residual loads, 8- or 16-byte stores, with its global loads taken out
+// of the store stream: bias (b4, one load per tile: a lane keeps its 4 columns for all
 // rows) and the residual operand (r4) are fetched by the caller AHEAD of the stores of the previous rows.  gfx9 retires
 // loads and stores through one in-order counter (vmcnt), so a load issued after a store cannot be waited for without
 // waiting for that store's round trip to L2 as well; with the loads one row-group ahead, the stores stream out
@@ -111,7 +83,7 @@ template <int E>
 __device__ __forceinline__ f32x4 epi_load_res4(const GemmArgs& p, int m, int n) {
   f32x4 r = {0.f, 0.f, 0.f, 0.f};
   if (m >= p.M) return r;
-  if (E == MV_EPI_BIAS_RES || E == MV_EPI_DGELU || E == MV_EPI_RES) {
+  if (E == MV_EPI_BIAS_RES || E == MV_EPI_DGELU || E == MV_EPI_RES || E == MV_EPI_MUL) {
     const size_t ro = (size_t)m * p.ldr + n;
     r = (p.r_dtype == MV_F32) ? ld4<float>((const float*)p.R + ro) : ld4<bf16_t>((const bf16_t*)p.R + ro);
   } else if (E == MV_EPI_NONE) {
@@ -124,11 +96,13 @@ __device__ __forceinline__ void epilogue4v(const GemmArgs& p, int m, int n, f32x
   if (m >= p.M) return;
   const size_t co = (size_t)m * p.ldc + n;
   f32x4 o = v;
-  if (E == MV_EPI_BIAS || E == MV_EPI_BIAS_GELU || E == MV_EPI_BIAS_RES || E == MV_EPI_BIAS_TANH) o += b4;
+  if (E == MV_EPI_BIAS || E == MV_EPI_BIAS_GELU || E == MV_EPI_BIAS_RES || E == MV_EPI_BIAS_TANH || E == MV_EPI_BIAS_GELU_D) o += b4;
   if (E == MV_EPI_BIAS_RES && p.drop.thr) o = mv_drop4(o, (size_t)m * p.N + n, p.drop);
   if (E == MV_EPI_DGELU) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) o[i] *= dgelu_erf(r[i]);
+  } else if (E == MV_EPI_MUL) {
+    o *= r;
   } else if (E == MV_EPI_BIAS_RES || E == MV_EPI_RES || E == MV_EPI_NONE) {
     o += r;
   }
@@ -141,6 +115,13 @@ __device__ __forceinline__ void epilogue4v(const GemmArgs& p, int m, int n, f32x
     if (p.c_dtype == MV_F32) st4<float>((float*)p.C2 + c2, o); else st4<bf16_t>((bf16_t*)p.C2 + c2, o);
 #pragma unroll
     for (int i = 0; i < 4; ++i) o[i] = gelu_erf(o[i]);
+  }
+  if (E == MV_EPI_BIAS_GELU_D) {
+    f32x4 d;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { float g_, d_; gelu_erf_and_grad(o[i], g_, d_); o[i] = g_; d[i] = d_; }
+    const size_t c2 = (size_t)m * p.ldc2 + n;
+    if (p.c_dtype == MV_F32) st4<float>((float*)p.C2 + c2, d); else st4<bf16_t>((bf16_t*)p.C2 + c2, d);
   }
   if (p.c_dtype == MV_F32) st4<float>((float*)p.C + co, o);
   else st4<bf16_t>((bf16_t*)p.C + co, o);
@@ -155,6 +136,8 @@ __device__ __forceinline__ void epilogue4v(const GemmArgs& p, int m, int n, f32x
     case MV_EPI_DGELU: BODY(MV_EPI_DGELU); break;          \
     case MV_EPI_RES: BODY(MV_EPI_RES); break;              \
     case MV_EPI_BIAS_TANH: BODY(MV_EPI_BIAS_TANH); break;  \
+    case MV_EPI_BIAS_GELU_D: BODY(MV_EPI_BIAS_GELU_D); break; \
+    case MV_EPI_MUL: BODY(MV_EPI_MUL); break;              \
     default: BODY(MV_EPI_NONE); break;                     \
   }
 
@@ -328,7 +311,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmArgs p) {
       fast[j] = p.vec_ok && (p.N - n >= 4);                                                                   \
       b4[j] = (f32x4){0.f, 0.f, 0.f, 0.f}; rc[j] = b4[j]; rn[j] = b4[j];                                      \
       if (fast[j]) {                                                                                          \
-        if (E_ == MV_EPI_BIAS || E_ == MV_EPI_BIAS_GELU || E_ == MV_EPI_BIAS_RES || E_ == MV_EPI_BIAS_TANH)    \
+        if (E_ == MV_EPI_BIAS || E_ == MV_EPI_BIAS_GELU || E_ == MV_EPI_BIAS_RES || E_ == MV_EPI_BIAS_TANH || E_ == MV_EPI_BIAS_GELU_D)    \
           b4[j] = *(const f32x4*)(p.bias + n);                                                                \
         rc[j] = epi_load_res4<E_>(p, m0 + wm + l15, n);                                                       \
       }                                                                                                       \
@@ -431,38 +414,60 @@ __device__ __forceinline__ bf16x8 g2_frag(const char* tile, int base, int l15, i
 // through its own 4.25-KiB scratch (272-B row pitch: conflict-free both ways) so that 16 lanes cover one full output
 // row: whole 128/256-byte lines per store.  Loads run one row-group ahead of the stores (see epilogue4v).
 // Expects in scope: p, acc, scr, split, m0, n0, wm, wn, l15, lq, rrow, c4, col_on, NJ.
+#define G2_RG 4
 #define G2_EPI_BODY(E_)                                                                                        \
   {                                                                                                            \
     constexpr int EE = (E_) < 0 ? 0 : (E_);                                                                    \
+    constexpr bool HAS_R = (E_) == MV_EPI_BIAS_RES || (E_) == MV_EPI_RES || (E_) == MV_EPI_MUL || (E_) == MV_EPI_DGELU; \
     const int ncol = n0 + wn + c4 * 4;                                                                         \
     const bool lane_fast = ((E_) >= 0) && col_on && p.vec_ok && (p.N - ncol >= 4);                             \
-    f32x4 b4 = {0.f, 0.f, 0.f, 0.f}, rcur = {0.f, 0.f, 0.f, 0.f};                                              \
-    if (lane_fast) {                                                                                           \
-      if (EE == MV_EPI_BIAS || EE == MV_EPI_BIAS_GELU || EE == MV_EPI_BIAS_RES || EE == MV_EPI_BIAS_TANH)      \
-        b4 = *(const f32x4*)(p.bias + ncol);                                                                   \
-      rcur = epi_load_res4<EE>(p, m0 + wm + rrow, ncol);                                                       \
-    }                                                                                                          \
-    _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                            \
-      _Pragma("unroll") for (int j = 0; j < NJ; ++j) *(f32x4*)(scr + l15 * 272 + j * 64 + lq * 16) = acc[i][j]; \
-      _Pragma("unroll 1") for (int rr = 0; rr < 4; ++rr) {                                                     \
-        const int row = rr * 4 + rrow, mcur = m0 + wm + i * 16 + row;                                          \
-        const int fn = i * 4 + rr + 1;                                                                         \
-        f32x4 rnext = {0.f, 0.f, 0.f, 0.f};                                                                    \
-        if (lane_fast && fn < 32) rnext = epi_load_res4<EE>(p, m0 + wm + (fn >> 2) * 16 + (fn & 3) * 4 + rrow, ncol); \
-        const f32x4 v = *(const f32x4*)(scr + row * 272 + c4 * 16);                                            \
-        if (col_on) {                                                                                          \
-          if ((E_) < 0) store_partial4(p, split, mcur, ncol, v);                                               \
-          else if (lane_fast) epilogue4v<EE>(p, mcur, ncol, v, b4, rcur);                                      \
-          else epilogue4_slow(p, mcur, ncol, v);                                                               \
+    f32x4 b4 = {0.f, 0.f, 0.f, 0.f};                                                                           \
+    if (lane_fast && (EE == MV_EPI_BIAS || EE == MV_EPI_BIAS_GELU || EE == MV_EPI_BIAS_RES || EE == MV_EPI_BIAS_TANH || \
+                      EE == MV_EPI_BIAS_GELU_D))                                                               \
+      b4 = *(const f32x4*)(p.bias + ncol);                                                                     \
+    if (HAS_R && __all(lane_fast || !col_on)) {                                                                \
+      /* residual operand: a tile's worth comes from HBM, so G2_RG 16-row groups of row loads are kept in flight \
+         per wave; each slot is re-requested as soon as it has been consumed */                                \
+      f32x4 rb[4 * G2_RG];                                                                                     \
+      _Pragma("unroll") for (int t = 0; t < 4 * G2_RG; ++t) {                                                  \
+        rb[t] = (f32x4){0.f, 0.f, 0.f, 0.f};                                                                   \
+        if (col_on) rb[t] = epi_load_res4<EE>(p, m0 + wm + (t >> 2) * 16 + (t & 3) * 4 + rrow, ncol);          \
+      }                                                                                                        \
+      _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                          \
+        _Pragma("unroll") for (int j = 0; j < NJ; ++j) *(f32x4*)(scr + l15 * 272 + j * 64 + lq * 16) = acc[i][j]; \
+        _Pragma("unroll") for (int rr = 0; rr < 4; ++rr) {                                                     \
+          const int row = rr * 4 + rrow, mcur = m0 + wm + i * 16 + row;                                        \
+          const f32x4 v = *(const f32x4*)(scr + row * 272 + c4 * 16);                                          \
+          const f32x4 rc = rb[(i % G2_RG) * 4 + rr];                                                           \
+          if (i + G2_RG < 8 && col_on) rb[(i % G2_RG) * 4 + rr] = epi_load_res4<EE>(p, mcur + 16 * G2_RG, ncol); \
+          if (col_on) epilogue4v<EE>(p, mcur, ncol, v, b4, rc);                                                \
         }                                                                                                      \
-        rcur = rnext;                                                                                          \
+      }                                                                                                        \
+    } else {                                                                                                   \
+      f32x4 rcur = {0.f, 0.f, 0.f, 0.f};                                                                       \
+      if (lane_fast) rcur = epi_load_res4<EE>(p, m0 + wm + rrow, ncol);                                        \
+      _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                          \
+        _Pragma("unroll") for (int j = 0; j < NJ; ++j) *(f32x4*)(scr + l15 * 272 + j * 64 + lq * 16) = acc[i][j]; \
+        _Pragma("unroll 1") for (int rr = 0; rr < 4; ++rr) {                                                   \
+          const int row = rr * 4 + rrow, mcur = m0 + wm + i * 16 + row;                                        \
+          const int fn = i * 4 + rr + 1;                                                                       \
+          f32x4 rnext = {0.f, 0.f, 0.f, 0.f};                                                                  \
+          if (lane_fast && fn < 32) rnext = epi_load_res4<EE>(p, m0 + wm + (fn >> 2) * 16 + (fn & 3) * 4 + rrow, ncol); \
+          const f32x4 v = *(const f32x4*)(scr + row * 272 + c4 * 16);                                          \
+          if (col_on) {                                                                                        \
+            if ((E_) < 0) store_partial4(p, split, mcur, ncol, v);                                             \
+            else if (lane_fast) epilogue4v<EE>(p, mcur, ncol, v, b4, rcur);                                    \
+            else epilogue4_slow(p, mcur, ncol, v);                                                             \
+          }                                                                                                    \
+          rcur = rnext;                                                                                        \
+        }                                                                                                      \
       }                                                                                                        \
     }                                                                                                          \
   }
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <bool TA, bool TB, int NJ, int WN, int NSTAGE, int KS, bool XA = false>
+template <bool TA, bool TB, int NJ, int WN, int NSTAGE, int KS>
 __global__ __launch_bounds__(128 * WN, 2) void gemm_ring_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NW = 2 * WN;                      // waves per block
@@ -525,10 +530,9 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_ring_kernel(GemmArgs p) {
   // that buffer with stage s+NSTAGE.
   // (The second fragment set does not fit in 256 registers next to the transposed-read addresses, so the kernels
   // with a contraction-major operand keep the simpler schedule: read the fragments after the barrier, then MFMA.)
-  constexpr bool PF = !TA && !TB && KS == 1;
-  if (do_load && !XA) {
+  if (do_load) {
 #pragma unroll
-    for (int s = 0; s < (PF ? NSTAGE : NSTAGE - 1); ++s)
+    for (int s = 0; s < NSTAGE - 1; ++s)
       if (s < nst) G2_ISSUE(s);
   }
 #define G2_WAIT(YOUNGER_)                                           \
@@ -553,95 +557,32 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_ring_kernel(GemmArgs p) {
     _Pragma("unroll") for (int j = 0; j < NJ; ++j)                                               \
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FB_[j], FA_[i], acc[i][j], 0, 0, 0); \
   } while (0)
-#define G2_STEP(S_, FA_, FB_, FAN_, FBN_)                                                        \
-  do {                                                                                           \
-    if ((S_) + 1 < nst) {                                                                        \
-      G2_WAIT(min(nst - 2 - (S_), NSTAGE - 2));       /* stage S+1 landed (this wave's part) */  \
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* my fragment reads of stage S are done */ \
-      __builtin_amdgcn_s_barrier();                                                              \
-      __builtin_amdgcn_sched_barrier(0);                                                         \
-      if (do_load && (S_) + NSTAGE < nst) G2_ISSUE((S_) + NSTAGE);                               \
-      if (do_mma) G2_FRAGS(FAN_, FBN_, (S_) + 1);                                                \
-    }                                                                                            \
-    if (do_mma) G2_MMA(FA_, FB_);                                                                \
-  } while (0)
-
-  if constexpr (XA) {
-    // Asymmetric ring for 64-deep stages in the full 160 KiB of LDS: three A slots and two B slots.  With the plain
-    // two-stage ring a stage is requested one K-tile (~1.3 us of MFMAs) before it is needed, which is less than the
-    // ~1.8 us an operand stage takes to arrive under load -- every K-tile then ends in a wait.  Here the A operand
-    // (the big streaming one) is requested TWO K-tiles ahead and only the B half-stage keeps the one-tile lead.
-    // Issue order per K-tile is B(s+1) then A(s+2), so the wait for {A(s), B(s)} may leave A(s+1) outstanding.
-    static_assert(!XA || (NSTAGE == 2 && KS == 2), "XA: 64-deep stages, 3 A + 2 B slots");
-    constexpr int LPA = A_BYTES / 1024 / NW;
-    char* const baseB = smem + 3 * A_BYTES;
-#define XA_ISSUE_A(S_) g2_issue<TA, true, A_BYTES / 1024, NW, KS>(rsA, p.bytesA, p.lda, m0, p.M, G2_BM, kbeg + (S_) * BKS, kend, smem + ((S_) % 3) * A_BYTES, wid, lane)
-#define XA_ISSUE_B(S_) g2_issue<TB, BP512, B_BYTES / 1024, NW, KS>(rsB, p.bytesB, p.ldb, n0, p.N, BN, kbeg + (S_) * BKS, kend, baseB + ((S_) % 2) * B_BYTES, wid, lane)
-    if (nst > 0) { XA_ISSUE_B(0); XA_ISSUE_A(0); }
-    if (nst > 1) XA_ISSUE_A(1);
-    for (int s = 0; s < nst; ++s) {
-      if (s + 1 < nst) wait_vmcnt<LPA>(); else wait_vmcnt<0>();
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-      if (s + 1 < nst) XA_ISSUE_B(s + 1);
-      if (s + 2 < nst) XA_ISSUE_A(s + 2);
-      const char* tA = smem + (s % 3) * A_BYTES;
-      const char* tB = baseB + (s % 2) * B_BYTES;
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        bf16x8 fa[8], fb[NJ];
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) fb[j] = g2_frag<TB, BP512, KS>(tB, wn + j * 16, l15, lq, ks);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) fa[i] = g2_frag<TA, true, KS>(tA, wm + i * 16, l15, lq, ks);
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-          for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
-      }
-    }
-#undef XA_ISSUE_A
-#undef XA_ISSUE_B
-  } else if constexpr (PF) {
-    bf16x8 fa0[8], fb0[NJ], fa1[8], fb1[NJ];
-    if (nst > 0) {
-      G2_WAIT(min(nst - 1, NSTAGE - 1));
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-      if (do_mma) G2_FRAGS(fa0, fb0, 0);
-    }
-    for (int s = 0; s < nst; s += 2) {
-      G2_STEP(s, fa0, fb0, fa1, fb1);
-      if (s + 1 < nst) G2_STEP(s + 1, fa1, fb1, fa0, fb0);
-    }
-  } else if (p.dbg & 96) {
-    // timing experiments only: 32 = no barrier, 64 = fragments read once (MFMA issue rate alone)
-    bf16x8 fa[8], fb[NJ];
-    G2_FRAGS_K(fa, fb, 0, 0);
-    for (int s = 0; s < nst; ++s) {
-      if (!(p.dbg & 32)) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        if (!(p.dbg & 64)) G2_FRAGS_K(fa, fb, s, ks);
-        G2_MMA(fa, fb);
-      }
-    }
-  } else {
+  {
     for (int s = 0; s < nst; ++s) {
       G2_WAIT(min(nst - 1 - s, NSTAGE - 2));            // stage s landed
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
       if (do_load && s + NSTAGE - 1 < nst) G2_ISSUE(s + NSTAGE - 1);   // refills the buffer everyone finished reading
       if (!do_mma) continue;
+      if constexpr (KS == 2 && !TA && !TB) {
+        // all 24 fragment reads of the 64-deep stage are issued before its first MFMA: the MFMAs then wait on a
+        // counted lgkmcnt that only the first reads hold up, instead of a read-wait-MFMA ping-pong per 2 fragments
+        bf16x8 fa0[8], fb0[NJ], fa1[8], fb1[NJ];
+        G2_FRAGS_K(fa0, fb0, s, 0);
+        G2_FRAGS_K(fa1, fb1, s, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        G2_MMA(fa0, fb0);
+        G2_MMA(fa1, fb1);
+      } else {
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        bf16x8 fa[8], fb[NJ];
-        G2_FRAGS_K(fa, fb, s, ks);
-        G2_MMA(fa, fb);
+        for (int ks = 0; ks < KS; ++ks) {
+          bf16x8 fa[8], fb[NJ];
+          G2_FRAGS_K(fa, fb, s, ks);
+          G2_MMA(fa, fb);
+        }
       }
     }
   }
-#undef G2_STEP
 #undef G2_MMA
 #undef G2_FRAGS
 #undef G2_FRAGS_K
@@ -676,6 +617,8 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_ring_kernel(GemmArgs p) {
 // the first wait of the next unit is a COUNTED vmcnt that only requires the ring stage (older than the stores) to be
 // complete (gfx9 vmcnt retires loads and stores in issue order), so a tile's 128 KiB of output drains to HBM under
 // the next tile's MFMAs instead of in a chip-wide burst at the end of every round of tiles.
+#undef G2_RG
+#define G2_RG 2   // the persistent kernel keeps its issue cursor live across the epilogue: fewer registers to spare
 template <bool TA, bool TB, int NJ, int WN, int NSTAGE>
 __global__ __launch_bounds__(128 * WN, 1) void gemm_pring_kernel(GemmArgs p, int units, int tiles) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -898,12 +841,12 @@ extern "C" int mv_gemm(int dtype, int ta, int tb, int M, int N, int K, const voi
   if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) return MV_E_ARG;
   if (dtype != MV_F32 && dtype != MV_BF16) return MV_E_DTYPE;
   if (c_dtype != MV_F32 && c_dtype != MV_BF16) return MV_E_DTYPE;
-  if (epi < 0 || epi > MV_EPI_BIAS_TANH) return MV_E_ARG;
-  const bool need_bias = (epi == MV_EPI_BIAS || epi == MV_EPI_BIAS_GELU || epi == MV_EPI_BIAS_RES || epi == MV_EPI_BIAS_TANH);
-  const bool need_r = (epi == MV_EPI_BIAS_RES || epi == MV_EPI_DGELU || epi == MV_EPI_RES);
+  if (epi < 0 || epi > MV_EPI_MUL) return MV_E_ARG;
+  const bool need_bias = (epi == MV_EPI_BIAS || epi == MV_EPI_BIAS_GELU || epi == MV_EPI_BIAS_RES || epi == MV_EPI_BIAS_TANH || epi == MV_EPI_BIAS_GELU_D);
+  const bool need_r = (epi == MV_EPI_BIAS_RES || epi == MV_EPI_DGELU || epi == MV_EPI_RES || epi == MV_EPI_MUL);
   if (need_bias && !bias) return MV_E_ARG;
   if (need_r && (!R || (r_dtype != MV_F32 && r_dtype != MV_BF16))) return MV_E_ARG;
-  if (epi == MV_EPI_BIAS_GELU && !C2) return MV_E_ARG;
+  if ((epi == MV_EPI_BIAS_GELU || epi == MV_EPI_BIAS_GELU_D) && !C2) return MV_E_ARG;
   if (lda < (ta ? M : K) || ldb < (tb ? N : K) || ldc < N) return MV_E_SHAPE;
   if (need_r && ldr < N) return MV_E_SHAPE;
   if (splitk < 0) splitk = 1;
@@ -925,7 +868,7 @@ extern "C" int mv_gemm(int dtype, int ta, int tb, int M, int N, int K, const voi
   const size_t rsz = (r_dtype == MV_F32) ? 16 : 8;
   p.vec_ok = ((ldc & 3) == 0) && aligned_to(C, csz) && (!need_bias || aligned_to(bias, 16)) &&
              (!need_r || (((ldr & 3) == 0) && aligned_to(R, rsz))) &&
-             (epi != MV_EPI_BIAS_GELU || (((ldc2 & 3) == 0) && aligned_to(C2, csz)));
+             ((epi != MV_EPI_BIAS_GELU && epi != MV_EPI_BIAS_GELU_D) || (((ldc2 & 3) == 0) && aligned_to(C2, csz)));
   const bool mfma = (dtype == MV_BF16) && (g_mv_impl == 0);
   if (mfma) {
     if ((lda & 7) || (ldb & 7) || !aligned_to(A, 16) || !aligned_to(B, 16)) return MV_E_SHAPE;
@@ -941,7 +884,10 @@ extern "C" int mv_gemm(int dtype, int ta, int tb, int M, int N, int K, const voi
     // measured on the model's shapes (profiles/r01_gemm_variants.txt): the ring kernels win for y = x.W^T and
     // dW = dy^T.x, the 128x128 register-staged kernel for dx = dy.W
     // (ring kernel with 64-deep stages for wide outputs and for dW; 128x128 register-staged for N <= 1024 and dX)
-    const bool wide_nt = !ta && !tb && N >= 1024;
+    // (measured: the 256-row kernel also wins for narrow bf16 outputs once the contraction is long: da / dx in
+    //  y = x.W'^T form, 191 vs 208 us and 138 vs 148 us; not for f32 outputs, where the 128x128 kernel's 3 blocks per CU
+    //  hide the wider stores better)
+    const bool wide_nt = !ta && !tb && (N >= 1024 || (K >= 2048 && c_dtype == MV_BF16));
     const bool big = (g_mv_gemm_force == 2) || (g_mv_gemm_force == 0 && M >= 256 && N >= 128 && (K & 7) == 0 && (wide_nt || ta) &&
                                                (t128 >= 128 || (K >= 4096 && splitk != 1)));
     if (big) {
@@ -970,7 +916,7 @@ extern "C" int mv_gemm(int dtype, int ta, int tb, int M, int N, int K, const voi
       // variants: 4 = 256x256 (32-deep stages x4), 3 = 256x192, 2 = 256x128 (x3, 2 blocks/CU),
       //           14 = 256x256 with 64-deep stages x2 (128-B lines), 15 = 256x192 likewise, 12 / 13 = 256x128 with
       //           64-deep stages x2 / x3
-      const int tiles = (int)((variant == 4 || variant == 14 || variant == 24 || variant == 34) ? t256 : ((variant == 3 || variant == 15) ? t192 : t128));
+      const int tiles = (int)t256;
       dim3 grid(tiles, splitk);
       static int n_cu = 0;
       if (n_cu == 0) {
@@ -992,31 +938,21 @@ extern "C" int mv_gemm(int dtype, int ta, int tb, int M, int N, int K, const voi
     hipLaunchKernelGGL((gemm_pring_kernel<TA_, TB_, NJ_, WN_, NS_>), dim3(units < n_cu ? units : n_cu),              \
                        dim3(128 * (WN_)), shm, stream, p, units, tiles);                                             \
   } while (0)
-#define LAUNCH_RING_X(TA_, TB_, NJ_, WN_, NS_, KS_, XA_)                                                             \
+#define LAUNCH_RING(TA_, TB_, NJ_, WN_, NS_, KS_)                                                                    \
   do {                                                                                                               \
-    constexpr size_t shm = (size_t)(NS_) * (KS_) * (16384 + ((WN_) * 16 * (NJ_) > 128 ? 16384 : 8192)) +             \
-                           ((XA_) ? (size_t)16384 * (KS_) : 0);                                                      \
+    constexpr size_t shm = (size_t)(NS_) * (KS_) * (16384 + ((WN_) * 16 * (NJ_) > 128 ? 16384 : 8192));               \
     static bool attr_set = false;                                                                                    \
     if (!attr_set) {                                                                                                 \
-      (void)hipFuncSetAttribute((const void*)gemm_ring_kernel<TA_, TB_, NJ_, WN_, NS_, KS_, XA_>,                    \
+      (void)hipFuncSetAttribute((const void*)gemm_ring_kernel<TA_, TB_, NJ_, WN_, NS_, KS_>,                         \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);                               \
       attr_set = true;                                                                                               \
     }                                                                                                                \
-    hipLaunchKernelGGL((gemm_ring_kernel<TA_, TB_, NJ_, WN_, NS_, KS_, XA_>), grid, dim3(128 * (WN_)), shm, stream, p); \
+    hipLaunchKernelGGL((gemm_ring_kernel<TA_, TB_, NJ_, WN_, NS_, KS_>), grid, dim3(128 * (WN_)), shm, stream, p);    \
   } while (0)
-#define LAUNCH_RING(TA_, TB_, NJ_, WN_, NS_, KS_) LAUNCH_RING_X(TA_, TB_, NJ_, WN_, NS_, KS_, false)
 #define LAUNCH_RING_V(TA_, TB_)                                  \
   do {                                                           \
     if (variant == 24) LAUNCH_PRING(TA_, TB_, 4, 4, 2);          \
-    else if (variant == 34) LAUNCH_RING_X(TA_, TB_, 4, 4, 2, 2, true); \
-    else if (variant == 22) LAUNCH_PRING(TA_, TB_, 4, 2, 3);     \
-    else if (variant == 4) LAUNCH_RING(TA_, TB_, 4, 4, 4, 1);    \
-    else if (variant == 3) LAUNCH_RING(TA_, TB_, 3, 4, 4, 1);    \
-    else if (variant == 14) LAUNCH_RING(TA_, TB_, 4, 4, 2, 2);   \
-    else if (variant == 15) LAUNCH_RING(TA_, TB_, 3, 4, 2, 2);   \
-    else if (variant == 12) LAUNCH_RING(TA_, TB_, 4, 2, 2, 2);   \
-    else if (variant == 13) LAUNCH_RING(TA_, TB_, 4, 2, 3, 2);   \
-    else LAUNCH_RING(TA_, TB_, 4, 2, 3, 1);                      \
+    else LAUNCH_RING(TA_, TB_, 4, 4, 2, 2);                      \
   } while (0)
       if (!ta && !tb) LAUNCH_RING_V(false, false);
       else if (!ta && tb) LAUNCH_RING_V(false, true);
@@ -1024,7 +960,6 @@ extern "C" int mv_gemm(int dtype, int ta, int tb, int M, int N, int K, const voi
       else LAUNCH_RING_V(true, false);
 #undef LAUNCH_RING_V
 #undef LAUNCH_RING
-#undef LAUNCH_RING_X
 #undef LAUNCH_PRING
     } else {
       if (splitk == 0) {

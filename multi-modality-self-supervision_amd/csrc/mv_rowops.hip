@@ -779,6 +779,38 @@ extern "C" int mv_cast2d(const void* src, int src_dtype, long long lds_, void* d
   return MV_OK;
 }
 
+// dst[c, r] = src[r, c]: 64x64 tiles through LDS (65-element pitch), both sides coalesced.  Used once per optimizer step
+// to keep k-contiguous copies of the weights whose input-gradient GEMM would otherwise read them contraction-major.
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ src, long long lds_, T* __restrict__ dst, long long ldd,
+                                                        int rows, int cols) {
+  __shared__ T tile[64][65];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int r = r0 + ty * 16 + i, c = c0 + tx;
+    if (r < rows && c < cols) tile[ty * 16 + i][tx] = src[(size_t)r * lds_ + c];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int c = c0 + ty * 16 + i, r = r0 + tx;
+    if (r < rows && c < cols) dst[(size_t)c * ldd + r] = tile[tx][ty * 16 + i];
+  }
+}
+extern "C" int mv_transpose(int dtype, const void* src, long long lds_, void* dst, long long ldd, int rows, int cols, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!src || !dst || rows <= 0 || cols <= 0 || lds_ < cols || ldd < rows) return MV_E_ARG;
+  dim3 grid((cols + 63) / 64, (rows + 63) / 64), block(256);
+  if (grid.y > 65535) return MV_E_SHAPE;
+  if (dtype == MV_BF16) hipLaunchKernelGGL(transpose_kernel<bf16_t>, grid, block, 0, stream, (const bf16_t*)src, lds_, (bf16_t*)dst, ldd, rows, cols);
+  else if (dtype == MV_F32) hipLaunchKernelGGL(transpose_kernel<float>, grid, block, 0, stream, (const float*)src, lds_, (float*)dst, ldd, rows, cols);
+  else return MV_E_DTYPE;
+  MV_CHECK_LAUNCH();
+  return MV_OK;
+}
+
 template <typename TS, typename TDs>
 __global__ void cast_kernel(const TS* __restrict__ s, TDs* __restrict__ d, size_t n) {
   const size_t n4 = n / 4;

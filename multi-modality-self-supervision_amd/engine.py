@@ -23,7 +23,7 @@ from dataclasses import asdict, dataclass
 import torch
 
 from . import hip_ops as ops
-from ._lib import (EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RES, EPI_BIAS_TANH, EPI_DGELU, EPI_NONE, EPI_RES, MV_BF16, MV_F32)
+from ._lib import (EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_GELU_D, EPI_BIAS_RES, EPI_BIAS_TANH, EPI_MUL, EPI_NONE, EPI_RES, MV_BF16, MV_F32)
 
 
 @dataclass
@@ -125,6 +125,7 @@ class Engine:
         self.flat_v = None
         self.shadow = torch.zeros(self.n_flat, dtype=torch.bfloat16, device=self.device) if self.dt == MV_BF16 else None
         self.shadow_dirty = True
+        self.wT = {}                  # bf16 mode: k-contiguous (transposed) copies of the weights whose dX GEMM is large
         self._ws = {}
         self._gemm_ws = None
         self._side = None             # side HIP stream for the weight-gradient GEMMs of the backward
@@ -168,6 +169,8 @@ class Engine:
                 setattr(self, k, t.to(device))
         self.device = device
         self._ws.clear()
+        self.wT.clear()
+        self.shadow_dirty = True
         self._gemm_ws = None
         self._bind()
         return self
@@ -176,7 +179,24 @@ class Engine:
         """bf16 mode: refresh the bf16 copy the MFMA kernels read from the fp32 master weights."""
         if self.dt == MV_BF16:
             ops.cast(self.flat_p, self.shadow, self.n_flat)
+            self._refresh_transposed()
         self.shadow_dirty = False
+
+    def _refresh_transposed(self):
+        """W^T copies of the FFN and fused-QKV weights (bf16 mode): dX = dY.W then runs as y = x.W'^T with W' = W^T
+        k-contiguous, the form the 256-row LDS-DMA kernel is fastest in (profiles/r01_gemm_variants.txt)."""
+        if self.dt != MV_BF16:
+            return
+        H, I = self.cfg.hidden, self.cfg.intermediate
+        for l in range(self.cfg.layers):
+            p = f"enc.encoder.layer.{l}."
+            for key, W, (r, c) in ((p + "output.dense.weight", self.w[p + "output.dense.weight"], (H, I)),
+                                   (p + "intermediate.dense.weight", self.w[p + "intermediate.dense.weight"], (I, H)),
+                                   (p + "qkv", self.qkv_views(l)[0], (3 * H, H))):
+                t = self.wT.get(key)
+                if t is None or t.device != W.device:
+                    t = self.wT[key] = torch.empty((c, r), dtype=torch.bfloat16, device=W.device)
+                ops.transpose(W, t, r, c)
 
     def zero_grad(self):
         self.ensure_grad()
@@ -316,9 +336,11 @@ class Engine:
             ops.layernorm_fwd(pre1, self.p[p + "attention.output.LayerNorm.weight"], self.p[p + "attention.output.LayerNorm.bias"],
                               a1, a_["mean1"], a_["rstd1"], M, H, cfg.ln_eps)
             act = a_["i"] = self._buf(f"i{l}", (M, I), adt)
-            z = a_["z"] = self._buf(f"z{l}", (M, I), adt)
+            # the second output is gelu'(z), not z: the derivative shares the forward's exp / reciprocal, and the backward
+            # GEMM then only multiplies by it
+            dg = a_["dgelu"] = self._buf(f"dgelu{l}", (M, I), adt)
             ops.gemm(a1, self.w[p + "intermediate.dense.weight"], act, M=M, N=I, K=H, bias=self.p[p + "intermediate.dense.bias"],
-                     epi=EPI_BIAS_GELU, c2=z)
+                     epi=EPI_BIAS_GELU_D, c2=dg)
             pre2 = a_["pre2"] = self._buf(f"pre2_{l}", (M, H), f32)
             ops.gemm(act, self.w[p + "output.dense.weight"], pre2, M=M, N=H, K=I, bias=self.p[p + "output.dense.bias"],
                      epi=EPI_BIAS_RES, r=a1, p_drop=pd, drop_key=dk[(self.SITE_OUT2, l)])
@@ -484,6 +506,7 @@ class Engine:
         dh = H // A
         B, Lq, M, N, T = S["B"], S["L"], S["M"], S["N"], S["T"]
         adt, g = self.adt, self.g
+        bf = self.dt == MV_BF16 and bool(self.wT)      # input-gradient GEMMs in y = x.W'^T form over the transposed copies
         dy = S["dhidden"]
         main = torch.cuda.current_stream()
         if self._side is None:
@@ -527,12 +550,18 @@ class Engine:
             fork()
             with torch.cuda.stream(side):
                 self._dW(dproj2, a_["i"], g[p + "output.dense.weight"], H, I, M, lda=H, ldb=I)
-            ops.gemm(dproj2, self.w[p + "output.dense.weight"], dz, tb=True, M=M, N=I, K=H, epi=EPI_DGELU, r=a_["z"])
+            if bf:
+                ops.gemm(dproj2, self.wT[p + "output.dense.weight"], dz, M=M, N=I, K=H, epi=EPI_MUL, r=a_["dgelu"])
+            else:
+                ops.gemm(dproj2, self.w[p + "output.dense.weight"], dz, tb=True, M=M, N=I, K=H, epi=EPI_MUL, r=a_["dgelu"])
             fork()
             with torch.cuda.stream(side):
                 ops.colsum(dz, I, M, I, g[p + "intermediate.dense.bias"], accumulate=True)
                 self._dW(dz, a_["a"], g[p + "intermediate.dense.weight"], I, H, M, lda=I, ldb=H)
-            ops.gemm(dz, self.w[p + "intermediate.dense.weight"], da, tb=True, M=M, N=H, K=I, epi=EPI_RES, r=dpre2)
+            if bf:
+                ops.gemm(dz, self.wT[p + "intermediate.dense.weight"], da, M=M, N=H, K=I, epi=EPI_RES, r=dpre2)
+            else:
+                ops.gemm(dz, self.w[p + "intermediate.dense.weight"], da, tb=True, M=M, N=H, K=I, epi=EPI_RES, r=dpre2)
             # LN1 backward (+ bias grad of attention.output.dense)
             ops.layernorm_bwd(da, a_["pre1"], a_["mean1"], a_["rstd1"], self.p[p + "attention.output.LayerNorm.weight"], dpre1,
                               g[p + "attention.output.LayerNorm.weight"], g[p + "attention.output.LayerNorm.bias"],
@@ -551,7 +580,10 @@ class Engine:
                 self._dW(dqkv, a_["x"], gWqkv, 3 * H, H, M, lda=3 * H, ldb=H)
                 ev_layer = side_done()
             dx = dxb[l & 1]          # never the buffer dy currently lives in
-            ops.gemm(dqkv, Wqkv, dx, tb=True, M=M, N=H, K=3 * H, epi=EPI_RES, r=dpre1)
+            if bf:
+                ops.gemm(dqkv, self.wT[p + "qkv"], dx, M=M, N=H, K=3 * H, epi=EPI_RES, r=dpre1)
+            else:
+                ops.gemm(dqkv, Wqkv, dx, tb=True, M=M, N=H, K=3 * H, epi=EPI_RES, r=dpre1)
             dy = dx
             if bucket_hook:
                 # LayerNorm / bias gradients of the layer were written on the main stream, the weights on the side stream
@@ -576,4 +608,5 @@ class Engine:
         self.ensure_opt()
         ops.adamw_step(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.shadow, self.n_flat, lr, betas[0], betas[1], eps,
                        weight_decay, step, correct_bias, grad_scale)
+        self._refresh_transposed()
         self.shadow_dirty = False

@@ -5,7 +5,7 @@ from __future__ import annotations
 import torch
 
 from . import _lib as L
-from ._lib import (EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RES, EPI_BIAS_TANH, EPI_DGELU, EPI_NONE, EPI_RES, MV_BF16,  # noqa: F401
+from ._lib import (EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_GELU_D, EPI_BIAS_RES, EPI_BIAS_TANH, EPI_DGELU, EPI_MUL, EPI_NONE, EPI_RES, MV_BF16,  # noqa: F401
                    MV_F32)
 
 
@@ -175,6 +175,17 @@ def dact(mode, dy, z, out, n):
 def cast(src, dst, n):
     rc = _lib().mv_cast(L.ptr(src), L.dt_of(src), L.ptr(dst), L.dt_of(dst), n, L.stream_ptr())
     L.check(rc, "mv_cast")
+
+
+def transpose(src, dst, rows, cols, lds=None, ldd=None):
+    """dst[c, r] = src[r, c] (same dtype)."""
+    L.require_cuda(src, dst)
+    if src.dtype != dst.dtype:
+        raise TypeError("transpose: dtypes differ")
+    rc = _lib().mv_transpose(L.dt_of(src), L.ptr(src), lds if lds is not None else cols, L.ptr(dst), ldd if ldd is not None else rows,
+                             rows, cols, L.stream_ptr())
+    L.check(rc, "mv_transpose")
+    return dst
 
 
 def cast2d(src, lds, dst, ldd, rows, cols):
