@@ -104,9 +104,10 @@ def time_dominant_kernel(eng, B, L):
     fl = 2.0 * M * H * I
     return dict(kernel="gemm_ring_kernel<NT, 256x256x64> 32768x3072x768 +bias+GELU (writes gelu(z) and gelu'(z))", ms=ms,
                 tflops=fl / ms / 1e9, algorithmic_flop=fl,
-                hbm_traffic_pmc_bytes=4.22e8,
-                traffic_note="FETCH_SIZE x2 + WRITE_SIZE of the same kernel with the bias-only epilogue (one bf16 output), "
-                             "profiles/r01_gemm_pmc.txt; the GELU epilogue writes a second 201 MB tensor")
+                algorithmic_bytes=2.0 * (M * H + I * H + 2 * M * I),
+                hbm_traffic_pmc_bytes=6.24e8,
+                traffic_note="rocprofv3 --pmc, separate passes: FETCH_SIZE 110,887 KB x2 (gfx950 wide-read correction) = 221.8 MB "
+                             "+ WRITE_SIZE 393,216 KB = 402.7 MB per launch (profiles/r01_gemm_pmc.txt)")
 
 
 def main():
@@ -191,11 +192,15 @@ def main():
                        "mask": c["family"], "layers": cfg.layers, "hidden": cfg.hidden, "vocab": cfg.vocab_size,
                        "parallelism": f"dp{world}", "optimizer": "HF AdamW fused", "dropout": cfg.dropout,
                        "mlm_loss": float(st[0] / max(float(st[1]), 1.0)), "itm_loss": float(st[3] / max(float(st[4]), 1.0))},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_BF16_TFLOPS, "traffic": None,
-                         "flop_per_sample": f_step, "convention": "dense model FLOPs, backward = 2 x forward (SURVEY 8d)",
-                         "executed_tflops": value / world * f_exec / 1e12, "dominant_kernel": kern,
-                         "dominant_kernel_frac": kern["tflops"] / PEAK_BF16_TFLOPS},
+            # dominant kernel (the FFN-up GEMM, largest single share of the step): algorithmic FLOPs per launch / its
+            # average duration, HIP events around 20 launches on its own stream (time_dominant_kernel); traffic = HBM bytes
+            # per launch from rocprofv3 PMC passes of the same kernel (profiles/r01_gemm_pmc.txt)
+            "roofline": {"bound": "mfma", "achieved": kern["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": kern["tflops"] / PEAK_BF16_TFLOPS, "traffic": kern["hbm_traffic_pmc_bytes"],
+                         "kernel": kern,
+                         "step": {"achieved": achieved, "frac": achieved / PEAK_BF16_TFLOPS, "flop_per_sample": f_step,
+                                  "convention": "dense model FLOPs of the whole step, backward = 2 x forward (SURVEY 8d)",
+                                  "executed_tflops": value / world * f_exec / 1e12}},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.config)

@@ -17,6 +17,7 @@ Reference semantics implemented here (paths relative to the upstream repo):
 from __future__ import annotations
 
 import math
+import os
 from collections import OrderedDict
 from dataclasses import asdict, dataclass
 
@@ -511,7 +512,7 @@ class Engine:
         main = torch.cuda.current_stream()
         if self._side is None:
             self._side = torch.cuda.Stream(device=self.device)
-        side = self._side
+        side = main if os.environ.get("MV_SINGLE_STREAM") == "1" else self._side     # measurement switch
         side.wait_stream(main)              # the heads' gradients and the zeroed flat gradient are ordered before us
 
         def fork():
