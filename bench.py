@@ -179,10 +179,16 @@ def main():
         f_fwd = flops_fwd_per_sample(cfg.hidden, cfg.intermediate, cfg.vocab_size, cfg.img_hidden, cfg.layers, L, N)
         f_step = 3.0 * f_fwd
         achieved = value / world * f_step / 1e12
-        # executed FLOPs: the MLM head runs on the labelled rows only (unlabelled rows have zero loss and gradient)
+        # executed FLOPs: the MLM head runs on the labelled rows only (unlabelled rows have zero loss and gradient), and
+        # with padding removal the encoder runs on the valid rows only (positions after the text [SEP] are invisible to
+        # every valid query in the full / seq2seq families and carry no label)
         n_lab = float(st[1]) / B
-        f_head_dense = L * (2.0 * cfg.hidden ** 2 + 2.0 * cfg.hidden * cfg.vocab_size)
-        f_exec = 3.0 * (f_fwd - f_head_dense + n_lab * (2.0 * cfg.hidden ** 2 + 2.0 * cfg.hidden * cfg.vocab_size))
+        Hh, Ii, Vv = cfg.hidden, cfg.intermediate, cfg.vocab_size
+        packed = model.engine.S.get("cu") is not None
+        vls = torch.cat([b_["attn_desc"].host_desc()[:, 2] for b_ in batches]).double() if packed else torch.full((1,), float(L)).double()
+        rows_mean = float(vls.mean())
+        f_enc = cfg.layers * (rows_mean * (8.0 * Hh * Hh + 4.0 * Hh * Ii) + 4.0 * float((vls * vls).mean()) * Hh)
+        f_exec = 3.0 * (2.0 * N * cfg.img_hidden * Hh + f_enc + 2.0 * Hh * Hh + n_lab * (2.0 * Hh * Hh + 2.0 * Hh * Vv) + 4.0 * Hh)
         kern = time_dominant_kernel(model.engine, B, L)
         out = {
             "metric": "image-text pairs/sec pretraining step, BERT-base seq512", "value": value, "unit": "pairs/s",
@@ -191,6 +197,8 @@ def main():
             "config": {"workload": c["name"], "per_gpu_batch": B, "global_batch": B * world, "seq_len": L, "regions": N,
                        "mask": c["family"], "layers": cfg.layers, "hidden": cfg.hidden, "vocab": cfg.vocab_size,
                        "parallelism": f"dp{world}", "optimizer": "HF AdamW fused", "dropout": cfg.dropout,
+                       "rows": (f"padding removed: encoder on the valid rows only (mean {rows_mean:.1f} of {L} positions per sample; "
+                                "results equal the padded run)") if packed else "padded",
                        "mlm_loss": float(st[0] / max(float(st[1]), 1.0)), "itm_loss": float(st[3] / max(float(st[4]), 1.0))},
             # dominant kernel (the FFN-up GEMM, largest single share of the step): algorithmic FLOPs per launch / its
             # average duration, HIP events around 20 launches on its own stream (time_dominant_kernel); traffic = HBM bytes

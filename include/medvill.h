@@ -145,6 +145,20 @@ int mv_mlm_corrupt(const int64_t* ids, const int32_t* lengths, const float* u, c
                    int B, int N, int S, int64_t* input_txt, int64_t* segment, int64_t* txt_labels, int32_t* n_ids,
                    int32_t* desc, int32_t* counts, int32_t* label_rows, int32_t* label_ids, int32_t* n_labels, void* stream);
 
+/* ---- packed rows (padding removal) -------------------------------------------------------------------
+ * In the full, seq2seq and 1-D mask families no valid query can see a position after the sample's text [SEP]
+ * (SURVEY.md Appendix B), and those positions carry no label: their rows contribute exactly nothing to the loss,
+ * to any gradient or to any valid position's hidden state.  The encoder may therefore run on the valid rows only.
+ * mv_pack_plan turns the mask descriptors into the row plan:
+ *   cu     int32 [B+1]   exclusive prefix sums of vl[b] = desc[b][2] (clamped to L); cu[B] = number of packed rows
+ *   rowmap int32 [>= cu[B]] (capacity B*L)  logical flat position b*L + p of every packed row
+ *   inv    int32 [B*L]   packed row of logical position b*L + p, or -1 when it was dropped
+ * Consumers: mv_embed_fwd/bwd take (rowmap, n_rows) and read / write packed rows; mv_attn_fwd/bwd take (cu, total_rows)
+ * and address qkv / ctx / dctx / dqkv by packed row while mask words, lse, delta and the dropout counter keep their
+ * logical [B, L] indexing (so a packed run draws the same attention-dropout masks as the padded one).  All four accept
+ * NULL for the dense [B*L] layout.  Packed attention exists for the bf16 MFMA kernels only.                      */
+int mv_pack_plan(const int32_t* desc, int B, int L, int32_t* cu, int32_t* rowmap, int32_t* inv, void* stream);
+
 /* ---- fused-mask multi-head attention --------------------------------------------------------
  * Replaces HF BertSelfAttention's scores/softmax/context (spec:
  * Downstream_task/report_generation_and_vqa/sc/pytorch_pretrained_bert/model.py:301-320):
@@ -156,13 +170,13 @@ int mv_mlm_corrupt(const int64_t* ids, const int32_t* lengths, const float* u, c
  * mask of mv_dropout_mask(p_drop, drop_key) over index ((b*A + h)*L + q)*Lp + k, Lp = L rounded up to 4.  */
 int mv_attn_fwd(int dtype, const void* qkv, const uint32_t* bits, const uint8_t* tileinfo,
                 void* ctx, float* lse, int B, int L, int A, int dh,
-                float p_drop, unsigned long long drop_key, void* stream);
+                float p_drop, unsigned long long drop_key, const int32_t* cu, int total_rows, void* stream);
 
 /* dqkv [B*L,3H] from dctx [B*L,H]; `delta` is a [B,A,L] f32 scratch (rowsum(dctx*ctx)). */
 int mv_attn_bwd(int dtype, const void* qkv, const void* ctx, const void* dctx, const float* lse,
                 const uint32_t* bits, const uint8_t* tileinfo,
                 void* dqkv, float* delta, int B, int L, int A, int dh,
-                float p_drop, unsigned long long drop_key, void* stream);
+                float p_drop, unsigned long long drop_key, const int32_t* cu, int total_rows, void* stream);
 
 /* ---- LayerNorm ------------------------------------------------------------------------------
  * y = (x-mean)/sqrt(var+eps)*gamma+beta over the last dim (HF LayerNorm eps=1e-12 in the
@@ -195,7 +209,7 @@ int mv_embed_fwd(int dtype, const int64_t* cls_tok, const int64_t* txt, const in
                  const void* E, const void* P, const void* Ty, const float* gamma, const float* beta,
                  void* x0, float* pre, float* mean, float* rstd,
                  int B, int N, int T, int H, int V, int maxpos, float eps,
-                 float p_drop, unsigned long long drop_key, void* stream);
+                 float p_drop, unsigned long long drop_key, const int32_t* rowmap, int n_rows, void* stream);
 
 /* Backward of the above: LN backward of dx0, scatter-add (f32 atomics) into dE [V,H], dP, dTy,
  * dgamma, dbeta (all ACCUMULATED) and write d(imgproj) [B,N,H] in `dtype`.  Row `pad_token_id`
@@ -206,7 +220,7 @@ int mv_embed_bwd(int dtype, const void* dx0, const float* pre, const float* mean
                  const int64_t* img_pos, const int64_t* sep_tok,
                  float* dE, float* dP, float* dTy, float* dgamma, float* dbeta, void* dimgproj,
                  int B, int N, int T, int H, int V, int maxpos, int pad_token_id,
-                 float p_drop, unsigned long long drop_key, void* stream);
+                 float p_drop, unsigned long long drop_key, const int32_t* rowmap, int n_rows, void* stream);
 
 /* ---- losses + step metrics ------------------------------------------------------------------
  * Replaces nn.CrossEntropyLoss(ignore_index=-100) on mlm.transpose(1,2) and

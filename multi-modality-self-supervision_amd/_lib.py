@@ -34,14 +34,15 @@ PROTOTYPES = {
     "mv_mask_build": [vp, i32, i32, vp, vp, vp],
     "mv_mlm_draws": [u64, i32, i32, i32, vp, vp, vp],
     "mv_mlm_corrupt": [vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
-    "mv_attn_fwd": [i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, u64, vp],
-    "mv_attn_bwd": [i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, u64, vp],
+    "mv_pack_plan": [vp, i32, i32, vp, vp, vp, vp],
+    "mv_attn_fwd": [i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, u64, vp, i32, vp],
+    "mv_attn_bwd": [i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, u64, vp, i32, vp],
     "mv_layernorm_fwd": [i32, vp, i32, vp, vp, vp, vp, vp, i32, i32, f32, vp],
     "mv_layernorm_bwd": [i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, f32, u64, vp],
     "mv_embed_fwd": [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, f32,
-                     u64, vp],
+                     u64, vp, i32, vp],
     "mv_embed_bwd": [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32,
-                     u64, vp],
+                     u64, vp, i32, vp],
     "mv_dropout_mask": [f32, u64, sz, vp, C.POINTER(C.c_float), vp],
     "mv_ce_fwd_bwd": [vp, i32, i32, vp, i32, i32, vp, vp, i32, i32, vp, f32, vp],
     "mv_gather_rows": [i32, vp, i32, vp, i32, i32, vp, i32, vp],

@@ -144,6 +144,9 @@ struct AttnArgs {
   unsigned bytes_qkv, bytes_ctx;
   DropCfg drop;   // attention-probability dropout; mask index = ((b*A + h)*L + q)*Lp + k, Lp = L rounded up to 4
   int Lp;
+  // packed rows (nullable): sample b owns rows cu[b] .. cu[b+1]-1 of qkv / ctx / dctx / out / dqkv, i.e. only its first
+  // cu[b+1]-cu[b] positions exist; mask words, lse, delta and the dropout counter keep their logical [B, L] indexing
+  const int32_t* cu;
 };
 // keep-bits of the 4 consecutive keys k4..k4+3 (k4 % 4 == 0) of query row q
 __device__ __forceinline__ unsigned attn_drop_hash(const DropCfg& d, size_t bh, int L, int Lp, int q, int k4) {
@@ -257,8 +260,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_mfma_kernel(AttnArgs a) {
   const int head = blockIdx.y, b = blockIdx.z;
   const int L = a.L, H = a.H, ld = 3 * a.H, T = a.T;
   const int qb0 = blockIdx.x * 128, q0 = qb0 + wid * 32, q = q0 + l31;
-  const bool wave_on = q0 < L, q_ok = q < L;
-  const size_t rowbase = (size_t)b * L;
+  const int Lv = a.cu ? a.cu[b + 1] - a.cu[b] : L;             // positions of this sample that exist as rows
+  if (qb0 >= Lv) return;
+  const bool wave_on = q0 < Lv, q_ok = q < Lv;
+  const size_t rowbase = a.cu ? (size_t)a.cu[b] : (size_t)b * L;
+  const size_t lrow = (size_t)b * L;                            // logical row base (mask words)
   __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.qkv, 0, a.bytes_qkv, 0x00020000);
 
   bf16x8 qf[4];
@@ -271,25 +277,25 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_mfma_kernel(AttnArgs a) {
 #pragma unroll
   for (int i = 0; i < 16; ++i) { o[0][i] = 0.f; o[1][i] = 0.f; }
 
-  const int nkt = (L + 63) / 64;
+  const int nkt = (Lv + 63) / 64;
   const int ta = qb0 >> 6;
   const TileMasks tmk = load_tile_masks_q(a.info, b, T, ta, min(q0 >> 6, T - 1), lane);
   int cur = next_tile(tmk.need, -1, nkt);
   u32x4 rk[2], rv[2];
   if (cur < nkt) {
-    tile_load(rk, rs, a.bytes_qkv, rowbase, cur * 64, L, ld, H + head * 64, tid);
-    tile_load(rv, rs, a.bytes_qkv, rowbase, cur * 64, L, ld, 2 * H + head * 64, tid);
+    tile_load(rk, rs, a.bytes_qkv, rowbase, cur * 64, Lv, ld, H + head * 64, tid);
+    tile_load(rv, rs, a.bytes_qkv, rowbase, cur * 64, Lv, ld, 2 * H + head * 64, tid);
     tile_store(rk, smem, tid);
     tile_store(rv, smem + 8192, tid);
   }
   __syncthreads();
   int buf = 0;
-  const uint32_t* myw = a.bits + (rowbase + (q_ok ? q : 0)) * a.W;
+  const uint32_t* myw = a.bits + (lrow + (q_ok ? q : 0)) * a.W;
   while (cur < nkt) {
     const int nxt = next_tile(tmk.need, cur, nkt);
     if (nxt < nkt) {
-      tile_load(rk, rs, a.bytes_qkv, rowbase, nxt * 64, L, ld, H + head * 64, tid);
-      tile_load(rv, rs, a.bytes_qkv, rowbase, nxt * 64, L, ld, 2 * H + head * 64, tid);
+      tile_load(rk, rs, a.bytes_qkv, rowbase, nxt * 64, Lv, ld, H + head * 64, tid);
+      tile_load(rv, rs, a.bytes_qkv, rowbase, nxt * 64, Lv, ld, 2 * H + head * 64, tid);
     }
     const char* tK = smem + buf * 16384;
     const char* tV = tK + 8192;
@@ -305,7 +311,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_mfma_kernel(AttnArgs a) {
         for (int s = 0; s < 4; ++s)
           st[kk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(tK, 32 * kk, s, l31, h), qf[s], st[kk], 0, 0, 0);
       }
-      const bool tail = (k0 + 64 > L);
+      const bool tail = (k0 + 64 > Lv);
       float mx = -INFINITY;
       const bool plain = (cls == 1) && !tail;       // fully visible tile: no mask words, no bounds, scale folded into the exp
       if (plain) {
@@ -324,7 +330,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_mfma_kernel(AttnArgs a) {
             const int kr = acc_row(r, h);
             float v = st[kk][r] * c2;
             if (cls != 1) v += ((w >> kr) & 1u) ? 0.f : MASK_ADD * LOG2E;
-            if (tail && (k0 + 32 * kk + kr >= L)) v = -INFINITY;
+            if (tail && (k0 + 32 * kk + kr >= Lv)) v = -INFINITY;
             st[kk][r] = v;
             mx = fmaxf(mx, v);
           }
@@ -403,8 +409,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_mfma_kernel(AttnArgs a) {
   const int head = blockIdx.y, b = blockIdx.z;
   const int L = a.L, H = a.H, ld = 3 * a.H, T = a.T;
   const int qb0 = blockIdx.x * 128, q0 = qb0 + wid * 32, q = q0 + l31;
-  const bool wave_on = q0 < L, q_ok = q < L;
-  const size_t rowbase = (size_t)b * L;
+  const int Lv = a.cu ? a.cu[b + 1] - a.cu[b] : L;
+  if (qb0 >= Lv) return;
+  const bool wave_on = q0 < Lv, q_ok = q < Lv;
+  const size_t rowbase = a.cu ? (size_t)a.cu[b] : (size_t)b * L;
+  const size_t lrow = (size_t)b * L;
   __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.qkv, 0, a.bytes_qkv, 0x00020000);
   __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc((void*)a.dctx, 0, a.bytes_ctx, 0x00020000);
 
@@ -435,32 +444,32 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_mfma_kernel(AttnArgs a) {
 #pragma unroll
   for (int i = 0; i < 16; ++i) { dq[0][i] = 0.f; dq[1][i] = 0.f; }
 
-  const int nkt = (L + 63) / 64;
+  const int nkt = (Lv + 63) / 64;
   const int ta = qb0 >> 6;
   const TileMasks tmk = load_tile_masks_q(a.info, b, T, ta, min(q0 >> 6, T - 1), lane);
   int cur = next_tile(tmk.need, -1, nkt);
   u32x4 rk[2], rv[2];
   if (cur < nkt) {
-    tile_load(rk, rs, a.bytes_qkv, rowbase, cur * 64, L, ld, H + head * 64, tid);
-    tile_load(rv, rs, a.bytes_qkv, rowbase, cur * 64, L, ld, 2 * H + head * 64, tid);
+    tile_load(rk, rs, a.bytes_qkv, rowbase, cur * 64, Lv, ld, H + head * 64, tid);
+    tile_load(rv, rs, a.bytes_qkv, rowbase, cur * 64, Lv, ld, 2 * H + head * 64, tid);
     tile_store(rk, smem, tid);
     tile_store(rv, smem + 8192, tid);
   }
   __syncthreads();
   int buf = 0;
-  const uint32_t* myw = a.bits + (rowbase + (q_ok ? q : 0)) * a.W;
+  const uint32_t* myw = a.bits + (lrow + (q_ok ? q : 0)) * a.W;
   while (cur < nkt) {
     const int nxt = next_tile(tmk.need, cur, nkt);
     if (nxt < nkt) {
-      tile_load(rk, rs, a.bytes_qkv, rowbase, nxt * 64, L, ld, H + head * 64, tid);
-      tile_load(rv, rs, a.bytes_qkv, rowbase, nxt * 64, L, ld, 2 * H + head * 64, tid);
+      tile_load(rk, rs, a.bytes_qkv, rowbase, nxt * 64, Lv, ld, H + head * 64, tid);
+      tile_load(rv, rs, a.bytes_qkv, rowbase, nxt * 64, Lv, ld, 2 * H + head * 64, tid);
     }
     const char* tK = smem + buf * 16384;
     const char* tV = tK + 8192;
     const int cls = !wave_on ? 0 : (((tmk.w_is1 >> cur) & 1) ? 1 : (((tmk.w_nz >> cur) & 1) ? 2 : 0));
     if (wave_on && cls != 0) {
       const int k0 = cur * 64;
-      const bool tail = (k0 + 64 > L);
+      const bool tail = (k0 + 64 > Lv);
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
         f32x16 st, dp;
@@ -484,7 +493,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_mfma_kernel(AttnArgs a) {
             const float v = fmaf(st[r], c2, ((w >> kr) & 1u) ? 0.f : MASK_ADD * LOG2E);
             pv = fexp2(v - lse2);
           }
-          if (tail && (k0 + 32 * kk + kr >= L)) pv = 0.f;
+          if (tail && (k0 + 32 * kk + kr >= Lv)) pv = 0.f;
           float dpr = dp[r];
           if (a.drop.thr) {
             if ((r & 3) == 0) hcur = attn_drop_hash(a.drop, (size_t)b * a.A + head, L, a.Lp, q_ok ? q : 0, k0 + 32 * kk + kr);
@@ -529,8 +538,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_mfma_kernel(AttnArgs a) {
   const int head = blockIdx.y, b = blockIdx.z;
   const int L = a.L, H = a.H, ld = 3 * a.H, T = a.T;
   const int kb0 = blockIdx.x * 128, k0w = kb0 + wid * 32, key = k0w + l31;
-  const bool wave_on = k0w < L, k_ok = key < L;
-  const size_t rowbase = (size_t)b * L;
+  const int Lv = a.cu ? a.cu[b + 1] - a.cu[b] : L;
+  if (kb0 >= Lv) return;
+  const bool wave_on = k0w < Lv, k_ok = key < Lv;
+  const size_t rowbase = a.cu ? (size_t)a.cu[b] : (size_t)b * L;
+  const size_t lrow = (size_t)b * L;
   __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.qkv, 0, a.bytes_qkv, 0x00020000);
   __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc((void*)a.dctx, 0, a.bytes_ctx, 0x00020000);
 
@@ -545,7 +557,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_mfma_kernel(AttnArgs a) {
 #pragma unroll
   for (int i = 0; i < 16; ++i) { dk[0][i] = 0.f; dk[1][i] = 0.f; dv[0][i] = 0.f; dv[1][i] = 0.f; }
 
-  const int nqt = (L + 63) / 64;
+  const int nqt = (Lv + 63) / 64;
   const int ka = kb0 >> 6;
   const int kw0 = kb0 >> 5;           // first of the block's 4 mask words
   const size_t sbase = ((size_t)b * a.A + head) * L;
@@ -554,14 +566,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_mfma_kernel(AttnArgs a) {
   float r_lse = 0.f, r_dl = 0.f;
   uint32_t r_w = 0;
   auto stage_load_all = [&](int t) {
-    tile_load(rq, rs, a.bytes_qkv, rowbase, t * 64, L, ld, head * 64, tid);
-    tile_load(rd, rsd, a.bytes_ctx, rowbase, t * 64, L, H, head * 64, tid);
+    tile_load(rq, rs, a.bytes_qkv, rowbase, t * 64, Lv, ld, head * 64, tid);
+    tile_load(rd, rsd, a.bytes_ctx, rowbase, t * 64, Lv, H, head * 64, tid);
     const int qi = t * 64 + (tid & 63);
-    if (tid < 64) r_lse = (qi < L) ? a.lse_in[sbase + qi] * LOG2E : INFINITY;
-    else if (tid < 128) r_dl = (qi < L) ? a.delta[sbase + qi] : 0.f;
+    if (tid < 64) r_lse = (qi < Lv) ? a.lse_in[sbase + qi] * LOG2E : INFINITY;
+    else if (tid < 128) r_dl = (qi < Lv) ? a.delta[sbase + qi] : 0.f;
     {
       const int qq = t * 64 + (tid >> 2), wi = kw0 + (tid & 3);
-      r_w = (qq < L && wi < a.W) ? a.bits[(rowbase + qq) * a.W + wi] : 0u;
+      r_w = (qq < Lv && wi < a.W) ? a.bits[(lrow + qq) * a.W + wi] : 0u;
     }
   };
   auto stage_store_all = [&](char* st) {
@@ -866,7 +878,8 @@ static int launch_simple_fwd(const void* qkv, const uint32_t* bits, void* ctx, f
 }
 
 extern "C" int mv_attn_fwd(int dtype, const void* qkv, const uint32_t* bits, const uint8_t* tileinfo, void* ctx, float* lse,
-                           int B, int L, int A, int dh, float p_drop, unsigned long long drop_key, void* stream_) {
+                           int B, int L, int A, int dh, float p_drop, unsigned long long drop_key, const int32_t* cu,
+                           int total_rows, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   const DropCfg drop = mv_make_drop(p_drop, drop_key);
   if ((size_t)B * A * L * ((L + 3) & ~3) >= (1ull << 34)) return MV_E_SHAPE;   // mask counter is 32 bits of (index >> 2)
@@ -875,9 +888,12 @@ extern "C" int mv_attn_fwd(int dtype, const void* qkv, const uint32_t* bits, con
   const int H = A * dh;
   if (dtype == MV_BF16 && g_mv_impl == 0) {
     if (dh != 64) return MV_E_SHAPE;
-    const size_t bq = (size_t)B * L * 3 * H * 2;
+    if (cu && (total_rows <= 0 || total_rows > B * L)) return MV_E_ARG;
+    const size_t nrow = cu ? (size_t)total_rows : (size_t)B * L;
+    const size_t bq = nrow * 3 * H * 2;
     if (bq >= 0x7fffffffULL || (((uintptr_t)qkv) & 15) || (((uintptr_t)ctx) & 7)) return MV_E_SHAPE;
     AttnArgs a{};
+    a.cu = cu;
     a.qkv = (const bf16_t*)qkv; a.out = (bf16_t*)ctx; a.bits = bits; a.info = tileinfo; a.lse = lse;
     a.B = B; a.L = L; a.A = A; a.H = H; a.W = (L + 31) / 32; a.T = (L + 63) / 64;
     a.scale = 1.0f / sqrtf((float)dh);
@@ -889,7 +905,7 @@ extern "C" int mv_attn_fwd(int dtype, const void* qkv, const uint32_t* bits, con
     MV_CHECK_LAUNCH();
     return MV_OK;
   }
-  if (dh > 128) return MV_E_SHAPE;
+  if (dh > 128 || cu) return MV_E_SHAPE;       // packed rows: MFMA kernels only
   return dtype == MV_F32 ? launch_simple_fwd<float>(qkv, bits, ctx, lse, B, L, A, dh, drop, stream)
                          : launch_simple_fwd<bf16_t>(qkv, bits, ctx, lse, B, L, A, dh, drop, stream);
 }
@@ -915,7 +931,7 @@ static int launch_simple_bwd(const void* qkv, const void* ctx, const void* dctx,
 
 extern "C" int mv_attn_bwd(int dtype, const void* qkv, const void* ctx, const void* dctx, const float* lse, const uint32_t* bits,
                            const uint8_t* tileinfo, void* dqkv, float* delta, int B, int L, int A, int dh, float p_drop,
-                           unsigned long long drop_key, void* stream_) {
+                           unsigned long long drop_key, const int32_t* cu, int total_rows, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   const DropCfg drop = mv_make_drop(p_drop, drop_key);
   if (!qkv || !ctx || !dctx || !lse || !bits || !tileinfo || !dqkv || !delta || B <= 0 || L <= 0 || A <= 0 || dh <= 0)
@@ -924,9 +940,12 @@ extern "C" int mv_attn_bwd(int dtype, const void* qkv, const void* ctx, const vo
   const int H = A * dh;
   if (dtype == MV_BF16 && g_mv_impl == 0) {
     if (dh != 64) return MV_E_SHAPE;
-    const size_t bq = (size_t)B * L * 3 * H * 2, bc = (size_t)B * L * H * 2;
+    if (cu && (total_rows <= 0 || total_rows > B * L)) return MV_E_ARG;
+    const size_t nrow = cu ? (size_t)total_rows : (size_t)B * L;
+    const size_t bq = nrow * 3 * H * 2, bc = nrow * H * 2;
     if (bq >= 0x7fffffffULL || (((uintptr_t)qkv) & 15) || (((uintptr_t)dctx) & 15) || (((uintptr_t)dqkv) & 7)) return MV_E_SHAPE;
     AttnArgs a{};
+    a.cu = cu;
     a.qkv = (const bf16_t*)qkv; a.ctx = (const bf16_t*)ctx; a.dctx = (const bf16_t*)dctx; a.dqkv = (bf16_t*)dqkv;
     a.bits = bits; a.info = tileinfo; a.lse_in = lse; a.delta = delta; a.delta_out = delta;
     a.B = B; a.L = L; a.A = A; a.H = H; a.W = (L + 31) / 32; a.T = (L + 63) / 64;
@@ -946,7 +965,7 @@ extern "C" int mv_attn_bwd(int dtype, const void* qkv, const void* ctx, const vo
     MV_CHECK_LAUNCH();
     return MV_OK;
   }
-  if (dh > 128) return MV_E_SHAPE;
+  if (dh > 128 || cu) return MV_E_SHAPE;
   return dtype == MV_F32 ? launch_simple_bwd<float>(qkv, ctx, dctx, lse, bits, dqkv, delta, B, L, A, dh, drop, stream)
                          : launch_simple_bwd<bf16_t>(qkv, ctx, dctx, lse, bits, dqkv, delta, B, L, A, dh, drop, stream);
 }

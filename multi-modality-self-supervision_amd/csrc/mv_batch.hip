@@ -126,7 +126,37 @@ __global__ __launch_bounds__(NT) void label_index_kernel(const int64_t* __restri
   }
 }
 
+// Packed-row plan: sample b keeps its first vl[b] positions (everything after its text [SEP] is padding that no valid
+// query can see in the full / seq2seq / 1-D mask families).  cu = exclusive prefix sums of vl; rowmap[cu[b] + p] = b*L + p;
+// inv[b*L + p] = cu[b] + p for p < vl[b], -1 for the dropped positions.
+__global__ __launch_bounds__(NT) void pack_plan_kernel(const int32_t* __restrict__ desc, int B, int L, int32_t* __restrict__ cu,
+                                                       int32_t* __restrict__ rowmap, int32_t* __restrict__ inv) {
+  __shared__ int s_red[NT / 64];
+  const int b = blockIdx.x;
+  int part = 0;
+  for (int i = threadIdx.x; i < b; i += NT) part += min(max(desc[3 * i + 2], 0), L);
+  const int base = block_sum(part, s_red);
+  const int vl = min(max(desc[3 * b + 2], 0), L);
+  if (threadIdx.x == 0) {
+    cu[b] = base;
+    if (b == B - 1) cu[B] = base + vl;
+  }
+  for (int p = threadIdx.x; p < L; p += NT) {
+    if (p < vl) rowmap[base + p] = b * L + p;
+    inv[(size_t)b * L + p] = p < vl ? base + p : -1;
+  }
+}
+
 }  // namespace
+
+extern "C" int mv_pack_plan(const int32_t* desc, int B, int L, int32_t* cu, int32_t* rowmap, int32_t* inv, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!desc || !cu || !rowmap || !inv || B <= 0 || L <= 0) return MV_E_ARG;
+  if ((long long)B * L > 0x7fffffffLL) return MV_E_SHAPE;
+  pack_plan_kernel<<<B, NT, 0, stream>>>(desc, B, L, cu, rowmap, inv);
+  MV_CHECK_LAUNCH();
+  return MV_OK;
+}
 
 extern "C" int mv_mlm_draws(unsigned long long key, int B, int S, int vocab, float* u, int32_t* rnd, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;

@@ -888,7 +888,7 @@ extern "C" int mv_gemm(int dtype, int ta, int tb, int M, int N, int K, const voi
     //  y = x.W'^T form, 191 vs 208 us and 138 vs 148 us; not for f32 outputs, where the 128x128 kernel's 3 blocks per CU
     //  hide the wider stores better)
     const bool wide_nt = !ta && !tb && (N >= 1024 || (K >= 2048 && c_dtype == MV_BF16));
-    const bool big = (g_mv_gemm_force == 2) || (g_mv_gemm_force == 0 && M >= 256 && N >= 128 && (K & 7) == 0 && (wide_nt || ta) &&
+    const bool big = (g_mv_gemm_force == 2) || (g_mv_gemm_force == 0 && M >= 256 && N >= 128 && ((K & 7) == 0 || (ta && tb)) && (wide_nt || ta) &&
                                                (t128 >= 128 || (K >= 4096 && splitk != 1)));
     if (big) {
       long long sk = splitk;

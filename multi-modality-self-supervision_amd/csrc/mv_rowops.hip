@@ -178,6 +178,8 @@ extern "C" int mv_layernorm_bwd(int dtype, const void* dy, const void* x, int x_
 struct EmbArgs {
   const int64_t* cls_tok; const int64_t* txt; const int64_t* segment; const int64_t* img_pos; const int64_t* sep_tok;
   int B, N, T, H, V, maxpos, L;
+  const int32_t* rowmap;   // packed rows (nullable): row r holds logical position rowmap[r] = b*L + l; n_rows of them
+  int n_rows;
 };
 // position l of sample b -> (token id or -1 for an image region, position id, type id, region index)
 __device__ __forceinline__ void emb_decode(const EmbArgs& a, int b, int l, int& tok, int& pos, int& typ, int& reg) {
@@ -201,8 +203,9 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(EmbArgs a, const T* __re
                                                         float* __restrict__ rstd, float eps, DropCfg drop) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= a.B * a.L) return;
-  const int b = row / a.L, l = row - b * a.L, H = a.H;
+  if (row >= a.n_rows) return;
+  const int li = a.rowmap ? a.rowmap[row] : row;
+  const int b = li / a.L, l = li - b * a.L, H = a.H;
   int tok, pos, typ, reg;
   emb_decode(a, b, l, tok, pos, typ, reg);
   const T* src = (tok >= 0) ? E + (size_t)tok * H : imgproj + ((size_t)b * a.N + reg) * H;
@@ -259,9 +262,10 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(EmbArgs a, const T* __re
   f32x4 ag[NC], ab[NC], at0[NC], at1[NC];
 #pragma unroll
   for (int i = 0; i < NC; ++i) { ag[i] = (f32x4){0, 0, 0, 0}; ab[i] = ag[i]; at0[i] = ag[i]; at1[i] = ag[i]; }
-  const int M = a.B * a.L;
+  const int M = a.n_rows;
   for (int row = blockIdx.x * 4 + wl; row < M; row += gridDim.x * 4) {
-    const int b = row / a.L, l = row - b * a.L;
+    const int li = a.rowmap ? a.rowmap[row] : row;
+    const int b = li / a.L, l = li - b * a.L;
     int tok, pos, typ, reg;
     emb_decode(a, b, l, tok, pos, typ, reg);
     const float mu = mean[row], rs = rstd[row];
@@ -338,15 +342,17 @@ static int emb_check(int B, int N, int T, int H, int V, int maxpos) {
 extern "C" int mv_embed_fwd(int dtype, const int64_t* cls_tok, const int64_t* txt, const int64_t* segment, const int64_t* img_pos,
                             const int64_t* sep_tok, const void* imgproj, const void* E, const void* P, const void* Ty,
                             const float* gamma, const float* beta, void* x0, float* pre, float* mean, float* rstd, int B, int N,
-                            int T, int H, int V, int maxpos, float eps, float p_drop, unsigned long long drop_key, void* stream_) {
+                            int T, int H, int V, int maxpos, float eps, float p_drop, unsigned long long drop_key,
+                            const int32_t* rowmap, int n_rows, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!cls_tok || !txt || !segment || !sep_tok || !E || !P || !Ty || !gamma || !beta || !x0 || !pre || !mean || !rstd) return MV_E_ARG;
   if (N > 0 && (!img_pos || !imgproj)) return MV_E_ARG;
   int rc = emb_check(B, N, T, H, V, maxpos);
   if (rc) return rc;
   if (T > maxpos) return MV_E_SHAPE;   // text positions 0..T-1 must exist
-  EmbArgs a{cls_tok, txt, segment, img_pos, sep_tok, B, N, T, H, V, maxpos, N + T + 2};
-  dim3 grid((B * a.L + 3) / 4), block(256);
+  if (rowmap && (n_rows <= 0 || n_rows > B * (N + T + 2))) return MV_E_ARG;
+  EmbArgs a{cls_tok, txt, segment, img_pos, sep_tok, B, N, T, H, V, maxpos, N + T + 2, rowmap, rowmap ? n_rows : B * (N + T + 2)};
+  dim3 grid((a.n_rows + 3) / 4), block(256);
   const DropCfg drop = mv_make_drop(p_drop, drop_key);
 #define EMF(NC_) hipLaunchKernelGGL((embed_fwd_kernel<T_, NC_>), grid, block, 0, stream, a, (const T_*)imgproj, (const T_*)E, (const T_*)P, (const T_*)Ty, gamma, beta, (T_*)x0, pre, mean, rstd, eps, drop)
   if (dtype == MV_F32) { typedef float T_; NC_DISPATCH(H, EMF); }
@@ -361,15 +367,16 @@ extern "C" int mv_embed_bwd(int dtype, const void* dx0, const float* pre, const 
                             const int64_t* cls_tok, const int64_t* txt, const int64_t* segment, const int64_t* img_pos,
                             const int64_t* sep_tok, float* dE, float* dP, float* dTy, float* dgamma, float* dbeta, void* dimgproj,
                             int B, int N, int T, int H, int V, int maxpos, int pad_token_id, float p_drop,
-                            unsigned long long drop_key, void* stream_) {
+                            unsigned long long drop_key, const int32_t* rowmap, int n_rows, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!dx0 || !pre || !mean || !rstd || !gamma || !cls_tok || !txt || !segment || !sep_tok || !dE || !dP || !dTy || !dgamma || !dbeta)
     return MV_E_ARG;
   if (N > 0 && (!img_pos || !dimgproj)) return MV_E_ARG;
   int rc = emb_check(B, N, T, H, V, maxpos);
   if (rc) return rc;
-  EmbArgs a{cls_tok, txt, segment, img_pos, sep_tok, B, N, T, H, V, maxpos, N + T + 2};
-  int blocks = (B * a.L + 3) / 4;
+  if (rowmap && (n_rows <= 0 || n_rows > B * (N + T + 2))) return MV_E_ARG;
+  EmbArgs a{cls_tok, txt, segment, img_pos, sep_tok, B, N, T, H, V, maxpos, N + T + 2, rowmap, rowmap ? n_rows : B * (N + T + 2)};
+  int blocks = (a.n_rows + 3) / 4;
   if (blocks > 1024) blocks = 1024;
   dim3 grid(blocks), block(256);
   const DropCfg drop = mv_make_drop(p_drop, drop_key);

@@ -23,8 +23,19 @@ class MaskDesc:
     """Per-sample mask descriptors {family, n2, vl} (int32 [B,3]): what the attention kernels need instead of the
     reference's materialised int64 [B,L,L] matrices.  Accepted wherever `attn_mask` is (CXRBERT.forward, TrainStep)."""
 
-    def __init__(self, desc: torch.Tensor, L: int):
+    def __init__(self, desc: torch.Tensor, L: int, host: torch.Tensor = None):
         self.desc, self.L = desc.to(torch.int32), int(L)
+        self._host = host                # CPU copy (kept when the descriptors were built on the host: no sync later)
+
+    def host_desc(self) -> torch.Tensor:
+        if self._host is None:
+            self._host = self.desc.cpu()
+        return self._host
+
+    def packable(self) -> bool:
+        """True when no valid query can see a position after the text [SEP] (full / seq2seq / 1-D families)."""
+        f = self.host_desc()[:, 0]
+        return bool(((f == 0) | (f == 1) | (f == 4)).all())
 
     @classmethod
     def make(cls, family, N: int, S: int, n_ids, device="cpu"):
@@ -36,19 +47,19 @@ class MaskDesc:
         d[:, 0] = torch.tensor([FAMILY_ID[f] for f in fam], dtype=torch.int32)
         d[:, 1] = N + 2
         d[:, 2] = N + 2 + n_ids
-        return cls(d.to(device), S + N + 3)
+        return cls(d.to(device), S + N + 3, host=d)
 
     def dim(self):
         return 3
 
     def __getitem__(self, idx):          # batch slicing, like a [B, ...] tensor
-        return MaskDesc(self.desc[idx].reshape(-1, 3), self.L)
+        return MaskDesc(self.desc[idx].reshape(-1, 3), self.L, None if self._host is None else self._host[idx].reshape(-1, 3))
 
     def __len__(self):
         return int(self.desc.shape[0])
 
     def to(self, device, *a, **k):
-        return MaskDesc(self.desc.to(device), self.L)
+        return MaskDesc(self.desc.to(device), self.L, self._host)
 
 
 def build_mask(family: str, N: int, S: int, n_ids, device="cpu") -> torch.Tensor:

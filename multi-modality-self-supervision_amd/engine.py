@@ -258,7 +258,11 @@ class Engine:
         ops.gemm(dy, x, gW, ta=True, tb=True, M=No, N=Ko, K=Mtok, lda=lda, ldb=ldb, ldc=ldc, splitk=0 if auto else 1, ws=ws)
 
     # ------------------------------------------------------------------ encoder forward
-    def encoder_forward(self, cls_tok, input_txt, attn_mask, segment, img_feats, img_pos, sep_tok):
+    def encoder_forward(self, cls_tok, input_txt, attn_mask, segment, img_feats, img_pos, sep_tok, pack=False):
+        """pack=True (fused training path, bf16, mask descriptors of the full / seq2seq / 1-D families): the encoder runs
+        on the valid rows only -- positions after a sample's text [SEP] are invisible to every valid query in those
+        families and carry no label, so they contribute nothing to the loss or to any gradient (include/medvill.h,
+        'packed rows').  Hidden states are then [sum(vl), H] and the first return value is that packed matrix."""
         cfg, dt, adt, dev = self.cfg, self.dt, self.adt, self.device
         H, A, I, D = cfg.hidden, cfg.heads, cfg.intermediate, cfg.img_hidden
         dh = H // A
@@ -275,7 +279,17 @@ class Engine:
         if self.shadow_dirty:
             self.sync_shadow()
         f32 = torch.float32
-        S = self.S = dict(B=B, T=T, N=N, L=Lq, M=M)
+        S = self.S = dict(B=B, T=T, N=N, L=Lq, M=M, cu=None, rowmap=None, inv=None)
+        if pack:
+            if not isinstance(attn_mask, MaskDesc) or dt != MV_BF16:
+                raise ValueError("pack=True needs mask descriptors (data.MaskDesc) and the bf16 path")
+            hd = attn_mask.host_desc()
+            if not bool(((hd[:, 0] == 0) | (hd[:, 0] == 1) | (hd[:, 0] == 4)).all()):
+                raise ValueError("pack=True: padding is visible to valid queries in the BAR / non-cross families")
+            M = int(hd[:, 2].clamp(0, Lq).sum())
+            S["cu"], S["rowmap"], S["inv"] = ops.pack_plan(attn_mask.desc.to(dev), B, Lq)
+            S["M"] = M
+        cu, rowmap = S["cu"], S["rowmap"]
         pd = S["p_drop"] = float(cfg.dropout) if self.training else 0.0
         self.drop_counter += 1
         dk = S["drop_keys"] = self._drop_keys(cfg.layers)
@@ -316,7 +330,7 @@ class Engine:
                       self.w[e + "word_embeddings.weight"], self.w[e + "position_embeddings.weight"],
                       self.w[e + "token_type_embeddings.weight"], self.p[e + "LayerNorm.weight"], self.p[e + "LayerNorm.bias"],
                       x, pre0, mean0, rstd0, B, N, T, H, cfg.vocab_size, cfg.max_pos, cfg.ln_eps, p_drop=pd,
-                      drop_key=dk[(self.SITE_EMB, 0)])
+                      drop_key=dk[(self.SITE_EMB, 0)], rowmap=rowmap, n_rows=M)
         S["layers"] = []
         for l in range(cfg.layers):
             p = f"enc.encoder.layer.{l}."
@@ -327,7 +341,8 @@ class Engine:
             ops.gemm(x, Wqkv, qkv, M=M, N=3 * H, K=H, bias=bqkv, epi=EPI_BIAS)
             ctx = a_["ctx"] = self._buf(f"ctx{l}", (M, H), adt)
             lse = a_["lse"] = self._buf(f"lse{l}", (B, A, Lq), f32)
-            ops.attn_fwd(qkv, bits, tinfo, ctx, lse, B, Lq, A, dh, p_drop=pd, drop_key=dk[(self.SITE_ATTN, l)])
+            ops.attn_fwd(qkv, bits, tinfo, ctx, lse, B, Lq, A, dh, p_drop=pd, drop_key=dk[(self.SITE_ATTN, l)], cu=cu,
+                         total_rows=M)
             pre1 = a_["pre1"] = self._buf(f"pre1_{l}", (M, H), f32)
             ops.gemm(ctx, self.w[p + "attention.output.dense.weight"], pre1, M=M, N=H, K=H,
                      bias=self.p[p + "attention.output.dense.bias"], epi=EPI_BIAS_RES, r=x, p_drop=pd,
@@ -352,9 +367,14 @@ class Engine:
             S["layers"].append(a_)
         S["hidden"] = x
         pooled = S["pooled"] = self._buf("pooled", (B, H), adt)
-        ops.gemm(x, self.w["enc.pooler.dense.weight"], pooled, M=B, N=H, K=H, lda=Lq * H, bias=self.p["enc.pooler.dense.bias"],
-                 epi=EPI_BIAS_TANH)
-        return x.view(B, Lq, H), pooled
+        if cu is None:
+            S["h0"], S["h0_ld"] = x, Lq * H             # first row of every sample, addressed in place
+        else:
+            S["h0"], S["h0_ld"] = self._buf("h0", (B, H), adt), H
+            ops.gather_rows(x, H, cu, B, H, S["h0"], H)
+        ops.gemm(S["h0"], self.w["enc.pooler.dense.weight"], pooled, M=B, N=H, K=H, lda=S["h0_ld"],
+                 bias=self.p["enc.pooler.dense.bias"], epi=EPI_BIAS_TANH)
+        return (x.view(B, Lq, H) if cu is None else x), pooled
 
     # ------------------------------------------------------------------ heads (shared pieces)
     def _itm_forward(self):
@@ -423,11 +443,14 @@ class Engine:
         dpre = self._buf("dpoolpre", (B, H), self.adt)
         ops.dact(1, dpool, S["pooled"], dpre, B * H)
         ops.colsum(dpre, H, B, H, g["enc.pooler.dense.bias"], accumulate=True)
-        self._dW(dpre, S["hidden"], g["enc.pooler.dense.weight"], H, H, B, lda=H, ldb=Lq * H)
+        self._dW(dpre, S["h0"], g["enc.pooler.dense.weight"], H, H, B, lda=H, ldb=S["h0_ld"])
         dh0 = self._buf("dh0", (B, H), self.adt)
         ops.gemm(dpre, self.w["enc.pooler.dense.weight"], dh0, tb=True, M=B, N=H, K=H)
-        rows0 = self._buf("rows0", (B,), torch.int32)
-        rows0.copy_(torch.arange(B, device=self.device, dtype=torch.int32) * Lq)
+        if S["cu"] is None:
+            rows0 = self._buf("rows0", (B,), torch.int32)
+            rows0.copy_(torch.arange(B, device=self.device, dtype=torch.int32) * Lq)
+        else:
+            rows0 = S["cu"]                              # packed: sample b starts at row cu[b]
         ops.scatter_rows(dh0, H, rows0, B, H, S["dhidden"], H, accumulate=True)
 
     # ------------------------------------------------------------------ drop-in heads: full logits
@@ -466,6 +489,8 @@ class Engine:
         S, H, V = self.S, self.cfg.hidden, self.cfg.vocab_size
         M, B = S["M"], S["B"]
         R = int(label_rows.numel())
+        if S["inv"] is not None and R > 0:               # logical flat positions -> packed rows
+            label_rows = S["inv"].index_select(0, label_rows.to(torch.int64))
         stats = torch.zeros(6, dtype=torch.float32, device=self.device)
         if compute_grad:
             self.ensure_grad()
@@ -573,7 +598,8 @@ class Engine:
             with torch.cuda.stream(side):
                 self._dW(dproj1, a_["ctx"], g[p + "attention.output.dense.weight"], H, H, M, lda=H, ldb=H)
             ops.gemm(dproj1, self.w[p + "attention.output.dense.weight"], dctx, tb=True, M=M, N=H, K=H)
-            ops.attn_bwd(a_["qkv"], a_["ctx"], dctx, a_["lse"], S["bits"], S["tinfo"], dqkv, delta, B, Lq, A, dh, p_drop=pd,
+            ops.attn_bwd(a_["qkv"], a_["ctx"], dctx, a_["lse"], S["bits"], S["tinfo"], dqkv, delta, B, Lq, A, dh, cu=S["cu"],
+                         total_rows=M, p_drop=pd,
                          drop_key=dk[(self.SITE_ATTN, l)])
             fork()
             with torch.cuda.stream(side):
@@ -595,7 +621,7 @@ class Engine:
                       self.p[e + "LayerNorm.weight"], S["cls_tok"], S["txt"], S["segment"], S["img_pos"], S["sep_tok"],
                       g[e + "word_embeddings.weight"], g[e + "position_embeddings.weight"], g[e + "token_type_embeddings.weight"],
                       g[e + "LayerNorm.weight"], g[e + "LayerNorm.bias"], dimg, B, N, T, H, cfg.vocab_size, cfg.max_pos,
-                      pad_token_id=0, p_drop=pd, drop_key=dk[(self.SITE_EMB, 0)])
+                      pad_token_id=0, p_drop=pd, drop_key=dk[(self.SITE_EMB, 0)], rowmap=S["rowmap"], n_rows=M)
         main.wait_stream(side)              # every weight gradient is final; the split-K workspace is ours again
         if N > 0:
             ops.colsum(dimg, H, B * N, H, g["enc.img_embeddings.img_embeddings.bias"], accumulate=True)

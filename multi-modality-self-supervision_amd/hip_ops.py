@@ -95,15 +95,30 @@ def mlm_corrupt(ids, lengths, u, rnd, N, family=None, want_index=True):
     return out
 
 
-def attn_fwd(qkv, bits, tileinfo, ctx, lse, B, Lq, A, dh, p_drop=0.0, drop_key=0):
+def pack_plan(desc, B, Lq):
+    """(cu int32 [B+1], rowmap int32 [B*L], inv int32 [B*L]) from mask descriptors (see mv_pack_plan); device tensors."""
+    L.require_cuda(desc)
+    if desc.dtype != torch.int32 or tuple(desc.shape) != (B, 3):
+        raise TypeError("desc must be int32 [B,3]")
+    dev = desc.device
+    cu = torch.empty((B + 1,), dtype=torch.int32, device=dev)
+    rowmap = torch.empty((B * Lq,), dtype=torch.int32, device=dev)
+    inv = torch.empty((B * Lq,), dtype=torch.int32, device=dev)
+    rc = _lib().mv_pack_plan(L.ptr(desc.contiguous()), B, Lq, L.ptr(cu), L.ptr(rowmap), L.ptr(inv), L.stream_ptr())
+    L.check(rc, "mv_pack_plan")
+    return cu, rowmap, inv
+
+
+def attn_fwd(qkv, bits, tileinfo, ctx, lse, B, Lq, A, dh, p_drop=0.0, drop_key=0, cu=None, total_rows=0):
     rc = _lib().mv_attn_fwd(L.dt_of(qkv), L.ptr(qkv), L.ptr(bits), L.ptr(tileinfo), L.ptr(ctx), L.ptr(lse), B, Lq, A, dh,
-                            float(p_drop), int(drop_key), L.stream_ptr())
+                            float(p_drop), int(drop_key), L.ptr(cu), int(total_rows), L.stream_ptr())
     L.check(rc, "mv_attn_fwd")
 
 
-def attn_bwd(qkv, ctx, dctx, lse, bits, tileinfo, dqkv, delta, B, Lq, A, dh, p_drop=0.0, drop_key=0):
+def attn_bwd(qkv, ctx, dctx, lse, bits, tileinfo, dqkv, delta, B, Lq, A, dh, p_drop=0.0, drop_key=0, cu=None, total_rows=0):
     rc = _lib().mv_attn_bwd(L.dt_of(qkv), L.ptr(qkv), L.ptr(ctx), L.ptr(dctx), L.ptr(lse), L.ptr(bits), L.ptr(tileinfo),
-                            L.ptr(dqkv), L.ptr(delta), B, Lq, A, dh, float(p_drop), int(drop_key), L.stream_ptr())
+                            L.ptr(dqkv), L.ptr(delta), B, Lq, A, dh, float(p_drop), int(drop_key), L.ptr(cu), int(total_rows),
+                            L.stream_ptr())
     L.check(rc, "mv_attn_bwd")
 
 
@@ -121,19 +136,20 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dx, dgamma, dbeta, colsum, M, H, dx_
 
 
 def embed_fwd(dt, cls_tok, txt, segment, img_pos, sep_tok, imgproj, E, P, Ty, gamma, beta, x0, pre, mean, rstd, B, N, T, H, V,
-              maxpos, eps, p_drop=0.0, drop_key=0):
+              maxpos, eps, p_drop=0.0, drop_key=0, rowmap=None, n_rows=0):
     rc = _lib().mv_embed_fwd(dt, L.ptr(cls_tok), L.ptr(txt), L.ptr(segment), L.ptr(img_pos), L.ptr(sep_tok), L.ptr(imgproj),
                              L.ptr(E), L.ptr(P), L.ptr(Ty), L.ptr(gamma), L.ptr(beta), L.ptr(x0), L.ptr(pre), L.ptr(mean),
-                             L.ptr(rstd), B, N, T, H, V, maxpos, float(eps), float(p_drop), int(drop_key), L.stream_ptr())
+                             L.ptr(rstd), B, N, T, H, V, maxpos, float(eps), float(p_drop), int(drop_key), L.ptr(rowmap), int(n_rows),
+                             L.stream_ptr())
     L.check(rc, "mv_embed_fwd")
 
 
 def embed_bwd(dt, dx0, pre, mean, rstd, gamma, cls_tok, txt, segment, img_pos, sep_tok, dE, dP, dTy, dgamma, dbeta, dimgproj, B,
-              N, T, H, V, maxpos, pad_token_id=0, p_drop=0.0, drop_key=0):
+              N, T, H, V, maxpos, pad_token_id=0, p_drop=0.0, drop_key=0, rowmap=None, n_rows=0):
     rc = _lib().mv_embed_bwd(dt, L.ptr(dx0), L.ptr(pre), L.ptr(mean), L.ptr(rstd), L.ptr(gamma), L.ptr(cls_tok), L.ptr(txt),
                              L.ptr(segment), L.ptr(img_pos), L.ptr(sep_tok), L.ptr(dE), L.ptr(dP), L.ptr(dTy), L.ptr(dgamma),
                              L.ptr(dbeta), L.ptr(dimgproj), B, N, T, H, V, maxpos, int(pad_token_id), float(p_drop), int(drop_key),
-                             L.stream_ptr())
+                             L.ptr(rowmap), int(n_rows), L.stream_ptr())
     L.check(rc, "mv_embed_bwd")
 
 

@@ -23,12 +23,15 @@ class TrainStep:
     """Fused pretraining step over a CXRBERT model (single GPU or one rank of a DP job)."""
 
     def __init__(self, model: CXRBERT, lr=1e-5, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.0, distributed=False, group=None,
-                 mlm_task=True, itm_task=True):
+                 mlm_task=True, itm_task=True, pack_rows=True):
         # HF AdamW defaults, as effectively used by the reference: train_origin.py:60 passes only lr
         self.model, self.eng = model, model.engine
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
         self.step_cnt = 0
         self.mlm_task, self.itm_task = mlm_task, itm_task
+        # padding removal: when a batch carries mask descriptors of the full / seq2seq / 1-D families (bf16 path), the
+        # encoder runs on the valid rows only; results are those of the padded run (see Engine.encoder_forward)
+        self.pack_rows = pack_rows
         self.eng.ensure_opt()
         self.dp = None
         if distributed:
@@ -51,8 +54,10 @@ class TrainStep:
         eng.training = bool(train and self.model.training)      # dropout like the reference's model.train()
         if train:
             eng.flat_g.zero_()
-        eng.encoder_forward(batch["cls_tok"], batch["input_txt"], batch["attn_mask"], batch["segment"], batch["img_feats"],
-                            batch["img_pos"], batch["sep_tok"])
+        desc = batch.get("attn_desc")
+        pack = bool(self.pack_rows and desc is not None and eng.adt == torch.bfloat16 and desc.packable())
+        eng.encoder_forward(batch["cls_tok"], batch["input_txt"], desc if pack else batch["attn_mask"], batch["segment"],
+                            batch["img_feats"], batch["img_pos"], batch["sep_tok"], pack=pack)
         R, B = int(rows.numel()), int(aligned.numel())
         # loss normalisation = the reference's means over the GLOBAL mini-batch (train_origin.py:120-126)
         mlm_dev = itm_dev = None

@@ -133,7 +133,7 @@ def test_gemm_splitk_and_accumulate(impl):
     assert relerr(c, ref + 1.0) < 2e-4
 
 
-@pytest.mark.parametrize("ta,tb,M,N,K", [(0, 0, 1024, 768, 768), (0, 1, 2048, 768, 2304), (1, 1, 768, 3072, 8192),
+@pytest.mark.parametrize("ta,tb,M,N,K", [(0, 0, 1024, 768, 768), (0, 1, 2048, 768, 2304), (1, 1, 768, 3072, 8192), (1, 1, 768, 3072, 25483),
                                          (0, 0, 515, 2304, 264), (0, 1, 1000, 304, 1032)])
 def test_gemm_auto_dispatch_large(ta, tb, M, N, K):
     """Shapes that take the 256-row LDS-DMA kernel under the automatic tile choice, incl. auto split-K."""
@@ -151,7 +151,7 @@ def test_gemm_auto_dispatch_large(ta, tb, M, N, K):
 @pytest.mark.parametrize("ta,tb,M,N,K,epi", [(0, 0, 8200, 3000, 768, EPI_BIAS_GELU), (0, 0, 8192, 3072, 264, EPI_BIAS_RES),
                                              (0, 1, 9000, 2304, 520, EPI_DGELU), (0, 0, 16384, 768, 3072, EPI_BIAS),
                                              (0, 0, 8192, 3072, 768, EPI_BIAS_GELU_D), (0, 1, 8200, 3072, 768, EPI_MUL),
-                                             (1, 1, 768, 3072, 8192, EPI_NONE), (1, 1, 2304, 776, 4104, EPI_NONE),
+                                             (1, 1, 768, 3072, 8192, EPI_NONE), (1, 1, 2304, 776, 4104, EPI_NONE), (1, 1, 768, 768, 25483, EPI_NONE),
                                              (1, 0, 1000, 2048, 1032, EPI_RES)])
 def test_gemm_persistent_many_units_per_block(impl, ta, tb, M, N, K, epi):
     """More (tile, K-slice) units than CUs: every block of the persistent kernel walks several units, with the ring

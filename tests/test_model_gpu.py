@@ -305,6 +305,48 @@ def test_half_batches_sum_to_full_batch_gradient(B):
     assert torch.isfinite(g_full).all() and rel < 2e-2
 
 
+@pytest.mark.parametrize("family,B,N,S", [("mixed", 7, 6, 120), ("full", 3, 36, 473), ("s2s", 4, 1, 70)])
+def test_packed_rows_reproduce_the_padded_step(family, B, N, S):
+    """Padding removal (TrainStep pack_rows): running the encoder on the valid rows only must give the padded run's
+    loss statistics and gradients -- valid rows go through identical arithmetic (same MFMA contraction order, same key
+    tiling), only the order of the row-reductions in weight gradients differs (fp32 summation order)."""
+    cfg = mv.ModelConfig(hidden=128, heads=2, intermediate=512, layers=2, vocab_size=1024, max_pos=512, dropout=0.0)
+    batch = mv.data.synthetic_batch(cfg.vocab_size, B, N, S, family, seed=31, device=DEV)
+    out = []
+    for pack in (False, True):
+        model = mv.CXRBERT(cfg, None, dtype=torch.bfloat16, device=DEV)
+        model.reset_parameters(seed=5)
+        model.train()
+        ts = mv.TrainStep(model, lr=0.0, pack_rows=pack)
+        stats = ts(batch, train=True)
+        eng = model.engine
+        assert (eng.S["cu"] is not None) == pack
+        if pack:
+            vl = batch["attn_desc"].host_desc()[:, 2]
+            assert eng.S["M"] == int(vl.sum()) < B * (N + S + 3) and eng.S["hidden"].shape[0] == eng.S["M"]
+        out.append((stats.clone(), eng.flat_g.clone()))
+    (s0, g0), (s1, g1) = out
+    assert torch.equal(s0[[1, 2, 4, 5]], s1[[1, 2, 4, 5]])                       # counts: labels, correct predictions
+    assert float((s0 - s1).abs().max() / s0.abs().max()) < 1e-5                  # nll sums
+    rel = float((g0 - g1).norm() / g0.norm())
+    worst = float((g0 - g1).abs().max() / g0.abs().max())
+    print(f"packed vs padded gradient: rel L2 {rel:.2e}, max-abs/max {worst:.2e}")
+    assert rel < 1e-4 and worst < 1e-4
+
+
+def test_packing_is_refused_where_padding_is_visible():
+    cfg = mv.ModelConfig(hidden=128, heads=2, intermediate=512, layers=1, vocab_size=1024, max_pos=128)
+    model = mv.CXRBERT(cfg, None, dtype=torch.bfloat16, device=DEV)
+    b = mv.data.synthetic_batch(cfg.vocab_size, 2, 6, 40, "bar", seed=1, device=DEV)
+    assert not b["attn_desc"].packable()
+    with pytest.raises(ValueError):
+        model.engine.encoder_forward(b["cls_tok"], b["input_txt"], b["attn_desc"], b["segment"], b["img_feats"], b["img_pos"],
+                                     b["sep_tok"], pack=True)
+    ts = mv.TrainStep(model, lr=0.0)           # falls back to the padded path on its own
+    ts(b, train=True)
+    assert model.engine.S["cu"] is None
+
+
 def test_trainer_mirror_runs_an_epoch_and_saves(tmp_path):
     """CXRBERT_Trainer(args, train_dl, test_dl).train(epoch) / .save(epoch, path) as main_origin.py:57-62 drives it,
     fed with the reference's 9-tuple batches (dataset_origin.py:181) on the host."""
