@@ -268,6 +268,27 @@ int mv_transpose(int dtype, const void* src, long long lds, void* dst, long long
 /* dst(dst_dtype) = src(src_dtype), n elements */
 int mv_cast(const void* src, int src_dtype, void* dst, int dst_dtype, size_t n, void* stream);
 
+/* ---- region-feature extractor: ResNet-50 trunk pieces (models/image.py:46-69) ------------------------------
+ * The trunk runs in NHWC: an activation is the matrix [B*H*W, C] and every convolution is mv_gemm over it -- directly
+ * for 1x1 / stride 1, after mv_im2col otherwise (weights re-laid as [Cout, kh*kw*Cin], (ky, kx, c) order).  BatchNorm
+ * (+ residual)(+ ReLU) is mv_bn_act, with batch statistics from mv_col_stats in train() mode or the running ones in
+ * eval().  Forward only: the reference never trains the CNN (cxrbert_origin.py:66-70 unfreezes nothing).
+ *   mv_nchw_to_nhwc : f32 [B,C,H,W] -> dst_dtype [B,H,W,Cp], channels C..Cp-1 zero
+ *   mv_im2col       : src [B,H,W,C] -> dst [B*Ho*Wo, ldk], column (ky*kw + kx)*C + c = src[b, oy*stride-pad+ky, ox*stride-pad+kx, c]
+ *                     (0 outside the image; columns kh*kw*C..ldk-1 zero), Ho = (H + 2*pad - kh)/stride + 1
+ *   mv_col_stats    : stats f32 [2, C] = per-column sum and sum of squares over the rows of x [rows, C]
+ *   mv_bn_act       : y = (x - mean) * rstd * gamma + beta (+ residual) (max 0 when relu != 0); C % 4 == 0; x may be f32
+ *                     while y / residual are bf16: convolution outputs stay f32 until normalised, because BatchNorm
+ *                     subtracts a mean that can dwarf the spread (bf16 rounding of x would be amplified by |mean|/std)
+ *   mv_maxpool3x3s2 : 3x3 / stride 2 / pad 1 max pooling, NHWC                                                      */
+int mv_nchw_to_nhwc(const float* src, void* dst, int dst_dtype, int B, int C, int H, int W, int Cp, void* stream);
+int mv_im2col(int dtype, const void* src, int B, int H, int W, int C, int kh, int kw, int stride, int pad, void* dst, int ldk,
+              void* stream);
+int mv_col_stats(int dtype, const void* x, int ldx, int rows, int C, float* stats, void* stream);
+int mv_bn_act(int dtype, const void* x, int x_dtype, const float* mean, const float* rstd, const float* gamma, const float* beta,
+              const void* residual, void* y, long long rows, int C, int relu, void* stream);
+int mv_maxpool3x3s2(int dtype, const void* x, void* y, int B, int H, int W, int C, void* stream);
+
 /* ---- dropout mask (inspection / tests) -----------------------------------------------------------
  * The kernels above never store dropout masks: they regenerate them from a counter-based hash of
  * (drop_key, linear element index).  keep[i] = 1 if element i survives; an element is dropped with

@@ -9,6 +9,7 @@ from .engine import Engine, ModelConfig, param_layout  # noqa: F401
 from .cxrbert import CXRBERT  # noqa: F401
 from .trainer import CXRBERT_Trainer, TrainStep  # noqa: F401
 from .retrieval import CXRBertForRetrieval  # noqa: F401
+from .image import ImageEncoder_cnn  # noqa: F401
 from . import checkpoint, data  # noqa: F401
 
-__all__ = ["Engine", "ModelConfig", "param_layout", "CXRBERT", "CXRBERT_Trainer", "TrainStep", "CXRBertForRetrieval", "data"]
+__all__ = ["Engine", "ModelConfig", "param_layout", "CXRBERT", "CXRBERT_Trainer", "TrainStep", "CXRBertForRetrieval", "ImageEncoder_cnn", "data"]

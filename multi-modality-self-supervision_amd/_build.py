@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libmedvill_hip.so")
-SOURCES = ["mv_api.hip", "mv_gemm.hip", "mv_attn.hip", "mv_rowops.hip", "mv_batch.hip"]
+SOURCES = ["mv_api.hip", "mv_gemm.hip", "mv_attn.hip", "mv_rowops.hip", "mv_batch.hip", "mv_conv.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
 
 

@@ -53,6 +53,11 @@ PROTOTYPES = {
     "mv_cast2d": [vp, i32, i64, vp, i32, i64, i32, i32, vp],
     "mv_cast": [vp, i32, vp, i32, sz, vp],
     "mv_transpose": [i32, vp, i64, vp, i64, i32, i32, vp],
+    "mv_nchw_to_nhwc": [vp, vp, i32, i32, i32, i32, i32, i32, vp],
+    "mv_im2col": [i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp],
+    "mv_col_stats": [i32, vp, i32, i32, i32, vp, vp],
+    "mv_bn_act": [i32, vp, i32, vp, vp, vp, vp, vp, vp, i64, i32, i32, vp],
+    "mv_maxpool3x3s2": [i32, vp, vp, i32, i32, i32, i32, vp],
     "mv_adamw_step": [vp, vp, vp, vp, vp, sz, f32, f32, f32, f32, f32, i32, i32, f32, vp],
 }
 _RESTYPE = {"mv_set_impl": None, "mv_set_gemm_variant": None, "mv_build_info": C.c_char_p}

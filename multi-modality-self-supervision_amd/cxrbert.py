@@ -101,6 +101,11 @@ class CXRBERT(nn.Module):
             raise NotImplementedError("disturbing_mask model branch: use the non-cross MASK pattern with the standard branch")
         dev = torch.device(device) if device is not None else torch.device("cuda" if torch.cuda.is_available() else "cpu")
         self.engine = Engine(self.cfg, dtype=dtype, device=dev)
+        if isinstance(img_encoder, str):
+            if img_encoder.lower() not in ("resnet50", "cnn"):
+                raise NotImplementedError(f"img_encoder {img_encoder!r}: only the ResNet-50 region encoder is mirrored")
+            from .image import ImageEncoder_cnn           # models/image.py:46-69, cxrbert_origin.py:64-65
+            img_encoder = ImageEncoder_cnn(self.args, dtype=dtype).to(dev)
         self.img_encoder = img_encoder
         self._param_names = list(self.engine.layout.keys())
         self._register()
@@ -171,8 +176,8 @@ class CXRBERT(nn.Module):
             return input_img
         if self.img_encoder is not None:
             return self.img_encoder(input_img)
-        raise TypeError("input_img must be (region_feats[B,N,2048], region_pos[B,N]) or an img_encoder must be supplied "
-                        "(the ResNet-50 trunk of models/image.py is outside this library's scope)")
+        raise TypeError("input_img must be (region_feats[B,N,2048], region_pos[B,N]); for pixels construct the model with "
+                        "img_encoder='resnet50' (medvill_amd.image.ImageEncoder_cnn) or pass your own callable")
 
     def _run(self, want_heads, cls_tok, input_txt, attn_mask, segment, input_img, sep_tok):
         if attn_mask.dim() not in (2, 3):
@@ -193,6 +198,9 @@ class CXRBERT(nn.Module):
         sd = OrderedDict((n, self.engine.p[n].detach().clone()) for n in self._param_names)
         for alias, canon in ALIASES.items():
             sd[alias] = sd[canon]
+        if isinstance(self.img_encoder, nn.Module):        # enc.img_encoder.model.* like the reference's checkpoints
+            for k_, v in self.img_encoder.state_dict().items():
+                sd["enc.img_encoder." + k_] = v.detach().clone()
         return sd
 
     def load_state_dict(self, sd, strict=True):
@@ -203,6 +211,9 @@ class CXRBERT(nn.Module):
                     self.engine.p[n].copy_(sd[n].to(self.engine.device, torch.float32))
                 else:
                     missing.append(n)
+        cnn = {k_[len("enc.img_encoder."):]: v for k_, v in sd.items() if k_.startswith("enc.img_encoder.")}
+        if cnn and isinstance(self.img_encoder, nn.Module):
+            self.img_encoder.load_state_dict(cnn, strict=strict)
         unexpected = [k_ for k_ in sd if k_ not in self.engine.layout and k_ not in ALIASES
                       and "position_ids" not in k_ and not k_.startswith("enc.img_encoder.")]
         if strict and (missing or unexpected):

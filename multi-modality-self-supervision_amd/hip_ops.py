@@ -204,6 +204,39 @@ def transpose(src, dst, rows, cols, lds=None, ldd=None):
     return dst
 
 
+def nchw_to_nhwc(src, dst, B, C, H, W, Cp):
+    L.require_cuda(src, dst)
+    if src.dtype != torch.float32:
+        raise TypeError("nchw_to_nhwc: source pixels must be float32")
+    rc = _lib().mv_nchw_to_nhwc(L.ptr(src), L.ptr(dst), L.dt_of(dst), B, C, H, W, Cp, L.stream_ptr())
+    L.check(rc, "mv_nchw_to_nhwc")
+
+
+def im2col(src, dst, B, H, W, C, kh, kw, stride, pad, ldk):
+    L.require_cuda(src, dst)
+    rc = _lib().mv_im2col(L.dt_of(src), L.ptr(src), B, H, W, C, kh, kw, stride, pad, L.ptr(dst), ldk, L.stream_ptr())
+    L.check(rc, "mv_im2col")
+
+
+def col_stats(x, ldx, rows, C, stats):
+    L.require_cuda(x, stats)
+    rc = _lib().mv_col_stats(L.dt_of(x), L.ptr(x), ldx, rows, C, L.ptr(stats), L.stream_ptr())
+    L.check(rc, "mv_col_stats")
+
+
+def bn_act(x, mean, rstd, gamma, beta, y, rows, C, residual=None, relu=True):
+    L.require_cuda(x, mean, rstd, gamma, beta, y, residual)
+    rc = _lib().mv_bn_act(L.dt_of(y), L.ptr(x), L.dt_of(x), L.ptr(mean), L.ptr(rstd), L.ptr(gamma), L.ptr(beta), L.ptr(residual), L.ptr(y),
+                          int(rows), C, int(relu), L.stream_ptr())
+    L.check(rc, "mv_bn_act")
+
+
+def maxpool3x3s2(x, y, B, H, W, C):
+    L.require_cuda(x, y)
+    rc = _lib().mv_maxpool3x3s2(L.dt_of(x), L.ptr(x), L.ptr(y), B, H, W, C, L.stream_ptr())
+    L.check(rc, "mv_maxpool3x3s2")
+
+
 def cast2d(src, lds, dst, ldd, rows, cols):
     rc = _lib().mv_cast2d(L.ptr(src), L.dt_of(src), lds, L.ptr(dst), L.dt_of(dst), ldd, rows, cols, L.stream_ptr())
     L.check(rc, "mv_cast2d")

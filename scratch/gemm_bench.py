@@ -5,7 +5,7 @@ import medvill_amd as mv
 from medvill_amd import hip_ops as ops
 from medvill_amd._lib import *
 dev = "cuda"
-M = 32768
+M = int(sys.argv[1]) if len(sys.argv) > 1 else 32768
 def rnd(*s):
     return (torch.randn(*s, device=dev) * 0.5).to(torch.bfloat16)
 def bench1(fn, reps=20):

@@ -3,7 +3,7 @@ sys.path.insert(0, os.getcwd())
 import torch
 from medvill_amd import hip_ops as ops
 from medvill_amd._lib import *
-dev="cuda"; H=768; I=3072; M=32768
+dev="cuda"; H=768; I=3072; M=int(sys.argv[1]) if len(sys.argv)>1 else 32768
 def bench(fn, reps=20):
     for _ in range(3): fn()
     torch.cuda.synchronize()

@@ -1,0 +1,131 @@
+"""GPU parity of the region-feature extractor (ResNet-50 trunk through mv_gemm / mv_im2col / mv_bn_act) against the
+torch.nn.functional restatement in oracle/resnet_oracle.py on the same torchvision-layout weights.
+Tolerances (relative L2; max-abs within 10x): fp32 path 2e-4 (exact fp32 arithmetic in another order, 53 convolutions
+deep); bf16 path 2e-2 against the restatement with the same bf16 rounding points."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import medvill_amd as mv                                    # noqa: E402
+from medvill_amd import hip_ops as ops                       # noqa: E402
+from oracle import resnet_oracle as R                        # noqa: E402
+
+DEV = "cuda"
+
+
+def _encoder(dtype, seed=0, n=6):
+    torch.manual_seed(seed)
+    enc = mv.ImageEncoder_cnn(num_image_embeds=n, dtype=dtype)
+    g = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():                                   # non-trivial BatchNorm parameters and running statistics
+        for m in enc.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.weight.copy_(0.5 + torch.rand(m.weight.shape, generator=g))
+                m.bias.copy_(0.2 * torch.randn(m.bias.shape, generator=g))
+                m.running_mean.copy_(0.1 * torch.randn(m.running_mean.shape, generator=g))
+                m.running_var.copy_(0.5 + torch.rand(m.running_var.shape, generator=g))
+    return enc.to(DEV)
+
+
+def _sd_cpu(enc):
+    return {k: v.detach().cpu().float().clone() for k, v in enc.state_dict().items()}
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-4), (torch.bfloat16, 2e-2)])
+@pytest.mark.parametrize("training", [False, True])
+def test_trunk_matches_the_functional_restatement(dtype, tol, training):
+    enc = _encoder(dtype)
+    enc.train(training)
+    sd = _sd_cpu(enc)
+    # the bf16 path is compared with the restatement WITH its rounding points (see oracle/resnet_oracle.trunk: under batch
+    # statistics a randomly initialised ResNet amplifies bf16 rounding ~100x; against the unrounded fp32 restatement the
+    # eval() output differs by ~1 % and the train() output by ~45 % -- and so does the rounded restatement itself)
+    bf = dtype == torch.bfloat16
+    if bf and training:
+        pytest.skip("end-to-end bf16 under batch statistics is chaotic at random init: checked block by block below")
+    rnd = (lambda t: t.to(torch.bfloat16).float()) if bf else None
+    Bx, Hx, Wx = 3, 96, 64
+    x = torch.randn(Bx, 3, Hx, Wx, generator=torch.Generator().manual_seed(9))
+    ref = R.trunk(sd, x, training, rnd=rnd)                                  # [B,2048,h,w]; updates sd's running stats
+    y, h, w = enc.trunk(x.to(DEV))
+    got = y.view(Bx, h, w, 2048).permute(0, 3, 1, 2).float().cpu()
+    assert got.shape == ref.shape == (Bx, 2048, Hx // 32, Wx // 32)
+    err = float((got - ref).abs().max() / ref.abs().max())
+    l2 = float((got - ref).norm() / ref.norm())
+    print(f"trunk {dtype} training={training}: max-abs error / scale = {err:.2e}, relative L2 = {l2:.2e}")
+    assert l2 < tol and err < 10 * tol
+    if training:                                                            # running statistics moved like nn.BatchNorm2d's
+        new = _sd_cpu(enc)
+        for k in ("model.1.running_mean", "model.1.running_var", "model.7.2.bn3.running_mean", "model.7.2.bn3.running_var"):
+            d = float((new[k] - sd[k]).abs().max() / (sd[k].abs().max() + 1e-6))
+            assert d < (1e-4 if dtype == torch.float32 else 3e-2), (k, d)
+        assert int(new["model.1.num_batches_tracked"]) == 1
+
+
+@pytest.mark.parametrize("li,bi", [(4, 0), (5, 0), (6, 3), (7, 2)])
+def test_bf16_blocks_under_batch_statistics(li, bi):
+    """bf16 path, train() BatchNorm, one bottleneck at a time (first blocks have the strided 3x3 + downsample branch):
+    same bf16 input, same rounding points as the product -> agreement at bf16 rounding level, no deep amplification."""
+    enc = _encoder(torch.bfloat16).train()
+    sd = _sd_cpu(enc)
+    blk = enc.model[li][bi]
+    C = blk.conv1.in_channels
+    B, H, W = 4, 12, 10
+    bf = lambda t: t.to(torch.bfloat16).float()
+    x = bf(torch.randn(B, C, H, W, generator=torch.Generator().manual_seed(li * 10 + bi)).abs())      # post-ReLU-like input
+    ref = R.block(sd, f"model.{li}.{bi}", x, blk.stride, True, rnd=bf)
+    y = x.permute(0, 2, 3, 1).reshape(B * H * W, C).to(torch.bfloat16).to(DEV).contiguous()
+    out, H2, W2, C2 = enc._block(y, B, H, W, C, blk)
+    got = out.view(B, H2, W2, C2).permute(0, 3, 1, 2).float().cpu()
+    l2 = float((got - ref).norm() / ref.norm())
+    print(f"block model.{li}.{bi}: relative L2 {l2:.2e}")
+    assert got.shape == ref.shape and l2 < 1e-2
+
+
+def test_forward_contract_and_pixels_into_cxrbert():
+    """image.py:54-69: sorted, unique sampled positions shared by the batch, features gathered at them; and the whole
+    pixels -> region features -> CXRBERT.forward path runs with the encoder attached."""
+    enc = _encoder(torch.bfloat16, n=5).eval()
+    x = torch.randn(2, 3, 128, 128, generator=torch.Generator().manual_seed(3)).to(DEV)
+    feats, pos = enc(x)
+    assert feats.shape == (2, 5, 2048) and pos.shape == (2, 5) and pos.dtype == torch.int64
+    p = pos[0].tolist()
+    assert p == sorted(set(p)) and max(p) < 16 and torch.equal(pos[0], pos[1])
+    full, h, w = enc.trunk(x)
+    assert torch.equal(feats, full.view(2, h * w, 2048)[:, pos[0]])
+    cfg = mv.ModelConfig(hidden=128, heads=2, intermediate=512, layers=1, vocab_size=1024, max_pos=64)
+    from types import SimpleNamespace
+    model = mv.CXRBERT(cfg, SimpleNamespace(num_image_embeds=5), dtype=torch.bfloat16, device=DEV, img_encoder="resnet50").eval()
+    b = mv.data.synthetic_batch(cfg.vocab_size, 2, 5, 20, "full", seed=1, device=DEV)
+    mlm, itm = model(b["cls_tok"], b["input_txt"], b["attn_mask"], b["segment"], x, b["sep_tok"])
+    assert mlm.shape == (2, 5 + 20 + 3, 1024) and itm.shape == (2, 2) and torch.isfinite(mlm).all()
+    sd = model.state_dict()
+    assert "enc.img_encoder.model.0.weight" in sd and "enc.img_encoder.model.7.2.bn3.running_var" in sd
+    model.load_state_dict(sd)
+
+
+def test_conv_support_kernels_against_torch():
+    g = torch.Generator().manual_seed(5)
+    B, C, H, W = 2, 16, 9, 7
+    x = torch.randn(B, C, H, W, generator=g)
+    nhwc = torch.empty((B * H * W, C), dtype=torch.bfloat16, device=DEV)
+    ops.nchw_to_nhwc(x.to(DEV), nhwc, B, C, H, W, C)
+    assert torch.equal(nhwc.view(B, H, W, C).float().cpu(), x.permute(0, 2, 3, 1).to(torch.bfloat16).float())
+    for (k, s, p) in ((3, 1, 1), (3, 2, 1), (1, 2, 0), (7, 2, 3)):
+        Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+        ldk = (k * k * C + 7) // 8 * 8 + 8
+        cols = torch.full((B * Ho * Wo, ldk), 7.0, dtype=torch.bfloat16, device=DEV)
+        ops.im2col(nhwc, cols, B, H, W, C, k, k, s, p, ldk)
+        ref = torch.nn.functional.unfold(x.to(torch.bfloat16).float(), k, padding=p, stride=s)          # [B, C*k*k, L], (c, ky, kx) order
+        ref = ref.view(B, C, k * k, Ho * Wo).permute(0, 3, 2, 1).reshape(B * Ho * Wo, k * k * C)
+        assert torch.equal(cols[:, :k * k * C].float().cpu(), ref) and bool((cols[:, k * k * C:] == 0).all()), (k, s, p)
+    mp = torch.empty((B * 5 * 4, C), dtype=torch.bfloat16, device=DEV)
+    ops.maxpool3x3s2(nhwc, mp, B, H, W, C)
+    ref = torch.nn.functional.max_pool2d(x.to(torch.bfloat16).float(), 3, 2, 1).permute(0, 2, 3, 1).reshape(-1, C)
+    assert torch.equal(mp.float().cpu(), ref)
+    st = torch.empty((2, C), dtype=torch.float32, device=DEV)
+    ops.col_stats(nhwc, C, B * H * W, C, st)
+    xf = nhwc.float()
+    assert torch.allclose(st[0], xf.sum(0), rtol=1e-5, atol=1e-4) and torch.allclose(st[1], (xf * xf).sum(0), rtol=1e-5, atol=1e-4)
