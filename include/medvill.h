@@ -276,15 +276,18 @@ int mv_cast(const void* src, int src_dtype, void* dst, int dst_dtype, size_t n, 
  *   mv_nchw_to_nhwc : f32 [B,C,H,W] -> dst_dtype [B,H,W,Cp], channels C..Cp-1 zero
  *   mv_im2col       : src [B,H,W,C] -> dst [B*Ho*Wo, ldk], column (ky*kw + kx)*C + c = src[b, oy*stride-pad+ky, ox*stride-pad+kx, c]
  *                     (0 outside the image; columns kh*kw*C..ldk-1 zero), Ho = (H + 2*pad - kh)/stride + 1
- *   mv_col_stats    : stats f32 [2, C] = per-column sum and sum of squares over the rows of x [rows, C]
+ *   mv_col_stats    : stats f32 [2, C] = per-column sum and sum of squares over the rows of x [rows, C] (C, ldx % 4 == 0)
+ *   mv_bn_finalize  : mean / rstd of the batch from those sums (biased variance), plus nn.BatchNorm2d's momentum update of
+ *                     running_mean / running_var (unbiased variance) when they are given (both or neither)
  *   mv_bn_act       : y = (x - mean) * rstd * gamma + beta (+ residual) (max 0 when relu != 0); C % 4 == 0; x may be f32
- *                     while y / residual are bf16: convolution outputs stay f32 until normalised, because BatchNorm
- *                     subtracts a mean that can dwarf the spread (bf16 rounding of x would be amplified by |mean|/std)
+ *                     while y / residual are bf16
  *   mv_maxpool3x3s2 : 3x3 / stride 2 / pad 1 max pooling, NHWC                                                      */
 int mv_nchw_to_nhwc(const float* src, void* dst, int dst_dtype, int B, int C, int H, int W, int Cp, void* stream);
 int mv_im2col(int dtype, const void* src, int B, int H, int W, int C, int kh, int kw, int stride, int pad, void* dst, int ldk,
               void* stream);
 int mv_col_stats(int dtype, const void* x, int ldx, int rows, int C, float* stats, void* stream);
+int mv_bn_finalize(const float* stats, int C, long long rows, float eps, float momentum, float* mean, float* rstd,
+                   float* running_mean, float* running_var, void* stream);
 int mv_bn_act(int dtype, const void* x, int x_dtype, const float* mean, const float* rstd, const float* gamma, const float* beta,
               const void* residual, void* y, long long rows, int C, int relu, void* stream);
 int mv_maxpool3x3s2(int dtype, const void* x, void* y, int B, int H, int W, int C, void* stream);

@@ -64,22 +64,51 @@ __global__ __launch_bounds__(256) void im2col_kernel(const T* __restrict__ src, 
 }
 
 // per-column sum and sum of squares over the rows of x [rows, C] (f32 accumulators, atomics into stats[2][C]);
-// block = 64 columns x 4 row lanes, each block walks a slab of rows
+// block = 16 column groups of 4 (64 columns) x 16 row lanes, each block walks a slab of rows, two rows in flight per thread
 template <typename T>
 __global__ __launch_bounds__(256) void col_stats_kernel(const T* __restrict__ x, int ldx, int rows, int C, float* __restrict__ stats,
                                                         int rows_per_block) {
-  __shared__ float s1[4][64], s2[4][64];
-  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + cx;
+  __shared__ f32x4 s1[16][16], s2[16][16];
+  const int cg = threadIdx.x & 15, ry = threadIdx.x >> 4;
+  const int c = blockIdx.x * 64 + cg * 4;
   const int r0 = blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
-  float a = 0.f, q = 0.f;
-  if (c < C)
-    for (int r = r0 + ry; r < r1; r += 4) { const float v = ldf<T>(x + (size_t)r * ldx + c); a += v; q = fmaf(v, v, q); }
-  s1[ry][cx] = a; s2[ry][cx] = q;
+  f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, q0 = a0, a1 = a0, q1 = a0;
+  if (c < C) {
+    int r = r0 + ry;
+    for (; r + 16 < r1; r += 32) {
+      const f32x4 v0 = ld4<T>(x + (size_t)r * ldx + c), v1 = ld4<T>(x + (size_t)(r + 16) * ldx + c);
+      a0 += v0; q0 += v0 * v0; a1 += v1; q1 += v1 * v1;
+    }
+    if (r < r1) { const f32x4 v0 = ld4<T>(x + (size_t)r * ldx + c); a0 += v0; q0 += v0 * v0; }
+  }
+  s1[ry][cg] = a0 + a1; s2[ry][cg] = q0 + q1;
   __syncthreads();
-  if (ry == 0 && c < C) {
-    atomicAdd(stats + c, s1[0][cx] + s1[1][cx] + s1[2][cx] + s1[3][cx]);
-    atomicAdd(stats + C + c, s2[0][cx] + s2[1][cx] + s2[2][cx] + s2[3][cx]);
+  if (threadIdx.x < 64) {
+    const int col = blockIdx.x * 64 + threadIdx.x, g = threadIdx.x >> 2, e = threadIdx.x & 3;
+    if (col < C) {
+      float a = 0.f, q = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { a += s1[i][g][e]; q += s2[i][g][e]; }
+      atomicAdd(stats + col, a);
+      atomicAdd(stats + C + col, q);
+    }
+  }
+}
+
+// BatchNorm statistics from the column sums: mean, rstd of this batch (biased variance), and -- when running buffers are
+// given -- the momentum update of the running estimates with the UNBIASED variance (nn.BatchNorm2d train())
+__global__ void bn_finalize_kernel(const float* __restrict__ stats, int C, float rows, float eps, float momentum,
+                                   float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ run_mean,
+                                   float* __restrict__ run_var) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float m = stats[c] / rows;
+  const float var = fmaxf(stats[C + c] / rows - m * m, 0.f);
+  mean[c] = m;
+  rstd[c] = 1.0f / sqrtf(var + eps);
+  if (run_mean) {
+    run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * m;
+    run_var[c] = (1.f - momentum) * run_var[c] + momentum * var * (rows / fmaxf(rows - 1.f, 1.f));
   }
 }
 
@@ -172,6 +201,7 @@ extern "C" int mv_im2col(int dtype, const void* src, int B, int H, int W, int C,
 extern "C" int mv_col_stats(int dtype, const void* x, int ldx, int rows, int C, float* stats, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!x || !stats || rows <= 0 || C <= 0 || ldx < C) return MV_E_ARG;
+  if ((C & 3) || (ldx & 3)) return MV_E_SHAPE;
   hipError_t e = hipMemsetAsync(stats, 0, sizeof(float) * 2 * (size_t)C, stream);
   if (e != hipSuccess) return (int)e;
   int slabs = (rows + 511) / 512;
@@ -181,6 +211,16 @@ extern "C" int mv_col_stats(int dtype, const void* x, int ldx, int rows, int C, 
   if (dtype == MV_BF16) col_stats_kernel<bf16_t><<<grid, block, 0, stream>>>((const bf16_t*)x, ldx, rows, C, stats, rpb);
   else if (dtype == MV_F32) col_stats_kernel<float><<<grid, block, 0, stream>>>((const float*)x, ldx, rows, C, stats, rpb);
   else return MV_E_DTYPE;
+  MV_CHECK_LAUNCH();
+  return MV_OK;
+}
+
+extern "C" int mv_bn_finalize(const float* stats, int C, long long rows, float eps, float momentum, float* mean, float* rstd,
+                              float* running_mean, float* running_var, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!stats || !mean || !rstd || C <= 0 || rows <= 0) return MV_E_ARG;
+  if ((running_mean == nullptr) != (running_var == nullptr)) return MV_E_ARG;
+  bn_finalize_kernel<<<(C + 255) / 256, 256, 0, stream>>>(stats, C, (float)rows, eps, momentum, mean, rstd, running_mean, running_var);
   MV_CHECK_LAUNCH();
   return MV_OK;
 }

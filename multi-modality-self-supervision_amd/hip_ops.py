@@ -224,6 +224,13 @@ def col_stats(x, ldx, rows, C, stats):
     L.check(rc, "mv_col_stats")
 
 
+def bn_finalize(stats, C, rows, eps, momentum, mean, rstd, running_mean=None, running_var=None):
+    L.require_cuda(stats, mean, rstd, running_mean, running_var)
+    rc = _lib().mv_bn_finalize(L.ptr(stats), C, int(rows), float(eps), float(momentum), L.ptr(mean), L.ptr(rstd),
+                               L.ptr(running_mean), L.ptr(running_var), L.stream_ptr())
+    L.check(rc, "mv_bn_finalize")
+
+
 def bn_act(x, mean, rstd, gamma, beta, y, rows, C, residual=None, relu=True):
     L.require_cuda(x, mean, rstd, gamma, beta, y, residual)
     rc = _lib().mv_bn_act(L.dt_of(y), L.ptr(x), L.dt_of(x), L.ptr(mean), L.ptr(rstd), L.ptr(gamma), L.ptr(beta), L.ptr(residual), L.ptr(y),

@@ -66,6 +66,7 @@ class ImageEncoder_cnn(nn.Module):
             p.requires_grad = False
         self.adt = dtype
         self._wcache = {}
+        self._bncache = {}
 
     # ---- weights in GEMM layout: [Cout, kh*kw*Cin_padded], (ky, kx, c) order, compute dtype
     def _w2d(self, conv: nn.Conv2d, cin_pad: int):
@@ -94,9 +95,7 @@ class ImageEncoder_cnn(nn.Module):
         else:
             a = torch.empty((rows, K), dtype=self.adt, device=x.device)
             ops.im2col(x, a, B, H, W, C, kh, kw, s, pad, K)
-        # f32 output: BatchNorm subtracts a mean that can dwarf the spread, so the pre-normalisation values are not
-        # rounded to bf16 (the rounding error would be amplified by |mean| / std)
-        y = torch.empty((rows, O), dtype=torch.float32, device=x.device)
+        y = torch.empty((rows, O), dtype=self.adt, device=x.device)
         # mv_gemm addresses an operand through a 2-GiB buffer descriptor: large activation matrices go in row slabs
         step = max(256, ((1 << 31) - (1 << 20)) // (K * a.element_size()) // 256 * 256)
         for r0 in range(0, rows, step):
@@ -106,22 +105,24 @@ class ImageEncoder_cnn(nn.Module):
 
     def _bn(self, x, bn: nn.BatchNorm2d, residual=None, relu=True):
         rows, C = x.shape
+        dev = x.device
         if self.training:
-            st = torch.empty((2, C), dtype=torch.float32, device=x.device)
+            st = torch.empty((2, C), dtype=torch.float32, device=dev)
+            mean, rstd = torch.empty((C,), dtype=torch.float32, device=dev), torch.empty((C,), dtype=torch.float32, device=dev)
             ops.col_stats(x, C, rows, C, st)
-            mean = st[0] / rows
-            var = torch.clamp(st[1] / rows - mean * mean, min=0.0)          # biased: what normalises the batch
-            with torch.no_grad():
-                m = bn.momentum if bn.momentum is not None else 0.1
-                bn.running_mean.mul_(1 - m).add_(mean, alpha=m)
-                bn.running_var.mul_(1 - m).add_(var * (rows / max(rows - 1, 1)), alpha=m)   # unbiased, like torch
-                bn.num_batches_tracked += 1
+            m = bn.momentum if bn.momentum is not None else 0.1
+            ops.bn_finalize(st, C, rows, bn.eps, m, mean, rstd, bn.running_mean, bn.running_var)   # updates the running buffers
+            bn.num_batches_tracked += 1
         else:
-            mean, var = bn.running_mean, bn.running_var
-        rstd = torch.rsqrt(var + bn.eps)
-        y = torch.empty(x.shape, dtype=self.adt, device=x.device)
-        ops.bn_act(x, mean.contiguous(), rstd.contiguous(), bn.weight.detach().float(), bn.bias.detach().float(), y, rows, C,
-                   residual=residual, relu=relu)
+            key = id(bn)
+            hit = self._bncache.get(key)
+            ver = (bn.running_mean._version, bn.running_var._version)
+            if hit is None or hit[0] != ver or hit[1].device != dev:
+                hit = (ver, bn.running_mean.float().contiguous(), torch.rsqrt(bn.running_var.float() + bn.eps).contiguous())
+                self._bncache[key] = hit
+            mean, rstd = hit[1], hit[2]
+        y = torch.empty(x.shape, dtype=self.adt, device=dev)
+        ops.bn_act(x, mean, rstd, bn.weight, bn.bias, y, rows, C, residual=residual, relu=relu)
         return y
 
     def _block(self, y, B, H, W, C, blk: _Bottleneck):

@@ -26,23 +26,23 @@ def block(sd, p, y, stride, training, rnd=None):
     r = rnd if rnd is not None else (lambda t: t)
     w = lambda k: r(sd[k])
     idt = y
-    o = r(F.relu(_bn(F.conv2d(y, w(p + ".conv1.weight")), sd, p + ".bn1", training)))
-    o = r(F.relu(_bn(F.conv2d(o, w(p + ".conv2.weight"), stride=stride, padding=1), sd, p + ".bn2", training)))
-    o = _bn(F.conv2d(o, w(p + ".conv3.weight")), sd, p + ".bn3", training)
+    o = r(F.relu(_bn(r(F.conv2d(y, w(p + ".conv1.weight"))), sd, p + ".bn1", training)))
+    o = r(F.relu(_bn(r(F.conv2d(o, w(p + ".conv2.weight"), stride=stride, padding=1)), sd, p + ".bn2", training)))
+    o = _bn(r(F.conv2d(o, w(p + ".conv3.weight"))), sd, p + ".bn3", training)
     if (p + ".downsample.0.weight") in sd:
-        idt = r(_bn(F.conv2d(y, w(p + ".downsample.0.weight"), stride=stride), sd, p + ".downsample.1", training))
+        idt = r(_bn(r(F.conv2d(y, w(p + ".downsample.0.weight"), stride=stride)), sd, p + ".downsample.1", training))
     return r(F.relu(o + idt))
 
 
 def trunk(sd: dict, x: torch.Tensor, training: bool, rnd=None) -> torch.Tensor:
     """sd: state dict with keys model.0.weight, model.1.*, model.4.0.conv1.weight ... (float32; running statistics are
     updated IN PLACE when training, like nn.BatchNorm2d).  x [B,3,H,W] -> [B,2048,h,w].
-    rnd: optional rounding applied where the bf16 product stores bf16 (pixels, convolution weights, every BatchNorm
-    output): a randomly initialised ResNet under batch-statistics BatchNorm amplifies bf16 rounding ~100x over its 53
+    rnd: optional rounding applied where the bf16 product stores bf16 (pixels, convolution weights, every convolution
+    output and every BatchNorm output): a randomly initialised ResNet under batch-statistics BatchNorm amplifies bf16 rounding ~100x over its 53
     convolutions, so the bf16 path is checked against this restatement WITH its rounding points."""
     r = rnd if rnd is not None else (lambda t: t)
     w = lambda k: r(sd[k])
-    y = F.conv2d(r(x), w("model.0.weight"), stride=2, padding=3)
+    y = r(F.conv2d(r(x), w("model.0.weight"), stride=2, padding=3))
     y = r(F.relu(_bn(y, sd, "model.1", training)))
     y = F.max_pool2d(y, 3, stride=2, padding=1)
     for li, n in enumerate(LAYERS):
