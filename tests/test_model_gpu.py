@@ -459,3 +459,9 @@ def test_full_size_step_is_finite_repeatable_and_masks_pack_exactly():
     st = ts(b, train=True).cpu()
     assert bool(torch.isfinite(eng.flat_p).all()) and bool(torch.isfinite(eng.flat_g).all())
     assert abs(float(st[0] / st[1]) - np.log(cfg.vocab_size)) < 0.5 and int(st[4]) == B
+
+
+def test_graft_entry_smoke_runs():
+    """The driver's round-end smoke check (forward + fused step of the tiny config against the oracle)."""
+    import __graft_entry__ as g
+    g.smoke()
