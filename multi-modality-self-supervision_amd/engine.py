@@ -184,16 +184,17 @@ class Engine:
         self.shadow_dirty = False
 
     def _refresh_transposed(self):
-        """W^T copies of the FFN and fused-QKV weights (bf16 mode): dX = dY.W then runs as y = x.W'^T with W' = W^T
-        k-contiguous, the form the 256-row LDS-DMA kernel is fastest in (profiles/r01_gemm_variants.txt)."""
+        """W^T copy of the FFN-down weight (bf16 mode): dz = dy.W2 then runs as y = x.W'^T with W' = W2^T k-contiguous,
+        the form the 256-row LDS-DMA kernel is fastest in (profiles/r01_gemm_variants.txt)."""
         if self.dt != MV_BF16:
             return
         H, I = self.cfg.hidden, self.cfg.intermediate
         for l in range(self.cfg.layers):
             p = f"enc.encoder.layer.{l}."
-            for key, W, (r, c) in ((p + "output.dense.weight", self.w[p + "output.dense.weight"], (H, I)),
-                                   (p + "intermediate.dense.weight", self.w[p + "intermediate.dense.weight"], (I, H)),
-                                   (p + "qkv", self.qkv_views(l)[0], (3 * H, H))):
+            # only the FFN-down weight: its input-gradient GEMM has the wide (3072-column) output the 256-row kernel is
+            # built for (238 vs 260 us at the packed row count); da and dx have 768-column outputs, where the
+            # contraction-major 128x128 kernel is as fast or faster (profiles/r01_gemm_variants.txt)
+            for key, W, (r, c) in ((p + "output.dense.weight", self.w[p + "output.dense.weight"], (H, I)),):
                 t = self.wT.get(key)
                 if t is None or t.device != W.device:
                     t = self.wT[key] = torch.empty((c, r), dtype=torch.bfloat16, device=W.device)
@@ -584,10 +585,7 @@ class Engine:
             with torch.cuda.stream(side):
                 ops.colsum(dz, I, M, I, g[p + "intermediate.dense.bias"], accumulate=True)
                 self._dW(dz, a_["a"], g[p + "intermediate.dense.weight"], I, H, M, lda=I, ldb=H)
-            if bf:
-                ops.gemm(dz, self.wT[p + "intermediate.dense.weight"], da, M=M, N=H, K=I, epi=EPI_RES, r=dpre2)
-            else:
-                ops.gemm(dz, self.w[p + "intermediate.dense.weight"], da, tb=True, M=M, N=H, K=I, epi=EPI_RES, r=dpre2)
+            ops.gemm(dz, self.w[p + "intermediate.dense.weight"], da, tb=True, M=M, N=H, K=I, epi=EPI_RES, r=dpre2)
             # LN1 backward (+ bias grad of attention.output.dense)
             ops.layernorm_bwd(da, a_["pre1"], a_["mean1"], a_["rstd1"], self.p[p + "attention.output.LayerNorm.weight"], dpre1,
                               g[p + "attention.output.LayerNorm.weight"], g[p + "attention.output.LayerNorm.bias"],
@@ -607,10 +605,7 @@ class Engine:
                 self._dW(dqkv, a_["x"], gWqkv, 3 * H, H, M, lda=3 * H, ldb=H)
                 ev_layer = side_done()
             dx = dxb[l & 1]          # never the buffer dy currently lives in
-            if bf:
-                ops.gemm(dqkv, self.wT[p + "qkv"], dx, M=M, N=H, K=3 * H, epi=EPI_RES, r=dpre1)
-            else:
-                ops.gemm(dqkv, Wqkv, dx, tb=True, M=M, N=H, K=3 * H, epi=EPI_RES, r=dpre1)
+            ops.gemm(dqkv, Wqkv, dx, tb=True, M=M, N=H, K=3 * H, epi=EPI_RES, r=dpre1)
             dy = dx
             if bucket_hook:
                 # LayerNorm / bias gradients of the layer were written on the main stream, the weights on the side stream
