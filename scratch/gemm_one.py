@@ -9,7 +9,7 @@ x=(torch.randn(M,H,device=dev)*0.5).to(torch.bfloat16); W1=(torch.randn(I,H,devi
 xi=(torch.randn(M,I,device=dev)*0.5).to(torch.bfloat16); W2=(torch.randn(H,I,device=dev)*0.5).to(torch.bfloat16)
 b1=torch.randn(I,device=dev); bh=torch.randn(H,device=dev)
 oI=torch.empty(M,I,device=dev,dtype=torch.bfloat16); oI2=torch.empty(M,I,device=dev,dtype=torch.bfloat16); oH=torch.empty(M,H,device=dev,dtype=torch.bfloat16)
-for _ in range(5):
+for _ in range(23):     # 3 warm-ups + 20 launches, like bench.py:time_dominant_kernel
     if which == "ffn1d": ops.gemm(x,W1,oI,M=M,N=I,K=H,bias=b1,epi=EPI_BIAS_GELU_D,c2=oI2)
     elif which == "ffn1": ops.gemm(x,W1,oI,M=M,N=I,K=H,bias=b1,epi=EPI_BIAS)
     elif which == "ffn2": ops.gemm(xi,W2,oH,M=M,N=H,K=I,bias=bh,epi=EPI_BIAS)
