@@ -461,6 +461,27 @@ def test_full_size_step_is_finite_repeatable_and_masks_pack_exactly():
     assert abs(float(st[0] / st[1]) - np.log(cfg.vocab_size)) < 0.5 and int(st[4]) == B
 
 
+def test_fused_training_overfits_a_fixed_batch():
+    """End-to-end behaviour of the fused step (bf16, dropout on, padding removal, HF AdamW): repeated steps on one
+    small batch must drive both losses down monotonically-ish -- a wrong gradient sign, a stale bf16 shadow / transposed
+    weight copy or a broken optimizer shows up here even when single-step parity passes."""
+    cfg = mv.ModelConfig(hidden=128, heads=2, intermediate=512, layers=2, vocab_size=1024, max_pos=128)
+    model = mv.CXRBERT(cfg, None, dtype=torch.bfloat16, device=DEV)
+    model.reset_parameters(seed=11)
+    model.train()
+    batch = mv.data.synthetic_batch(cfg.vocab_size, 8, 6, 60, "mixed", seed=4, device=DEV)
+    ts = mv.TrainStep(model, lr=1e-3)
+    hist = []
+    for _ in range(60):
+        st = ts(batch, train=True).cpu()
+        hist.append((float(st[0] / st[1]), float(st[3] / st[4])))
+    assert model.engine.S["cu"] is not None                      # the packed path was the one exercised
+    first = np.mean([h[0] for h in hist[:5]]), np.mean([h[1] for h in hist[:5]])
+    last = np.mean([h[0] for h in hist[-5:]]), np.mean([h[1] for h in hist[-5:]])
+    print("mlm / itm loss, first 5 steps:", first, "last 5:", last)
+    assert last[0] < 0.5 * first[0] and last[1] < 0.5 * first[1] and np.isfinite(hist[-1]).all()
+
+
 def test_graft_entry_smoke_runs():
     """The driver's round-end smoke check (forward + fused step of the tiny config against the oracle)."""
     import __graft_entry__ as g
