@@ -285,6 +285,11 @@ int mv_cast(const void* src, int src_dtype, void* dst, int dst_dtype, size_t n, 
 int mv_nchw_to_nhwc(const float* src, void* dst, int dst_dtype, int B, int C, int H, int W, int Cp, void* stream);
 int mv_im2col(int dtype, const void* src, int B, int H, int W, int C, int kh, int kw, int stride, int pad, void* dst, int ldk,
               void* stream);
+/* y[(b,oy,ox), o] = sum_{ky,kx,c} x[b, oy*stride-pad+ky, ox*stride-pad+kx, c] * w[o, (ky*kw + kx)*C + c]  (NHWC x, zero padding):
+ * the convolution as an implicit GEMM on the MFMA kernel -- the activation operand is gathered tap by tap while it is
+ * staged, no patch matrix is materialised.  bf16 x / w, y in y_dtype; C a power of two >= 8, O % 4 == 0.            */
+int mv_conv2d(int dtype, const void* x, const void* w, void* y, int y_dtype, int B, int H, int W, int C, int O, int kh, int kw,
+              int stride, int pad, void* stream);
 int mv_col_stats(int dtype, const void* x, int ldx, int rows, int C, float* stats, void* stream);
 int mv_bn_finalize(const float* stats, int C, long long rows, float eps, float momentum, float* mean, float* rstd,
                    float* running_mean, float* running_var, void* stream);

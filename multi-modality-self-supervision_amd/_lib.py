@@ -55,6 +55,7 @@ PROTOTYPES = {
     "mv_transpose": [i32, vp, i64, vp, i64, i32, i32, vp],
     "mv_nchw_to_nhwc": [vp, vp, i32, i32, i32, i32, i32, i32, vp],
     "mv_im2col": [i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp],
+    "mv_conv2d": [i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     "mv_col_stats": [i32, vp, i32, i32, i32, vp, vp],
     "mv_bn_finalize": [vp, i32, i64, f32, f32, vp, vp, vp, vp, vp],
     "mv_bn_act": [i32, vp, i32, vp, vp, vp, vp, vp, vp, i64, i32, i32, vp],

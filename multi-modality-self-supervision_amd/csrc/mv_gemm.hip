@@ -27,6 +27,9 @@ struct GemmArgs {
   unsigned bytesA, bytesB;
   DropCfg drop;   // MV_EPI_BIAS_RES only: C = dropout(A.B + bias) + R
   int dbg;   // ablation bits (timing experiments only): 1 skip C stores, 2 skip operand loads, 4 skip LDS reads + MFMA
+  // implicit convolution (mv_conv2d): A is an NHWC activation [B, cvH, cvW, cvC]; its logical row m = (b, oy, ox) and column
+  // k = (ky*cvKw + kx)*cvC + c are gathered from pixel (oy*stride - pad + ky, ox*stride - pad + kx), zero outside
+  int cvH, cvW, cvC, cvCshift, cvKw, cvStride, cvPad, cvHo, cvWo;
 };
 
 // ------------------------------------------------------------------------------------------
@@ -186,6 +189,38 @@ __device__ __forceinline__ void stage_load(u32x4 (&reg)[4], __amdgpu_buffer_rsrc
   }
 }
 
+// per-thread constants of the 4 activation rows a thread stages in the implicit-convolution form
+struct ConvRows { int pix[4]; int iy0[4], ix0[4]; bool on[4]; };
+__device__ __forceinline__ ConvRows conv_rows(const GemmArgs& p, int row0, int tid) {
+  ConvRows c;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int gr = row0 + ((tid + 256 * i) >> 3);
+    c.on[i] = gr < p.M;
+    const int hw = p.cvHo * p.cvWo;
+    const int b = gr / hw, rem = gr - b * hw;
+    const int oy = rem / p.cvWo, ox = rem - oy * p.cvWo;
+    c.iy0[i] = oy * p.cvStride - p.cvPad;
+    c.ix0[i] = ox * p.cvStride - p.cvPad;
+    c.pix[i] = b * p.cvH * p.cvW;              // first pixel of the image
+  }
+  return c;
+}
+__device__ __forceinline__ void stage_load_conv(u32x4 (&reg)[4], __amdgpu_buffer_rsrc_t rs, unsigned bytes, const GemmArgs& p,
+                                                const ConvRows& c, int k0, int kend, int tid) {
+  const int ch = tid & 7;
+  const int gk = k0 + ch * 8;                   // 8 consecutive channels of one filter tap (cvC % 8 == 0)
+  const int tap = gk >> p.cvCshift, cc = gk & (p.cvC - 1);
+  const int ky = tap / p.cvKw, kx = tap - ky * p.cvKw;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int iy = c.iy0[i] + ky, ix = c.ix0[i] + kx;
+    const bool ok = c.on[i] && gk < kend && iy >= 0 && iy < p.cvH && ix >= 0 && ix < p.cvW;
+    const unsigned off = ((unsigned)(c.pix[i] + iy * p.cvW + ix) * (unsigned)p.cvC + (unsigned)cc) * 2u;
+    reg[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? off : bytes, 0, 0);
+  }
+}
+
 template <bool TR>
 __device__ __forceinline__ void stage_store(const u32x4 (&reg)[4], char* tile, int tid) {
 #pragma unroll
@@ -214,7 +249,7 @@ __device__ __forceinline__ bf16x8 load_frag(const char* tile, int base, int ks, 
   }
 }
 
-template <bool TA, bool TB>
+template <bool TA, bool TB, bool CONV = false>
 __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -257,7 +292,10 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmArgs p) {
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   u32x4 ra[4], rb[4];
-  stage_load<TA>(ra, rsA, p.bytesA, p.lda, m0, p.M, kbeg, kend, tid);
+  ConvRows crow;
+  if constexpr (CONV) crow = conv_rows(p, m0, tid);
+  if constexpr (CONV) stage_load_conv(ra, rsA, p.bytesA, p, crow, kbeg, kend, tid);
+  else stage_load<TA>(ra, rsA, p.bytesA, p.lda, m0, p.M, kbeg, kend, tid);
   stage_load<TB>(rb, rsB, p.bytesB, p.ldb, n0, p.N, kbeg, kend, tid);
   stage_store<TA>(ra, smem, tid);
   stage_store<TB>(rb, smem + 16384, tid);
@@ -269,7 +307,8 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmArgs p) {
     const bool more = (kt + 1 < nk);
     if (more) {
       const int k0 = kbeg + (kt + 1) * GT_BK;
-      stage_load<TA>(ra, rsA, p.bytesA, p.lda, m0, p.M, k0, kend, tid);
+      if constexpr (CONV) stage_load_conv(ra, rsA, p.bytesA, p, crow, k0, kend, tid);
+      else stage_load<TA>(ra, rsA, p.bytesA, p.lda, m0, p.M, k0, kend, tid);
       stage_load<TB>(rb, rsB, p.bytesB, p.ldb, n0, p.N, k0, kend, tid);
     }
 #pragma unroll
@@ -1011,5 +1050,46 @@ extern "C" int mv_gemm(int dtype, int ta, int tb, int M, int N, int K, const voi
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, p);
     MV_CHECK_LAUNCH();
   }
+  return MV_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Convolution as an implicit GEMM: y[(b,oy,ox), o] = sum_{ky,kx,c} x[b, oy*s-pad+ky, ox*s-pad+kx, c] * w[o, (ky*kw+kx)*C + c].
+// The 128x128 kernel gathers the activation operand tap by tap while staging it (8 channels = 16 bytes per lane), so the
+// [rows, kh*kw*C] patch matrix of mv_im2col is never written.  Replaces torch's conv2d inside the ResNet-50 trunk of
+// models/image.py:46-55 (torchvision Bottleneck 3x3 / strided 1x1 convolutions and the 7x7 stem).
+extern "C" int mv_conv2d(int dtype, const void* x, const void* w, void* y, int y_dtype, int B, int H, int W, int C, int O, int kh, int kw,
+                         int stride, int pad, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!x || !w || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0 || O <= 0 || kh <= 0 || kw <= 0 || stride <= 0 || pad < 0) return MV_E_ARG;
+  if (dtype != MV_BF16 || g_mv_impl != 0) return MV_E_DTYPE;              // MFMA path only; other cases: mv_im2col + mv_gemm
+  if (y_dtype != MV_F32 && y_dtype != MV_BF16) return MV_E_DTYPE;
+  if ((C & 7) || (C & (C - 1)) || (O & 3)) return MV_E_SHAPE;             // 16-byte channel groups, power-of-two C, vector stores
+  const int Ho = (H + 2 * pad - kh) / stride + 1, Wo = (W + 2 * pad - kw) / stride + 1;
+  if (Ho <= 0 || Wo <= 0) return MV_E_SHAPE;
+  const long long rows = (long long)B * Ho * Wo;
+  const size_t bytesA = (size_t)B * H * W * C * 2, bytesB = (size_t)O * kh * kw * C * 2;
+  if (rows > 0x7fffffffLL || bytesA >= 0x7fffffffULL || bytesB >= 0x7fffffffULL) return MV_E_SHAPE;
+  if ((((uintptr_t)x) | ((uintptr_t)w)) & 15) return MV_E_SHAPE;
+  GemmArgs p{};
+  p.A = x; p.B = w; p.C = y;
+  p.M = (int)rows; p.N = O; p.K = kh * kw * C; p.lda = p.K; p.ldb = p.K; p.ldc = O;
+  p.c_dtype = y_dtype; p.epi = MV_EPI_NONE; p.splitk = 1; p.kchunk = (p.K + GT_BK - 1) / GT_BK * GT_BK;
+  p.bytesA = (unsigned)bytesA; p.bytesB = (unsigned)bytesB;
+  p.vec_ok = (((uintptr_t)y) % (y_dtype == MV_F32 ? 16 : 8)) == 0;
+  p.drop = mv_make_drop(0.f, 0);
+  p.cvH = H; p.cvW = W; p.cvC = C; p.cvKw = kw; p.cvStride = stride; p.cvPad = pad; p.cvHo = Ho; p.cvWo = Wo;
+  p.cvCshift = 0;
+  while ((1 << p.cvCshift) < C) ++p.cvCshift;
+  const long long tiles = ((rows + GT_BM - 1) / GT_BM) * ((O + GT_BN - 1) / GT_BN);
+  if (tiles > 0x7fffffffLL) return MV_E_SHAPE;
+  const size_t shm = 2 * GT_STAGE_BYTES;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)gemm_mfma_kernel<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_mfma_kernel<false, false, true>), dim3((unsigned)tiles, 1), dim3(256), shm, stream, p);
+  MV_CHECK_LAUNCH();
   return MV_OK;
 }

@@ -218,6 +218,13 @@ def im2col(src, dst, B, H, W, C, kh, kw, stride, pad, ldk):
     L.check(rc, "mv_im2col")
 
 
+def conv2d(x, w, y, B, H, W, C, O, kh, kw, stride, pad):
+    """implicit-GEMM convolution over NHWC x [B*H*W, C] with w [O, kh*kw*C] -> y [B*Ho*Wo, O] (see mv_conv2d)."""
+    L.require_cuda(x, w, y)
+    rc = _lib().mv_conv2d(L.dt_of(x), L.ptr(x), L.ptr(w), L.ptr(y), L.dt_of(y), B, H, W, C, O, kh, kw, stride, pad, L.stream_ptr())
+    L.check(rc, "mv_conv2d")
+
+
 def col_stats(x, ldx, rows, C, stats):
     L.require_cuda(x, stats)
     rc = _lib().mv_col_stats(L.dt_of(x), L.ptr(x), ldx, rows, C, L.ptr(stats), L.stream_ptr())

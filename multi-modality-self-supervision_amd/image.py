@@ -67,6 +67,7 @@ class ImageEncoder_cnn(nn.Module):
         self.adt = dtype
         self._wcache = {}
         self._bncache = {}
+        self.implicit_conv = True         # bf16 path: mv_conv2d instead of mv_im2col + mv_gemm (test switch)
 
     # ---- weights in GEMM layout: [Cout, kh*kw*Cin_padded], (ky, kx, c) order, compute dtype
     def _w2d(self, conv: nn.Conv2d, cin_pad: int):
@@ -90,12 +91,15 @@ class ImageEncoder_cnn(nn.Module):
         Ho, Wo = (H + 2 * pad - kh) // s + 1, (W + 2 * pad - kw) // s + 1
         w = self._w2d(conv, C)
         rows, K, O = B * Ho * Wo, w.shape[1], w.shape[0]
+        y = torch.empty((rows, O), dtype=self.adt, device=x.device)
         if kh == 1 and kw == 1 and s == 1:
-            a = x
+            a = x                                         # a 1x1 / stride-1 convolution is the GEMM over the activation matrix itself
+        elif self.adt == torch.bfloat16 and self.implicit_conv:
+            ops.conv2d(x, w, y, B, H, W, C, O, kh, kw, s, pad)        # taps gathered inside the GEMM's operand staging
+            return y, Ho, Wo
         else:
             a = torch.empty((rows, K), dtype=self.adt, device=x.device)
             ops.im2col(x, a, B, H, W, C, kh, kw, s, pad, K)
-        y = torch.empty((rows, O), dtype=self.adt, device=x.device)
         # mv_gemm addresses an operand through a 2-GiB buffer descriptor: large activation matrices go in row slabs
         step = max(256, ((1 << 31) - (1 << 20)) // (K * a.element_size()) // 256 * 256)
         for r0 in range(0, rows, step):

@@ -2,6 +2,8 @@
 torch.nn.functional restatement in oracle/resnet_oracle.py on the same torchvision-layout weights.
 Tolerances (relative L2; max-abs within 10x): fp32 path 2e-4 (exact fp32 arithmetic in another order, 53 convolutions
 deep); bf16 path 2e-2 against the restatement with the same bf16 rounding points."""
+import math
+
 import numpy as np
 import pytest
 import torch
@@ -129,3 +131,36 @@ def test_conv_support_kernels_against_torch():
     ops.col_stats(nhwc, C, B * H * W, C, st)
     xf = nhwc.float()
     assert torch.allclose(st[0], xf.sum(0), rtol=1e-5, atol=1e-4) and torch.allclose(st[1], (xf * xf).sum(0), rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("C,O,k,s,p,H,W", [(64, 64, 3, 1, 1, 20, 17), (128, 128, 3, 2, 1, 19, 22), (256, 512, 1, 2, 0, 14, 9),
+                                           (8, 64, 7, 2, 3, 37, 40), (512, 512, 3, 1, 1, 7, 5)])
+def test_implicit_gemm_convolution_against_torch(C, O, k, s, p, H, W):
+    """mv_conv2d (taps gathered while the MFMA kernel stages its operand) == conv2d on the same bf16 inputs, and ==
+    the materialised-patch path (mv_im2col + mv_gemm) it replaces."""
+    g = torch.Generator().manual_seed(C + O + k)
+    B = 3
+    x = torch.randn(B, C, H, W, generator=g).to(torch.bfloat16)
+    w = (torch.randn(O, C, k, k, generator=g) / math.sqrt(C * k * k)).to(torch.bfloat16)
+    ref = torch.nn.functional.conv2d(x.float(), w.float(), stride=s, padding=p)
+    Ho, Wo = ref.shape[2:]
+    xm = x.permute(0, 2, 3, 1).reshape(B * H * W, C).contiguous().to(DEV)
+    wm = w.permute(0, 2, 3, 1).reshape(O, k * k * C).contiguous().to(DEV)
+    y = torch.full((B * Ho * Wo + 1, O), 7.0, dtype=torch.float32, device=DEV)
+    ops.conv2d(xm, wm, y[:-1], B, H, W, C, O, k, k, s, p)
+    got = y[:-1].view(B, Ho, Wo, O).permute(0, 3, 1, 2).cpu()
+    assert float((got - ref).abs().max() / ref.abs().max()) < 2e-5 * math.sqrt(C * k * k) and bool((y[-1] == 7.0).all())
+    cols = torch.empty((B * Ho * Wo, k * k * C), dtype=torch.bfloat16, device=DEV)
+    ops.im2col(xm, cols, B, H, W, C, k, k, s, p, k * k * C)
+    y2 = torch.empty((B * Ho * Wo, O), dtype=torch.float32, device=DEV)
+    ops.gemm(cols, wm, y2, M=B * Ho * Wo, N=O, K=k * k * C)
+    assert float((y2 - y[:-1]).abs().max() / ref.abs().max()) < 1e-5
+
+
+def test_trunk_is_the_same_with_materialised_patches():
+    enc = _encoder(torch.bfloat16).eval()
+    x = torch.randn(2, 3, 96, 64, generator=torch.Generator().manual_seed(2)).to(DEV)
+    a, h, w = enc.trunk(x)
+    enc.implicit_conv = False
+    b, _, _ = enc.trunk(x)
+    assert float((a.float() - b.float()).norm() / b.float().norm()) < 2e-3
