@@ -175,6 +175,27 @@ def main():
     print(f"[bench] rank {rank}: {ms_per_step:.2f} ms/step", file=sys.stderr, flush=True)
     value = world * B * args.steps / dt
     st = stats.cpu()
+    packed = model.engine.S.get("cu") is not None
+    padded_ms = None
+    if packed:
+        # for transparency: the same step with padding removal switched off (every padded position computed, like the
+        # reference does), timed after the headline region on the same batches; reported as config.padded_*
+        step.pack_rows = False
+        n2 = max(2, min(args.steps, 5))
+        for i in range(2):
+            step(batches[i % len(batches)])
+        sync()
+        t1 = time.perf_counter()
+        for i in range(n2):
+            step(batches[i % len(batches)])
+        sync()
+        d2 = time.perf_counter() - t1
+        if world > 1:
+            t = torch.tensor([d2], dtype=torch.float64, device=dev)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            d2 = float(t[0])
+        padded_ms = d2 / n2 * 1e3
+        step.pack_rows = True
     if rank == 0:
         f_fwd = flops_fwd_per_sample(cfg.hidden, cfg.intermediate, cfg.vocab_size, cfg.img_hidden, cfg.layers, L, N)
         f_step = 3.0 * f_fwd
@@ -184,7 +205,6 @@ def main():
         # every valid query in the full / seq2seq families and carry no label)
         n_lab = float(st[1]) / B
         Hh, Ii, Vv = cfg.hidden, cfg.intermediate, cfg.vocab_size
-        packed = model.engine.S.get("cu") is not None
         vls = torch.cat([b_["attn_desc"].host_desc()[:, 2] for b_ in batches]).double() if packed else torch.full((1,), float(L)).double()
         rows_mean = float(vls.mean())
         f_enc = cfg.layers * (rows_mean * (8.0 * Hh * Hh + 4.0 * Hh * Ii) + 4.0 * float((vls * vls).mean()) * Hh)
@@ -199,6 +219,7 @@ def main():
                        "parallelism": f"dp{world}", "optimizer": "HF AdamW fused", "dropout": cfg.dropout,
                        "rows": (f"padding removed: encoder on the valid rows only (mean {rows_mean:.1f} of {L} positions per sample; "
                                 "results equal the padded run)") if packed else "padded",
+                       "padded_ms_per_step": padded_ms, "padded_pairs_per_s": (world * B / (padded_ms / 1e3)) if padded_ms else None,
                        "mlm_loss": float(st[0] / max(float(st[1]), 1.0)), "itm_loss": float(st[3] / max(float(st[4]), 1.0))},
             # dominant kernel (the FFN-up GEMM, largest single share of the step): algorithmic FLOPs per launch / its
             # average duration, HIP events around 20 launches on its own stream (time_dominant_kernel); traffic = HBM bytes
