@@ -99,7 +99,10 @@ class CXRBERT_Trainer:
         else:
             if config is None:
                 config = BERT_CONFIGS.get(getattr(args, "bert_model", "bert-base-scratch"), BERT_CONFIGS["bert-base-scratch"])
-            self.model = CXRBERT(config, args, dtype=dtype, device=self.device)
+            # cxrbert_origin.py:59-65: anything but 'ViT' is the ResNet-50 region encoder; it is only built when the loader
+            # will hand over pixels (args.pixels / an explicit request), since feature batches never touch it
+            want_cnn = bool(getattr(args, "pixels", False)) and getattr(args, "img_encoder", "random-pixel") != "ViT"
+            self.model = CXRBERT(config, args, dtype=dtype, device=self.device, img_encoder="resnet50" if want_cnn else None)
         self.train_data, self.test_data = train_dataloader, test_dataloader
         self.distributed = torch.distributed.is_available() and torch.distributed.is_initialized() \
             and torch.distributed.get_world_size() > 1
@@ -111,9 +114,13 @@ class CXRBERT_Trainer:
         self.logger = logger            # optional callable(dict, step=epoch): stands in for wandb.log
         print("Total Parameters:", sum(p.nelement() for p in self.model.parameters()))
 
-    @staticmethod
-    def _to_batch(data):
+    def _to_batch(self, data):
         cls_tok, input_ids, txt_labels, attn_masks, img, segment, is_aligned, sep_tok = data[:8]
+        if torch.is_tensor(img):     # pixels [B,3,H,W] (dataset_origin.py:85-89): region features from the mirrored CNN
+            if self.model.img_encoder is None:
+                raise TypeError("the loader yields pixels: construct the trainer with args.pixels=True (ResNet-50 region encoder)")
+            with torch.no_grad():
+                img = self.model.img_encoder(img.to(self.device))
         feats, pos = img            # (region feats [B,N,2048], region positions [B,N])
         return dict(cls_tok=cls_tok, input_txt=input_ids, attn_mask=attn_masks, segment=segment, img_feats=feats, img_pos=pos,
                     sep_tok=sep_tok, txt_labels=txt_labels, is_aligned=is_aligned)

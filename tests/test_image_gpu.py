@@ -164,3 +164,18 @@ def test_trunk_is_the_same_with_materialised_patches():
     enc.implicit_conv = False
     b, _, _ = enc.trunk(x)
     assert float((a.float() - b.float()).norm() / b.float().norm()) < 2e-3
+
+
+def test_trainer_consumes_pixel_batches():
+    """main_origin.py's loop with the Dataset's real 9-tuple (pixels in slot 4): the trainer runs the region encoder."""
+    from types import SimpleNamespace
+    V, B, N, S = 1024, 2, 4, 20
+    args = SimpleNamespace(num_image_embeds=N, lr=1e-4, pixels=True, img_encoder="random-pixel", bert_model="x")
+    cfg = dict(vocab_size=V, hidden_size=128, num_hidden_layers=1, num_attention_heads=2, intermediate_size=512, max_position_embeddings=64)
+    b = mv.data.synthetic_batch(V, B, N, S, "full", seed=2, device="cpu")
+    px = torch.randn(B, 3, 64, 64, generator=torch.Generator().manual_seed(1))
+    loader = [(b["cls_tok"], b["input_txt"], b["txt_labels"], b["attn_mask"], px, b["segment"], b["is_aligned"], b["sep_tok"], None)]
+    tr = mv.CXRBERT_Trainer(args, train_dataloader=loader, test_dataloader=None, config=cfg)
+    assert isinstance(tr.model.img_encoder, mv.ImageEncoder_cnn)
+    out = tr.train(0)
+    assert np.isfinite(out["avg_loss"])
