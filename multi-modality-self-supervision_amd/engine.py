@@ -242,7 +242,13 @@ class Engine:
         t = self._ws.get(key)
         n = math.prod(shape)
         if t is None or t.numel() < n or t.dtype != dtype:
-            t = torch.empty(n, dtype=dtype, device=self.device)
+            # packed rows: the row count changes from batch to batch -- allocate row-shaped scratch for the padded row count
+            # once instead of growing it whenever a longer batch comes by
+            cap = n
+            rows, rows_cap = getattr(self, "_rows_now", 0), getattr(self, "_rows_cap", 0)
+            if rows_cap > rows > 0 and len(shape) > 0 and shape[0] == rows:
+                cap = n // rows * rows_cap
+            t = torch.empty(cap, dtype=dtype, device=self.device)
             self._ws[key] = t
         return t[:n].view(shape)
 
@@ -290,6 +296,7 @@ class Engine:
             M = int(hd[:, 2].clamp(0, Lq).sum())
             S["cu"], S["rowmap"], S["inv"] = ops.pack_plan(attn_mask.desc.to(dev), B, Lq)
             S["M"] = M
+        self._rows_now, self._rows_cap = M, B * Lq
         cu, rowmap = S["cu"], S["rowmap"]
         pd = S["p_drop"] = float(cfg.dropout) if self.training else 0.0
         self.drop_counter += 1
