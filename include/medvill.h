@@ -238,7 +238,8 @@ int mv_ce_fwd_bwd(const void* logits, int l_dtype, int ld, const int32_t* labels
                   const float* grad_scale_dev, float grad_scale_host, void* stream);
 
 /* ---- row gather / scatter (labelled-row compaction for the MLM head) ------------------------
- * dst[i,:] = src[rows[i],:]  /  dst[rows[i],:] (+)= src[i,:]; rows int32 [R].                 */
+ * dst[i,:] = src[rows[i],:]  /  dst[rows[i],:] (+)= src[i,:]; rows int32 [R].  A negative rows[i] means "no such
+ * row" (a position dropped by mv_pack_plan): gather writes zeros, scatter writes nothing.          */
 int mv_gather_rows(int dtype, const void* src, int lds, const int32_t* rows, int R, int H,
                    void* dst, int ldd, void* stream);
 int mv_scatter_rows(int dtype, const void* src, int lds, const int32_t* rows, int R, int H,

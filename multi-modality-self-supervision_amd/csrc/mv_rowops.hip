@@ -579,8 +579,13 @@ __global__ void gather_rows_kernel(const T* __restrict__ src, int lds_, const in
   const int lane = threadIdx.x & 63;
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= R) return;
-  const T* s = src + (size_t)rows[r] * lds_;
+  const int sr = rows[r];
   T* d = dst + (size_t)r * ldd;
+  if (sr < 0) {        // "no such row" (e.g. a position dropped by the packed-row plan): defined output, never a wild read
+    for (int c = lane * 4; c < H; c += 256) st4<T>(d + c, (f32x4){0.f, 0.f, 0.f, 0.f});
+    return;
+  }
+  const T* s = src + (size_t)sr * lds_;
   for (int c = lane * 4; c < H; c += 256) st4<T>(d + c, ld4<T>(s + c));
 }
 template <typename T>
@@ -588,7 +593,7 @@ __global__ void scatter_rows_kernel(const T* __restrict__ src, int lds_, const i
                                     T* __restrict__ dst, int ldd, int accumulate) {
   const int lane = threadIdx.x & 63;
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (r >= R) return;
+  if (r >= R || rows[r] < 0) return;      // negative row index = no such row: nothing is written
   const T* s = src + (size_t)r * lds_;
   T* d = dst + (size_t)rows[r] * ldd;
   for (int c = lane * 4; c < H; c += 256) {

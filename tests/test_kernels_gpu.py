@@ -548,6 +548,17 @@ def test_transpose(dt, rows, cols):
     assert torch.equal(y[:, :rows], x[:, :cols].t()) and bool((y[:, rows:] == 9.0).all())
 
 
+def test_gather_scatter_skip_negative_rows():
+    src = rnd((6, 8), torch.bfloat16, 3)
+    rows = torch.tensor([4, -1, 0], dtype=torch.int32, device=DEV)
+    dst = torch.full((3, 8), 9.0, dtype=torch.bfloat16, device=DEV)
+    ops.gather_rows(src, 8, rows, 3, 8, dst, 8)
+    assert torch.equal(dst[0], src[4]) and torch.equal(dst[2], src[0]) and bool((dst[1] == 0).all())
+    out = torch.full((6, 8), 5.0, dtype=torch.bfloat16, device=DEV)
+    ops.scatter_rows(dst, 8, rows, 3, 8, out, 8, accumulate=False)
+    assert torch.equal(out[4], dst[0]) and torch.equal(out[0], dst[2]) and bool((out[[1, 2, 3, 5]] == 5.0).all())
+
+
 def test_adamw_known_answer(golden_dir):
     """HF-AdamW KAT (tests/golden/adamw.npz, computed with python floats) on the fused kernel."""
     import os
