@@ -30,6 +30,17 @@ class CXRBertForRetrieval(nn.Module):
         return torch.nn.functional.linear(pooled.float(), w, b)      # [B,H] x [H,2]: plumbing-sized
 
     @torch.no_grad()
-    def score(self, *batch):
-        """P(aligned) per pair, as full_dset_retrieval.py:461-510 ranks candidates."""
-        return torch.softmax(self.forward(*batch), dim=-1)[:, 1]
+    def score(self, cls_tok, input_txt, attn_mask, segment, input_img, sep_tok):
+        """P(aligned) per pair, as full_dset_retrieval.py:461-510 ranks candidates.  When `attn_mask` is a
+        `data.MaskDesc` of a family whose padding is invisible (the retrieval scripts' 1-D masks are), the encoder runs
+        on the valid rows only (inference form of the padding removal)."""
+        from .data import MaskDesc
+        eng = self.bert.engine
+        if isinstance(attn_mask, MaskDesc) and eng.adt == torch.bfloat16 and attn_mask.packable():
+            feats, pos = self.bert._regions(input_img)
+            eng.training = False
+            eng.encoder_forward(cls_tok, input_txt, attn_mask, segment, feats, pos, sep_tok, pack=True)
+            logits = eng._itm_forward().clone()
+        else:
+            logits = self.forward(cls_tok, input_txt, attn_mask, segment, input_img, sep_tok)
+        return torch.softmax(logits.float(), dim=-1)[:, 1]

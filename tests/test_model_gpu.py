@@ -482,6 +482,21 @@ def test_fused_training_overfits_a_fixed_batch():
     assert last[0] < 0.5 * first[0] and last[1] < 0.5 * first[1] and np.isfinite(hist[-1]).all()
 
 
+def test_retrieval_scores_on_packed_rows_equal_the_padded_ones():
+    cfg = mv.ModelConfig(hidden=128, heads=2, intermediate=512, layers=2, vocab_size=1024, max_pos=128)
+    r = mv.CXRBertForRetrieval(cfg, None, dtype=torch.bfloat16, device=DEV).eval()
+    r.bert.reset_parameters(seed=8)
+    B, N, S = 6, 6, 50
+    b = mv.data.synthetic_batch(cfg.vocab_size, B, N, S, "1d", seed=12, device=DEV)
+    assert b["attn_mask"].dim() == 2 and b["attn_desc"].packable()
+    args = (b["cls_tok"], b["input_txt"])
+    rest = (b["segment"], (b["img_feats"], b["img_pos"]), b["sep_tok"])
+    padded = r.score(*args, b["attn_mask"], *rest)
+    packed = r.score(*args, b["attn_desc"], *rest)
+    assert r.bert.engine.S["cu"] is not None and r.bert.engine.S["M"] < B * (N + S + 3)
+    assert float((padded - packed).abs().max()) < 1e-4      # the ITM linear runs in fp32 (torch) on one path, bf16 MFMA on the other
+
+
 def test_graft_entry_smoke_runs():
     """The driver's round-end smoke check (forward + fused step of the tiny config against the oracle)."""
     import __graft_entry__ as g
