@@ -131,3 +131,39 @@ def test_downstream_checkpoint_key_maps():
     assert "bert.txt_embeddings.word_embeddings.weight" in dec and "bert.encoder.layer.1.output.dense.bias" in dec
     assert "bert.img_embeddings.img_embeddings.weight" in dec and "bert.pooler.dense.weight" in dec
     assert "cls.predictions.bias" in dec
+
+
+def test_mask_descriptors_know_when_padding_is_invisible():
+    """data.MaskDesc.packable: padding removal is offered for the full / seq2seq / 1-D families only, per batch."""
+    n_ids = torch.tensor([5, 9, 3])
+    for fam, ok in (("full", True), ("s2s", True), ("1d", True), ("bar", False), ("noncross", False)):
+        d = mv.data.MaskDesc.make(fam, 4, 10, n_ids)
+        assert d.packable() is ok and d.host_desc().tolist() == [[mv.data.FAMILY_ID[fam], 6, 6 + int(n)] for n in n_ids]
+    mixed = mv.data.MaskDesc.make(["full", "s2s", "bar"], 4, 10, n_ids)
+    assert not mixed.packable() and mixed[:2].packable() and len(mixed[1:]) == 2
+    # the closed forms behind the claim: in the packable families no valid query row has a visible key at or after vl
+    for fam in ("full", "s2s", "1d"):
+        for n in (1, 4, 11):
+            m = D.mask_predicate(fam, 4, 10, n)
+            vl = 6 + n
+            rows = m[None, :] if m.ndim == 1 else m[:vl]
+            assert not rows[:, vl:].any(), (fam, n)
+    for fam in ("bar", "noncross"):
+        m = D.mask_predicate(fam, 4, 10, 4)
+        assert m[:10, 10:].any()                          # valid queries do see padding there
+
+
+def test_region_encoder_container_matches_torchvision_layout():
+    """ImageEncoder_cnn holds exactly the parameters / buffers of torchvision's resnet50 children()[:-2] under the
+    reference's `model.<idx>` names (models/image.py:50-52), all frozen (cxrbert_origin.py:66-70 unfreezes nothing)."""
+    enc = mv.ImageEncoder_cnn(num_image_embeds=9)
+    sd = enc.state_dict()
+    convs = [k for k in sd if k.endswith(".weight") and sd[k].dim() == 4]
+    assert len(convs) == 53 and sum(v.numel() for k, v in sd.items() if sd[k].dim() in (1, 4) and "running" not in k) == 23508032
+    assert sd["model.0.weight"].shape == (64, 3, 7, 7) and sd["model.4.0.downsample.0.weight"].shape == (256, 64, 1, 1)
+    assert sd["model.5.0.conv2.weight"].shape == (128, 128, 3, 3) and enc.model[5][0].conv2.stride == (2, 2)
+    assert sd["model.7.2.bn3.running_var"].shape == (2048,) and "model.1.num_batches_tracked" in sd
+    assert not any(p.requires_grad for p in enc.parameters())
+    from oracle import resnet_oracle as R
+    y = R.trunk({k: v.float() for k, v in sd.items()}, torch.zeros(1, 3, 64, 64), training=False)
+    assert y.shape == (1, 2048, 2, 2)
