@@ -58,7 +58,9 @@ enum {
   MV_EPI_BIAS_TANH = 6, /* C = tanh(A.B + bias)         HF BertPooler, cxrbert_origin.py:130            */
   MV_EPI_BIAS_GELU_D = 7, /* Z = A.B + bias; C = gelu_erf(Z); C2 = gelu_erf'(Z): the derivative shares the forward's exp and
                              reciprocal, so the backward GEMM only multiplies (MV_EPI_MUL) and Z itself is never stored */
-  MV_EPI_MUL = 8        /* C = (A.B) * R[m,n]           (backward of MV_EPI_BIAS_GELU_D; R = saved gelu')  */
+  MV_EPI_MUL = 8,       /* C = (A.B) * R[m,n]           (backward of MV_EPI_BIAS_GELU_D; R = saved gelu')  */
+  MV_EPI_BIAS_RELU = 9,      /* C = max(A.B + bias[n], 0)            convolution + folded BatchNorm + ReLU (region encoder, eval()) */
+  MV_EPI_BIAS_RES_RELU = 10  /* C = max(A.B + bias[n] + R[m,n], 0)   ... + the bottleneck's identity branch                          */
 };
 
 /* implementation selector (test hook): 0 = auto (MFMA for bf16, VALU for f32), 1 = force the
@@ -288,9 +290,10 @@ int mv_im2col(int dtype, const void* src, int B, int H, int W, int C, int kh, in
               void* stream);
 /* y[(b,oy,ox), o] = sum_{ky,kx,c} x[b, oy*stride-pad+ky, ox*stride-pad+kx, c] * w[o, (ky*kw + kx)*C + c]  (NHWC x, zero padding):
  * the convolution as an implicit GEMM on the MFMA kernel -- the activation operand is gathered tap by tap while it is
- * staged, no patch matrix is materialised.  bf16 x / w, y in y_dtype; C a power of two >= 8, O % 4 == 0.            */
+ * staged, no patch matrix is materialised.  bf16 x / w, y in y_dtype; C a power of two >= 8, O % 4 == 0.
+ * epi: MV_EPI_NONE, MV_EPI_BIAS, MV_EPI_BIAS_RELU or MV_EPI_BIAS_RES_RELU (R [rows, O], leading dimension O).          */
 int mv_conv2d(int dtype, const void* x, const void* w, void* y, int y_dtype, int B, int H, int W, int C, int O, int kh, int kw,
-              int stride, int pad, void* stream);
+              int stride, int pad, const float* bias, int epi, const void* R, int r_dtype, void* stream);
 int mv_col_stats(int dtype, const void* x, int ldx, int rows, int C, float* stats, void* stream);
 int mv_bn_finalize(const float* stats, int C, long long rows, float eps, float momentum, float* mean, float* rstd,
                    float* running_mean, float* running_var, void* stream);

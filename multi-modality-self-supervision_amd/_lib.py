@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libmedvill_hip.so")
 
 MV_F32, MV_BF16 = 0, 1
-EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RES, EPI_DGELU, EPI_RES, EPI_BIAS_TANH, EPI_BIAS_GELU_D, EPI_MUL = range(9)
+EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RES, EPI_DGELU, EPI_RES, EPI_BIAS_TANH, EPI_BIAS_GELU_D, EPI_MUL, EPI_BIAS_RELU, EPI_BIAS_RES_RELU = range(11)
 _ERR = {-1: "MV_E_ARG (null pointer / bad size)", -2: "MV_E_SHAPE (unsupported shape or alignment)",
         -3: "MV_E_DTYPE", -4: "MV_E_WORKSPACE (workspace too small)"}
 
@@ -55,7 +55,7 @@ PROTOTYPES = {
     "mv_transpose": [i32, vp, i64, vp, i64, i32, i32, vp],
     "mv_nchw_to_nhwc": [vp, vp, i32, i32, i32, i32, i32, i32, vp],
     "mv_im2col": [i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp],
-    "mv_conv2d": [i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
+    "mv_conv2d": [i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp, i32, vp],
     "mv_col_stats": [i32, vp, i32, i32, i32, vp, vp],
     "mv_bn_finalize": [vp, i32, i64, f32, f32, vp, vp, vp, vp, vp],
     "mv_bn_act": [i32, vp, i32, vp, vp, vp, vp, vp, vp, i64, i32, i32, vp],

@@ -44,13 +44,15 @@ __device__ __forceinline__ void epilogue4_slow(const GemmArgs& p, int m, int n, 
     float x = v[i];
     const int e = p.epi;
     float b = 0.f, r = 0.f;
-    if (e == MV_EPI_BIAS || e == MV_EPI_BIAS_GELU || e == MV_EPI_BIAS_RES || e == MV_EPI_BIAS_TANH || e == MV_EPI_BIAS_GELU_D) b = p.bias[n + i];
-    if (e == MV_EPI_BIAS_RES || e == MV_EPI_DGELU || e == MV_EPI_RES || e == MV_EPI_MUL) r = ld_any(p.R, (size_t)m * p.ldr + n + i, p.r_dtype);
+    if (e == MV_EPI_BIAS || e == MV_EPI_BIAS_GELU || e == MV_EPI_BIAS_RES || e == MV_EPI_BIAS_TANH || e == MV_EPI_BIAS_GELU_D || e == MV_EPI_BIAS_RELU || e == MV_EPI_BIAS_RES_RELU) b = p.bias[n + i];
+    if (e == MV_EPI_BIAS_RES || e == MV_EPI_DGELU || e == MV_EPI_RES || e == MV_EPI_MUL || e == MV_EPI_BIAS_RES_RELU) r = ld_any(p.R, (size_t)m * p.ldr + n + i, p.r_dtype);
     switch (e) {
       case MV_EPI_BIAS: x += b; break;
       case MV_EPI_BIAS_GELU: x += b; break;
       case MV_EPI_BIAS_GELU_D: x += b; break;
       case MV_EPI_MUL: x *= r; break;
+      case MV_EPI_BIAS_RELU: x = fmaxf(x + b, 0.f); break;
+      case MV_EPI_BIAS_RES_RELU: x = fmaxf(x + b + r, 0.f); break;
       case MV_EPI_BIAS_RES:
         x += b;
         if (p.drop.thr) x = mv_drop1(x, (size_t)m * p.N + n + i, p.drop);
@@ -86,7 +88,7 @@ template <int E>
 __device__ __forceinline__ f32x4 epi_load_res4(const GemmArgs& p, int m, int n) {
   f32x4 r = {0.f, 0.f, 0.f, 0.f};
   if (m >= p.M) return r;
-  if (E == MV_EPI_BIAS_RES || E == MV_EPI_DGELU || E == MV_EPI_RES || E == MV_EPI_MUL) {
+  if (E == MV_EPI_BIAS_RES || E == MV_EPI_DGELU || E == MV_EPI_RES || E == MV_EPI_MUL || E == MV_EPI_BIAS_RES_RELU) {
     const size_t ro = (size_t)m * p.ldr + n;
     r = (p.r_dtype == MV_F32) ? ld4<float>((const float*)p.R + ro) : ld4<bf16_t>((const bf16_t*)p.R + ro);
   } else if (E == MV_EPI_NONE) {
@@ -99,15 +101,19 @@ __device__ __forceinline__ void epilogue4v(const GemmArgs& p, int m, int n, f32x
   if (m >= p.M) return;
   const size_t co = (size_t)m * p.ldc + n;
   f32x4 o = v;
-  if (E == MV_EPI_BIAS || E == MV_EPI_BIAS_GELU || E == MV_EPI_BIAS_RES || E == MV_EPI_BIAS_TANH || E == MV_EPI_BIAS_GELU_D) o += b4;
+  if (E == MV_EPI_BIAS || E == MV_EPI_BIAS_GELU || E == MV_EPI_BIAS_RES || E == MV_EPI_BIAS_TANH || E == MV_EPI_BIAS_GELU_D || E == MV_EPI_BIAS_RELU || E == MV_EPI_BIAS_RES_RELU) o += b4;
   if (E == MV_EPI_BIAS_RES && p.drop.thr) o = mv_drop4(o, (size_t)m * p.N + n, p.drop);
   if (E == MV_EPI_DGELU) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) o[i] *= dgelu_erf(r[i]);
   } else if (E == MV_EPI_MUL) {
     o *= r;
-  } else if (E == MV_EPI_BIAS_RES || E == MV_EPI_RES || E == MV_EPI_NONE) {
+  } else if (E == MV_EPI_BIAS_RES || E == MV_EPI_RES || E == MV_EPI_NONE || E == MV_EPI_BIAS_RES_RELU) {
     o += r;
+  }
+  if (E == MV_EPI_BIAS_RELU || E == MV_EPI_BIAS_RES_RELU) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = fmaxf(o[i], 0.f);
   }
   if (E == MV_EPI_BIAS_TANH) {
 #pragma unroll
@@ -141,6 +147,8 @@ __device__ __forceinline__ void epilogue4v(const GemmArgs& p, int m, int n, f32x
     case MV_EPI_BIAS_TANH: BODY(MV_EPI_BIAS_TANH); break;  \
     case MV_EPI_BIAS_GELU_D: BODY(MV_EPI_BIAS_GELU_D); break; \
     case MV_EPI_MUL: BODY(MV_EPI_MUL); break;              \
+    case MV_EPI_BIAS_RELU: BODY(MV_EPI_BIAS_RELU); break;  \
+    case MV_EPI_BIAS_RES_RELU: BODY(MV_EPI_BIAS_RES_RELU); break; \
     default: BODY(MV_EPI_NONE); break;                     \
   }
 
@@ -350,7 +358,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmArgs p) {
       fast[j] = p.vec_ok && (p.N - n >= 4);                                                                   \
       b4[j] = (f32x4){0.f, 0.f, 0.f, 0.f}; rc[j] = b4[j]; rn[j] = b4[j];                                      \
       if (fast[j]) {                                                                                          \
-        if (E_ == MV_EPI_BIAS || E_ == MV_EPI_BIAS_GELU || E_ == MV_EPI_BIAS_RES || E_ == MV_EPI_BIAS_TANH || E_ == MV_EPI_BIAS_GELU_D)    \
+        if (E_ == MV_EPI_BIAS || E_ == MV_EPI_BIAS_GELU || E_ == MV_EPI_BIAS_RES || E_ == MV_EPI_BIAS_TANH || E_ == MV_EPI_BIAS_GELU_D || E_ == MV_EPI_BIAS_RELU || E_ == MV_EPI_BIAS_RES_RELU)    \
           b4[j] = *(const f32x4*)(p.bias + n);                                                                \
         rc[j] = epi_load_res4<E_>(p, m0 + wm + l15, n);                                                       \
       }                                                                                                       \
@@ -457,12 +465,12 @@ __device__ __forceinline__ bf16x8 g2_frag(const char* tile, int base, int l15, i
 #define G2_EPI_BODY(E_)                                                                                        \
   {                                                                                                            \
     constexpr int EE = (E_) < 0 ? 0 : (E_);                                                                    \
-    constexpr bool HAS_R = (E_) == MV_EPI_BIAS_RES || (E_) == MV_EPI_RES || (E_) == MV_EPI_MUL || (E_) == MV_EPI_DGELU; \
+    constexpr bool HAS_R = (E_) == MV_EPI_BIAS_RES || (E_) == MV_EPI_RES || (E_) == MV_EPI_MUL || (E_) == MV_EPI_DGELU || (E_) == MV_EPI_BIAS_RES_RELU; \
     const int ncol = n0 + wn + c4 * 4;                                                                         \
     const bool lane_fast = ((E_) >= 0) && col_on && p.vec_ok && (p.N - ncol >= 4);                             \
     f32x4 b4 = {0.f, 0.f, 0.f, 0.f};                                                                           \
     if (lane_fast && (EE == MV_EPI_BIAS || EE == MV_EPI_BIAS_GELU || EE == MV_EPI_BIAS_RES || EE == MV_EPI_BIAS_TANH || \
-                      EE == MV_EPI_BIAS_GELU_D))                                                               \
+                      EE == MV_EPI_BIAS_GELU_D || EE == MV_EPI_BIAS_RELU || EE == MV_EPI_BIAS_RES_RELU))                                                               \
       b4 = *(const f32x4*)(p.bias + ncol);                                                                     \
     if (HAS_R && __all(lane_fast || !col_on)) {                                                                \
       /* residual operand: a tile's worth comes from HBM, so G2_RG 16-row groups of row loads are kept in flight \
@@ -880,9 +888,9 @@ extern "C" int mv_gemm(int dtype, int ta, int tb, int M, int N, int K, const voi
   if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) return MV_E_ARG;
   if (dtype != MV_F32 && dtype != MV_BF16) return MV_E_DTYPE;
   if (c_dtype != MV_F32 && c_dtype != MV_BF16) return MV_E_DTYPE;
-  if (epi < 0 || epi > MV_EPI_MUL) return MV_E_ARG;
-  const bool need_bias = (epi == MV_EPI_BIAS || epi == MV_EPI_BIAS_GELU || epi == MV_EPI_BIAS_RES || epi == MV_EPI_BIAS_TANH || epi == MV_EPI_BIAS_GELU_D);
-  const bool need_r = (epi == MV_EPI_BIAS_RES || epi == MV_EPI_DGELU || epi == MV_EPI_RES || epi == MV_EPI_MUL);
+  if (epi < 0 || epi > MV_EPI_BIAS_RES_RELU) return MV_E_ARG;
+  const bool need_bias = (epi == MV_EPI_BIAS || epi == MV_EPI_BIAS_GELU || epi == MV_EPI_BIAS_RES || epi == MV_EPI_BIAS_TANH || epi == MV_EPI_BIAS_GELU_D || epi == MV_EPI_BIAS_RELU || epi == MV_EPI_BIAS_RES_RELU);
+  const bool need_r = (epi == MV_EPI_BIAS_RES || epi == MV_EPI_DGELU || epi == MV_EPI_RES || epi == MV_EPI_MUL || epi == MV_EPI_BIAS_RES_RELU);
   if (need_bias && !bias) return MV_E_ARG;
   if (need_r && (!R || (r_dtype != MV_F32 && r_dtype != MV_BF16))) return MV_E_ARG;
   if ((epi == MV_EPI_BIAS_GELU || epi == MV_EPI_BIAS_GELU_D) && !C2) return MV_E_ARG;
@@ -1059,11 +1067,14 @@ extern "C" int mv_gemm(int dtype, int ta, int tb, int M, int N, int K, const voi
 // [rows, kh*kw*C] patch matrix of mv_im2col is never written.  Replaces torch's conv2d inside the ResNet-50 trunk of
 // models/image.py:46-55 (torchvision Bottleneck 3x3 / strided 1x1 convolutions and the 7x7 stem).
 extern "C" int mv_conv2d(int dtype, const void* x, const void* w, void* y, int y_dtype, int B, int H, int W, int C, int O, int kh, int kw,
-                         int stride, int pad, void* stream_) {
+                         int stride, int pad, const float* bias, int epi, const void* R, int r_dtype, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!x || !w || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0 || O <= 0 || kh <= 0 || kw <= 0 || stride <= 0 || pad < 0) return MV_E_ARG;
   if (dtype != MV_BF16 || g_mv_impl != 0) return MV_E_DTYPE;              // MFMA path only; other cases: mv_im2col + mv_gemm
   if (y_dtype != MV_F32 && y_dtype != MV_BF16) return MV_E_DTYPE;
+  if (epi != MV_EPI_NONE && epi != MV_EPI_BIAS && epi != MV_EPI_BIAS_RELU && epi != MV_EPI_BIAS_RES_RELU) return MV_E_ARG;
+  if (epi != MV_EPI_NONE && !bias) return MV_E_ARG;
+  if (epi == MV_EPI_BIAS_RES_RELU && (!R || (r_dtype != MV_F32 && r_dtype != MV_BF16))) return MV_E_ARG;
   if ((C & 7) || (C & (C - 1)) || (O & 3)) return MV_E_SHAPE;             // 16-byte channel groups, power-of-two C, vector stores
   const int Ho = (H + 2 * pad - kh) / stride + 1, Wo = (W + 2 * pad - kw) / stride + 1;
   if (Ho <= 0 || Wo <= 0) return MV_E_SHAPE;
@@ -1074,9 +1085,11 @@ extern "C" int mv_conv2d(int dtype, const void* x, const void* w, void* y, int y
   GemmArgs p{};
   p.A = x; p.B = w; p.C = y;
   p.M = (int)rows; p.N = O; p.K = kh * kw * C; p.lda = p.K; p.ldb = p.K; p.ldc = O;
-  p.c_dtype = y_dtype; p.epi = MV_EPI_NONE; p.splitk = 1; p.kchunk = (p.K + GT_BK - 1) / GT_BK * GT_BK;
+  p.bias = bias; p.R = R; p.r_dtype = r_dtype; p.ldr = O;
+  p.c_dtype = y_dtype; p.epi = epi; p.splitk = 1; p.kchunk = (p.K + GT_BK - 1) / GT_BK * GT_BK;
   p.bytesA = (unsigned)bytesA; p.bytesB = (unsigned)bytesB;
-  p.vec_ok = (((uintptr_t)y) % (y_dtype == MV_F32 ? 16 : 8)) == 0;
+  p.vec_ok = (((uintptr_t)y) % (y_dtype == MV_F32 ? 16 : 8)) == 0 && (!bias || (((uintptr_t)bias) & 15) == 0) &&
+             (!R || (((uintptr_t)R) % (r_dtype == MV_F32 ? 16 : 8)) == 0);
   p.drop = mv_make_drop(0.f, 0);
   p.cvH = H; p.cvW = W; p.cvC = C; p.cvKw = kw; p.cvStride = stride; p.cvPad = pad; p.cvHo = Ho; p.cvWo = Wo;
   p.cvCshift = 0;

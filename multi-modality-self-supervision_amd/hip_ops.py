@@ -5,7 +5,8 @@ from __future__ import annotations
 import torch
 
 from . import _lib as L
-from ._lib import (EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_GELU_D, EPI_BIAS_RES, EPI_BIAS_TANH, EPI_DGELU, EPI_MUL, EPI_NONE, EPI_RES, MV_BF16,  # noqa: F401
+from ._lib import (EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_GELU_D, EPI_BIAS_RELU, EPI_BIAS_RES, EPI_BIAS_RES_RELU, EPI_BIAS_TANH, EPI_DGELU,  # noqa: F401
+                   EPI_MUL, EPI_NONE, EPI_RES, MV_BF16,
                    MV_F32)
 
 
@@ -218,10 +219,11 @@ def im2col(src, dst, B, H, W, C, kh, kw, stride, pad, ldk):
     L.check(rc, "mv_im2col")
 
 
-def conv2d(x, w, y, B, H, W, C, O, kh, kw, stride, pad):
+def conv2d(x, w, y, B, H, W, C, O, kh, kw, stride, pad, bias=None, epi=EPI_NONE, r=None):
     """implicit-GEMM convolution over NHWC x [B*H*W, C] with w [O, kh*kw*C] -> y [B*Ho*Wo, O] (see mv_conv2d)."""
-    L.require_cuda(x, w, y)
-    rc = _lib().mv_conv2d(L.dt_of(x), L.ptr(x), L.ptr(w), L.ptr(y), L.dt_of(y), B, H, W, C, O, kh, kw, stride, pad, L.stream_ptr())
+    L.require_cuda(x, w, y, bias, r)
+    rc = _lib().mv_conv2d(L.dt_of(x), L.ptr(x), L.ptr(w), L.ptr(y), L.dt_of(y), B, H, W, C, O, kh, kw, stride, pad, L.ptr(bias), epi,
+                          L.ptr(r), L.dt_of(r) if r is not None else 0, L.stream_ptr())
     L.check(rc, "mv_conv2d")
 
 

@@ -67,6 +67,8 @@ class ImageEncoder_cnn(nn.Module):
         self.adt = dtype
         self._wcache = {}
         self._bncache = {}
+        self._foldcache = {}
+        self.fold_bn = True               # eval(), bf16: BatchNorm folded into the convolutions' weights and epilogues (test switch)
         self.implicit_conv = True         # bf16 path: mv_conv2d instead of mv_im2col + mv_gemm (test switch)
 
     # ---- weights in GEMM layout: [Cout, kh*kw*Cin_padded], (ky, kx, c) order, compute dtype
@@ -83,6 +85,42 @@ class ImageEncoder_cnn(nn.Module):
         w = w.reshape(O, kh * kw * cin_pad).to(self.adt).contiguous()
         self._wcache[key] = (ver, w)
         return w
+
+    # ---- eval(): BatchNorm folded into the convolution (w' = w * gamma * rstd per output channel, b' = beta - mean * gamma * rstd)
+    def _folded(self, conv: nn.Conv2d, bn: nn.BatchNorm2d, cin_pad: int):
+        key = (id(conv), id(bn))
+        ver = (conv.weight._version, bn.weight._version, bn.bias._version, bn.running_mean._version, bn.running_var._version)
+        hit = self._foldcache.get(key)
+        if hit is not None and hit[0] == ver and hit[1].device == conv.weight.device:
+            return hit[1], hit[2]
+        O, I, kh, kw = conv.weight.shape
+        sc = bn.weight.detach().float() * torch.rsqrt(bn.running_var.float() + bn.eps)
+        w = (conv.weight.detach().float() * sc.view(O, 1, 1, 1)).permute(0, 2, 3, 1)
+        if cin_pad != I:
+            w = torch.nn.functional.pad(w, (0, cin_pad - I))
+        w = w.reshape(O, kh * kw * cin_pad).to(self.adt).contiguous()
+        b = (bn.bias.detach().float() - bn.running_mean.float() * sc).contiguous()
+        self._foldcache[key] = (ver, w, b)
+        return w, b
+
+    def _conv_bn_eval(self, x, B, H, W, C, conv: nn.Conv2d, bn: nn.BatchNorm2d, residual=None, relu=True):
+        """eval(), bf16: convolution + BatchNorm (+ residual) (+ ReLU) as ONE GEMM with a fused epilogue."""
+        kh, kw = conv.kernel_size
+        s, pad = conv.stride[0], conv.padding[0]
+        Ho, Wo = (H + 2 * pad - kh) // s + 1, (W + 2 * pad - kw) // s + 1
+        w, b = self._folded(conv, bn, C)
+        rows, K, O = B * Ho * Wo, w.shape[1], w.shape[0]
+        epi = ops.EPI_BIAS_RES_RELU if residual is not None else (ops.EPI_BIAS_RELU if relu else ops.EPI_BIAS)
+        y = torch.empty((rows, O), dtype=self.adt, device=x.device)
+        if kh == 1 and kw == 1 and s == 1:
+            step = max(256, ((1 << 31) - (1 << 20)) // (K * x.element_size()) // 256 * 256)
+            for r0 in range(0, rows, step):
+                n = min(step, rows - r0)
+                ops.gemm(x[r0:r0 + n], w, y[r0:r0 + n], M=n, N=O, K=K, bias=b, epi=epi,
+                         r=None if residual is None else residual[r0:r0 + n])
+        else:
+            ops.conv2d(x, w, y, B, H, W, C, O, kh, kw, s, pad, bias=b, epi=epi, r=residual)
+        return y, Ho, Wo
 
     def _conv(self, x, B, H, W, C, conv: nn.Conv2d):
         """x: [B*H*W, C] activation matrix (NHWC) -> ([B*Ho*Wo, Cout], Ho, Wo)."""
@@ -131,6 +169,14 @@ class ImageEncoder_cnn(nn.Module):
 
     def _block(self, y, B, H, W, C, blk: _Bottleneck):
         """one bottleneck on the activation matrix y [B*H*W, C] -> (matrix, H', W', C')"""
+        if not self.training and self.fold_bn and self.adt == torch.bfloat16:
+            o, _, _ = self._conv_bn_eval(y, B, H, W, C, blk.conv1, blk.bn1)
+            o, H2, W2 = self._conv_bn_eval(o, B, H, W, blk.conv1.out_channels, blk.conv2, blk.bn2)
+            idt = y
+            if blk.downsample is not None:
+                idt, _, _ = self._conv_bn_eval(y, B, H, W, C, blk.downsample[0], blk.downsample[1], relu=False)
+            o, _, _ = self._conv_bn_eval(o, B, H2, W2, blk.conv2.out_channels, blk.conv3, blk.bn3, residual=idt)
+            return o, H2, W2, blk.conv3.out_channels
         idt = y
         o, _, _ = self._conv(y, B, H, W, C, blk.conv1)
         o = self._bn(o, blk.bn1)
@@ -151,8 +197,11 @@ class ImageEncoder_cnn(nn.Module):
         m = self.model
         xin = torch.empty((B * H * W, 8), dtype=self.adt, device=x.device)        # 3 channels padded to 8: 16-byte gathers
         ops.nchw_to_nhwc(x.float().contiguous(), xin, B, 3, H, W, 8)
-        y, H, W = self._conv(xin, B, H, W, 8, m[0])
-        y = self._bn(y, m[1])
+        if not self.training and self.fold_bn and self.adt == torch.bfloat16:
+            y, H, W = self._conv_bn_eval(xin, B, H, W, 8, m[0], m[1])
+        else:
+            y, H, W = self._conv(xin, B, H, W, 8, m[0])
+            y = self._bn(y, m[1])
         Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
         p = torch.empty((B * Ho * Wo, 64), dtype=self.adt, device=x.device)
         ops.maxpool3x3s2(y, p, B, H, W, 64)

@@ -179,3 +179,37 @@ def test_trainer_consumes_pixel_batches():
     assert isinstance(tr.model.img_encoder, mv.ImageEncoder_cnn)
     out = tr.train(0)
     assert np.isfinite(out["avg_loss"])
+
+
+def test_folded_batchnorm_equals_the_separate_pass_in_eval():
+    """eval(), bf16: convolution + folded BatchNorm (+ residual)(+ ReLU) in the GEMM epilogue vs convolution, then
+    mv_bn_act with the running statistics (different rounding points: folded weights are rounded after scaling)."""
+    enc = _encoder(torch.bfloat16).eval()
+    x = torch.randn(2, 3, 96, 64, generator=torch.Generator().manual_seed(6)).to(DEV)
+    a, h, w = enc.trunk(x)
+    enc.fold_bn = False
+    b, _, _ = enc.trunk(x)
+    l2 = float((a.float() - b.float()).norm() / b.float().norm())
+    print("folded vs separate BatchNorm (eval, bf16): relative L2", l2)
+    assert l2 < 2e-2
+    ref = R.trunk(_sd_cpu(enc), x.cpu(), False)
+    got = a.view(2, h, w, 2048).permute(0, 3, 1, 2).float().cpu()
+    assert float((got - ref).norm() / ref.norm()) < 3e-2
+
+
+@pytest.mark.parametrize("epi", ["relu", "res_relu"])
+def test_relu_epilogues(epi):
+    from medvill_amd._lib import EPI_BIAS_RELU, EPI_BIAS_RES_RELU
+    g = torch.Generator().manual_seed(4)
+    M, N, K = 300, 136, 72
+    a, b = (torch.randn(M, K, generator=g) * 0.5).to(torch.bfloat16).to(DEV), (torch.randn(N, K, generator=g) * 0.5).to(torch.bfloat16).to(DEV)
+    bias, r = torch.randn(N, generator=g).to(DEV), torch.randn(M, N, generator=g).to(torch.bfloat16).to(DEV)
+    y = torch.empty((M, N), dtype=torch.float32, device=DEV)
+    ref = a.double() @ b.double().t() + bias.double()
+    if epi == "relu":
+        ops.gemm(a, b, y, M=M, N=N, K=K, bias=bias, epi=EPI_BIAS_RELU)
+    else:
+        ops.gemm(a, b, y, M=M, N=N, K=K, bias=bias, epi=EPI_BIAS_RES_RELU, r=r)
+        ref = ref + r.double()
+    ref = ref.clamp(min=0)
+    assert float((y.double() - ref).abs().max() / ref.abs().max()) < 1e-4
