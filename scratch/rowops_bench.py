@@ -32,3 +32,9 @@ for (Mo, No, nm) in ((768, 3072, "dW2"), (2304, 768, "dWqkv"), (768, 768, "dWo")
     ws = torch.empty(16 * Mo * No, device=dev)
     t0 = bench(lambda: ops.gemm(a, bb, c, ta=True, tb=True, M=Mo, N=No, K=M, lda=Mo, ldb=No, splitk=0, ws=ws))
     print(f"TN {nm:6s} auto splitk {t0:7.1f} us {2.0*M*Mo*No/t0/1e6:6.0f} TF/s")
+# cross-entropy over the labelled rows' logits (fused loss + argmax + gradient), R x V f32 in, bf16 gradient out
+R, V = 3300, 30522
+Vp = (V + 7) // 8 * 8
+logits = torch.randn(R, Vp, device=dev); labels = torch.randint(0, V, (R,), device=dev, dtype=torch.int32)
+out = torch.zeros(3, device=dev); dl = torch.empty(R, Vp, device=dev, dtype=bf)
+t = bench(lambda: ops.ce_fwd_bwd(logits, Vp, labels, R, V, out, dl, Vp, grad_scale=1.0 / R)); print(f"ce fwd+bwd R={R}    {t:7.1f} us  {(R*V*6)/t/1e6:6.2f} TB/s")
