@@ -135,7 +135,7 @@ def corrupt_tokens(ids: torch.Tensor, lengths: torch.Tensor, vocab: int, gen: to
 
 
 def synthetic_batch(vocab: int, B: int, N: int, S: int, family: str, seed: int, device="cuda", img_hidden: int = 2048,
-                    M_regions: int = 256, feat_dtype=torch.float32) -> dict:
+                    M_regions: int = 256, feat_dtype=torch.float32, lengths=None) -> dict:
     """One mini-batch in the reference's batch protocol (dataset_origin.py:181) plus the
     labelled-row index the fused MLM head consumes.  family: full|s2s|bar|noncross|1d|mixed."""
     dev = torch.device(device)
@@ -143,7 +143,8 @@ def synthetic_batch(vocab: int, B: int, N: int, S: int, family: str, seed: int, 
     gen.manual_seed(seed)
     T, L = S + 1, S + N + 3
     lo = 1000 if vocab > 2000 else 200
-    lengths = torch.randint((S + 1) // 2, S + 1, (B,), generator=gen, device=dev)
+    drawn = torch.randint((S + 1) // 2, S + 1, (B,), generator=gen, device=dev)      # len ~ U{ceil(S/2)..S}
+    lengths = drawn if lengths is None else torch.as_tensor(lengths, dtype=torch.int64).clamp(1, S).to(dev)
     ids = torch.randint(lo, vocab, (B, S), generator=gen, device=dev)
     n_ids = lengths + 1
     if dev.type == "cuda":

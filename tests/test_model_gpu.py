@@ -311,7 +311,12 @@ def test_packed_rows_reproduce_the_padded_step(family, B, N, S):
     loss statistics and gradients -- valid rows go through identical arithmetic (same MFMA contraction order, same key
     tiling), only the order of the row-reductions in weight gradients differs (fp32 summation order)."""
     cfg = mv.ModelConfig(hidden=128, heads=2, intermediate=512, layers=2, vocab_size=1024, max_pos=512, dropout=0.0)
-    batch = mv.data.synthetic_batch(cfg.vocab_size, B, N, S, family, seed=31, device=DEV)
+    # ragged to the extremes: a single text token, no padding at all, and drawn lengths in between
+    lens = [1, S] + [None] * (B - 2)
+    drawn = mv.data.synthetic_batch(cfg.vocab_size, B, N, S, family, seed=31, device="cpu")["n_ids"] - 1
+    lens = [int(drawn[i]) if v is None else v for i, v in enumerate(lens)]
+    batch = mv.data.synthetic_batch(cfg.vocab_size, B, N, S, family, seed=31, device=DEV, lengths=lens)
+    assert batch["n_ids"].tolist()[:2] == [2, S + 1]
     out = []
     for pack in (False, True):
         model = mv.CXRBERT(cfg, None, dtype=torch.bfloat16, device=DEV)
