@@ -257,8 +257,10 @@ __device__ __forceinline__ bf16x8 load_frag(const char* tile, int base, int ks, 
   }
 }
 
-template <bool TA, bool TB, bool CONV = false>
-__global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmArgs p) {
+// SB: ONE 32-KiB LDS stage instead of two (the next K-tile waits in registers, two barriers per K-tile) so that three blocks
+// share a CU: 768 tile slots instead of 512, which turns 2.34 rounds of tiles (N = 768 at ~25k rows) into 1.56.
+template <bool TA, bool TB, bool CONV = false, bool SB = false>
+__global__ __launch_bounds__(256, SB ? 3 : 2) void gemm_mfma_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int l15 = lane & 15, lq = lane >> 4;
@@ -310,7 +312,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmArgs p) {
   __syncthreads();
 
   for (int kt = 0; kt < nk; ++kt) {
-    const char* tA = smem + (kt & 1) * GT_STAGE_BYTES;
+    const char* tA = smem + (SB ? 0 : (kt & 1)) * GT_STAGE_BYTES;
     const char* tB = tA + 16384;
     const bool more = (kt + 1 < nk);
     if (more) {
@@ -332,8 +334,9 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmArgs p) {
         for (int j = 0; j < 4; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
     }
+    if (SB) __syncthreads();                     // every wave is done reading the single stage before it is overwritten
     if (more) {
-      char* nA = smem + ((kt + 1) & 1) * GT_STAGE_BYTES;
+      char* nA = smem + (SB ? 0 : ((kt + 1) & 1)) * GT_STAGE_BYTES;
       stage_store<TA>(ra, nA, tid);
       stage_store<TB>(rb, nA + 16384, tid);
     }
@@ -1034,10 +1037,24 @@ extern "C" int mv_gemm(int dtype, int ta, int tb, int M, int N, int K, const voi
     }                                                                                                      \
     hipLaunchKernelGGL((gemm_mfma_kernel<TA_, TB_>), grid, block, shm, stream, p);                          \
   } while (0)
-      if (!ta && !tb) LAUNCH_MFMA(false, false);
-      else if (!ta && tb) LAUNCH_MFMA(false, true);
-      else if (ta && tb) LAUNCH_MFMA(true, true);
-      else LAUNCH_MFMA(true, false);
+#define LAUNCH_MFMA_SB(TA_, TB_)                                                                           \
+  do {                                                                                                     \
+    static bool attr_sb = false;                                                                           \
+    if (!attr_sb) {                                                                                        \
+      (void)hipFuncSetAttribute((const void*)gemm_mfma_kernel<TA_, TB_, false, true>,                      \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, GT_STAGE_BYTES);               \
+      attr_sb = true;                                                                                      \
+    }                                                                                                      \
+    hipLaunchKernelGGL((gemm_mfma_kernel<TA_, TB_, false, true>), grid, block, GT_STAGE_BYTES, stream, p); \
+  } while (0)
+      // one LDS stage and three blocks per CU by default (10-15 % faster on the model's 768-column GEMMs at ~25k rows:
+      // profiles/r01_gemm_variants.txt); the two-stage form stays reachable for cross-checks (mv_set_gemm_variant(., 32))
+      const bool sb = g_mv_gemm_nj != 32;
+      if (!ta && !tb) { if (sb) LAUNCH_MFMA_SB(false, false); else LAUNCH_MFMA(false, false); }
+      else if (!ta && tb) { if (sb) LAUNCH_MFMA_SB(false, true); else LAUNCH_MFMA(false, true); }
+      else if (ta && tb) { if (sb) LAUNCH_MFMA_SB(true, true); else LAUNCH_MFMA(true, true); }
+      else { if (sb) LAUNCH_MFMA_SB(true, false); else LAUNCH_MFMA(true, false); }
+#undef LAUNCH_MFMA_SB
 #undef LAUNCH_MFMA
     }
   } else {

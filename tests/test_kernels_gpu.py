@@ -41,10 +41,10 @@ def dgelu(z):
 GEMM_SHAPES = [(256, 256, 256), (130, 70, 200), (1024, 768, 768), (64, 2, 768), (96, 1000, 128), (517, 264, 3072)]
 
 
-VARIANT = {"mfma": (1, 0), "mfma256k64": (2, 14), "pring256": (2, 24), "mfma_auto": (0, 0)}   # mv_set_gemm_variant(force, nj)
+VARIANT = {"mfma": (1, 0), "mfma2s": (1, 32), "mfma256k64": (2, 14), "pring256": (2, 24), "mfma_auto": (0, 0)}   # mv_set_gemm_variant(force, nj)
 
 
-@pytest.mark.parametrize("impl", ["mfma", "mfma256k64", "pring256", "simple_bf16", "f32"])
+@pytest.mark.parametrize("impl", ["mfma", "mfma2s", "mfma256k64", "pring256", "simple_bf16", "f32"])
 @pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 1), (1, 0)])
 @pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
 def test_gemm_layouts(impl, ta, tb, M, N, K):
@@ -74,7 +74,7 @@ def test_gemm_layouts(impl, ta, tb, M, N, K):
         ops.set_gemm_variant(0, 0)
 
 
-@pytest.mark.parametrize("impl", ["mfma", "mfma256k64", "pring256", "f32"])
+@pytest.mark.parametrize("impl", ["mfma", "mfma2s", "mfma256k64", "pring256", "f32"])
 @pytest.mark.parametrize("epi", [EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RES, EPI_DGELU, EPI_RES, EPI_BIAS_TANH, EPI_BIAS_GELU_D, EPI_MUL])
 @pytest.mark.parametrize("M,N,K,cdt", [(256, 384, 128, "bf16"), (200, 130, 72, "f32"), (128, 768, 768, "f32")])
 def test_gemm_epilogues(impl, epi, M, N, K, cdt):
@@ -115,7 +115,7 @@ def test_gemm_epilogues(impl, epi, M, N, K, cdt):
     assert relerr(c, ref) < (2e-5 if cd == torch.float32 else 1e-2)
 
 
-@pytest.mark.parametrize("impl", ["mfma", "mfma256k64", "pring256", "f32"])
+@pytest.mark.parametrize("impl", ["mfma", "mfma2s", "mfma256k64", "pring256", "f32"])
 def test_gemm_splitk_and_accumulate(impl):
     dt = torch.float32 if impl == "f32" else torch.bfloat16
     Mt, No, Ko = 4096, 200, 136
