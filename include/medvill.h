@@ -264,8 +264,7 @@ int mv_cast2d(const void* src, int src_dtype, long long lds, void* dst, int dst_
               int rows, int cols, void* stream);
 
 /* dst[c, r] = src[r, c] for r < rows, c < cols (leading dimensions lds >= cols, ldd >= rows; same dtype both sides).
- * The engine keeps k-contiguous (transposed) bf16 copies of the FFN and QKV weights so that the input-gradient
- * GEMMs dX = dY.W run in the same y = x.W'^T form as the forward. */
+ * Utility (the training engine needs no transposed copies: every GEMM form reads the weights as stored). */
 int mv_transpose(int dtype, const void* src, long long lds, void* dst, long long ldd, int rows, int cols, void* stream);
 
 /* dst(dst_dtype) = src(src_dtype), n elements */

@@ -934,10 +934,8 @@ extern "C" int mv_gemm(int dtype, int ta, int tb, int M, int N, int K, const voi
     // measured on the model's shapes (profiles/r01_gemm_variants.txt): the ring kernels win for y = x.W^T and
     // dW = dy^T.x, the 128x128 register-staged kernel for dx = dy.W
     // (ring kernel with 64-deep stages for wide outputs and for dW; 128x128 register-staged for N <= 1024 and dX)
-    // (measured: the 256-row kernel also wins for narrow bf16 outputs once the contraction is long: da / dx in
-    //  y = x.W'^T form, 191 vs 208 us and 138 vs 148 us; not for f32 outputs, where the 128x128 kernel's 3 blocks per CU
-    //  hide the wider stores better)
-    const bool wide_nt = !ta && !tb && (N >= 1024 || (K >= 2048 && c_dtype == MV_BF16));
+    // (768-column outputs: the 128x128 kernel at three blocks per CU wins in every layout, also for long contractions)
+    const bool wide_nt = !ta && !tb && N >= 1024;
     const bool big = (g_mv_gemm_force == 2) || (g_mv_gemm_force == 0 && M >= 256 && N >= 128 && ((K & 7) == 0 || (ta && tb)) && (wide_nt || ta) &&
                                                (t128 >= 128 || (K >= 4096 && splitk != 1)));
     if (big) {

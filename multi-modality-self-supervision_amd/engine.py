@@ -126,7 +126,6 @@ class Engine:
         self.flat_v = None
         self.shadow = torch.zeros(self.n_flat, dtype=torch.bfloat16, device=self.device) if self.dt == MV_BF16 else None
         self.shadow_dirty = True
-        self.wT = {}                  # bf16 mode: k-contiguous (transposed) copies of the weights whose dX GEMM is large
         self._ws = {}
         self._gemm_ws = None
         self._side = None             # side HIP stream for the weight-gradient GEMMs of the backward
@@ -170,7 +169,6 @@ class Engine:
                 setattr(self, k, t.to(device))
         self.device = device
         self._ws.clear()
-        self.wT.clear()
         self.shadow_dirty = True
         self._gemm_ws = None
         self._bind()
@@ -180,25 +178,7 @@ class Engine:
         """bf16 mode: refresh the bf16 copy the MFMA kernels read from the fp32 master weights."""
         if self.dt == MV_BF16:
             ops.cast(self.flat_p, self.shadow, self.n_flat)
-            self._refresh_transposed()
         self.shadow_dirty = False
-
-    def _refresh_transposed(self):
-        """W^T copy of the FFN-down weight (bf16 mode): dz = dy.W2 then runs as y = x.W'^T with W' = W2^T k-contiguous,
-        the form the 256-row LDS-DMA kernel is fastest in (profiles/r01_gemm_variants.txt)."""
-        if self.dt != MV_BF16:
-            return
-        H, I = self.cfg.hidden, self.cfg.intermediate
-        for l in range(self.cfg.layers):
-            p = f"enc.encoder.layer.{l}."
-            # only the FFN-down weight: its input-gradient GEMM has the wide (3072-column) output the 256-row kernel is
-            # built for (238 vs 260 us at the packed row count); da and dx have 768-column outputs, where the
-            # contraction-major 128x128 kernel is as fast or faster (profiles/r01_gemm_variants.txt)
-            for key, W, (r, c) in ((p + "output.dense.weight", self.w[p + "output.dense.weight"], (H, I)),):
-                t = self.wT.get(key)
-                if t is None or t.device != W.device:
-                    t = self.wT[key] = torch.empty((c, r), dtype=torch.bfloat16, device=W.device)
-                ops.transpose(W, t, r, c)
 
     def zero_grad(self):
         self.ensure_grad()
@@ -540,7 +520,6 @@ class Engine:
         dh = H // A
         B, Lq, M, N, T = S["B"], S["L"], S["M"], S["N"], S["T"]
         adt, g = self.adt, self.g
-        bf = self.dt == MV_BF16 and bool(self.wT)      # input-gradient GEMMs in y = x.W'^T form over the transposed copies
         dy = S["dhidden"]
         main = torch.cuda.current_stream()
         if self._side is None:
@@ -584,10 +563,7 @@ class Engine:
             fork()
             with torch.cuda.stream(side):
                 self._dW(dproj2, a_["i"], g[p + "output.dense.weight"], H, I, M, lda=H, ldb=I)
-            if bf:
-                ops.gemm(dproj2, self.wT[p + "output.dense.weight"], dz, M=M, N=I, K=H, epi=EPI_MUL, r=a_["dgelu"])
-            else:
-                ops.gemm(dproj2, self.w[p + "output.dense.weight"], dz, tb=True, M=M, N=I, K=H, epi=EPI_MUL, r=a_["dgelu"])
+            ops.gemm(dproj2, self.w[p + "output.dense.weight"], dz, tb=True, M=M, N=I, K=H, epi=EPI_MUL, r=a_["dgelu"])
             fork()
             with torch.cuda.stream(side):
                 ops.colsum(dz, I, M, I, g[p + "intermediate.dense.bias"], accumulate=True)
@@ -637,5 +613,4 @@ class Engine:
         self.ensure_opt()
         ops.adamw_step(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.shadow, self.n_flat, lr, betas[0], betas[1], eps,
                        weight_decay, step, correct_bias, grad_scale)
-        self._refresh_transposed()
         self.shadow_dirty = False
