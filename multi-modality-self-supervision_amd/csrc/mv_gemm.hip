@@ -1111,13 +1111,13 @@ extern "C" int mv_conv2d(int dtype, const void* x, const void* w, void* y, int y
   while ((1 << p.cvCshift) < C) ++p.cvCshift;
   const long long tiles = ((rows + GT_BM - 1) / GT_BM) * ((O + GT_BN - 1) / GT_BN);
   if (tiles > 0x7fffffffLL) return MV_E_SHAPE;
-  const size_t shm = 2 * GT_STAGE_BYTES;
+  const size_t shm = GT_STAGE_BYTES;           // one LDS stage, three blocks per CU (see gemm_mfma_kernel)
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_mfma_kernel<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    (void)hipFuncSetAttribute((const void*)gemm_mfma_kernel<false, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_mfma_kernel<false, false, true>), dim3((unsigned)tiles, 1), dim3(256), shm, stream, p);
+  hipLaunchKernelGGL((gemm_mfma_kernel<false, false, true, true>), dim3((unsigned)tiles, 1), dim3(256), shm, stream, p);
   MV_CHECK_LAUNCH();
   return MV_OK;
 }
