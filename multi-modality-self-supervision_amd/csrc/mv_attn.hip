@@ -254,7 +254,7 @@ __device__ __forceinline__ int next_tile(unsigned long long need, int after, int
 }
 
 // ---- forward --------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void attn_fwd_mfma_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256, 3) void attn_fwd_mfma_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 stages x (K 8 KiB + V 8 KiB)
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, h = lane >> 5;
   const int head = blockIdx.y, b = blockIdx.z;
