@@ -21,7 +21,7 @@
  *     positive = hipError_t of a failed launch.  Nothing throws.
  *   - re-entrant, no global mutable state except mv_set_impl() (test hook).
  *   - dtype: MV_F32 = exact fp32 path (plain VALU kernels; parity at 1e-3 and below),
- *            MV_BF16 = bf16 storage, fp32 accumulate, MFMA kernels (the fast path).
+ *            MV_BF16 / MV_F16 = 16-bit storage, fp32 accumulate, MFMA kernels (the fast path).
  *   - matrices are row-major; "ld*" are leading dimensions in ELEMENTS.
  */
 #ifndef MEDVILL_H_
@@ -34,9 +34,15 @@
 extern "C" {
 #endif
 
-#define MV_ABI_VERSION 1
+#define MV_ABI_VERSION 2
 
-enum { MV_F32 = 0, MV_BF16 = 1 };
+/* MV_F16 is the encoding of the FORWARD operands of the 16-bit path (weights' f16 shadow, stored activations that
+ * feed y = x.W^T and the attention forward): 11 significand bits instead of bf16's 8 at the same MFMA rate.  At
+ * BERT-base depth bf16-encoded forward operands cannot meet the 1e-2 logit tolerance (the weight rounding alone gives
+ * 1.4e-2, profiles/r02_bf16_error.txt); gradients keep MV_BF16 for its exponent range.  Kernels that produce a forward
+ * activation can write it twice from one accumulator: the f16 copy for the next forward product and the bf16 copy that
+ * the backward's gradient products (dW = dy^T.x, attention backward) pair with bf16 gradients. */
+enum { MV_F32 = 0, MV_BF16 = 1, MV_F16 = 2 };
 
 enum {
   MV_OK = 0,
@@ -84,8 +90,9 @@ void mv_set_gemm_variant(int force, int nj);
  * so  y = x.W^T            is (ta=0, tb=0, A=x,  B=W)
  *     dx = dy.W            is (ta=0, tb=1, A=dy, B=W)
  *     dW = dy^T.x          is (ta=1, tb=1, A=dy, B=x)
- * dtype applies to A and B; c_dtype to C (and C2); r_dtype to R; bias is always f32.
- * bf16 operands need 16-byte aligned bases and lda, ldb multiples of 8; a contraction length
+ * dtype applies to A and B (MV_F16 only for ta = tb = 0); c_dtype to C (and C2); r_dtype to R; bias is always f32.
+ * C3 (nullable, leading dimension ldc3): a second copy of C in the 16-bit encoding c3_dtype (see MV_F16 above).
+ * 16-bit operands need 16-byte aligned bases and lda, ldb multiples of 8; a contraction length
  * K that is not a multiple of 8 is allowed only when the k-contiguous operand's rows are
  * zero-padded up to the next multiple of 8.
  * splitk = 0: let the library pick (needs ws for up to 16 slices, else 1 is used).
@@ -100,6 +107,7 @@ int mv_gemm(int dtype, int ta, int tb, int M, int N, int K,
             const float* bias, int epi,
             const void* R, int ldr, int r_dtype,
             void* C2, int ldc2,
+            void* C3, int ldc3, int c3_dtype,
             int splitk, float* ws, size_t ws_bytes, int accumulate,
             float p_drop, unsigned long long drop_key, void* stream);
 
@@ -169,9 +177,11 @@ int mv_pack_plan(const int32_t* desc, int B, int L, int32_t* cu, int32_t* rowmap
  * lse [B, A, L] (f32) = log-sum-exp of each score row, kept for the backward.
  * dh must be 64 (bf16 MFMA path) or <= 128 (f32 path).
  * p_drop > 0: attention-probability dropout (HF BertSelfAttention.dropout): ctx = dropout(softmax).v with the
- * mask of mv_dropout_mask(p_drop, drop_key) over index ((b*A + h)*L + q)*Lp + k, Lp = L rounded up to 4.  */
+ * mask of mv_dropout_mask(p_drop, drop_key) over index ((b*A + h)*L + q)*Lp + k, Lp = L rounded up to 4.
+ * dtype MV_F16: qkv and ctx in the f16 encoding; ctx_bf16 (nullable, MV_F16 only) receives the bf16 copy of ctx that
+ * the backward pairs with bf16 gradients.  */
 int mv_attn_fwd(int dtype, const void* qkv, const uint32_t* bits, const uint8_t* tileinfo,
-                void* ctx, float* lse, int B, int L, int A, int dh,
+                void* ctx, void* ctx_bf16, float* lse, int B, int L, int A, int dh,
                 float p_drop, unsigned long long drop_key, const int32_t* cu, int total_rows, void* stream);
 
 /* dqkv [B*L,3H] from dctx [B*L,H]; `delta` is a [B,A,L] f32 scratch (rowsum(dctx*ctx)). */
@@ -183,10 +193,10 @@ int mv_attn_bwd(int dtype, const void* qkv, const void* ctx, const void* dctx, c
 /* ---- LayerNorm ------------------------------------------------------------------------------
  * y = (x-mean)/sqrt(var+eps)*gamma+beta over the last dim (HF LayerNorm eps=1e-12 in the
  * encoder; TF-style BertLayerNorm eps=1e-5 of cxrbert_origin.py:189-202 in the MLM head).
- * x_dtype: dtype of x (the fused-residual GEMM writes f32); y in `dtype`.
- * mean, rstd: f32 [M], kept for backward.                                                     */
+ * x_dtype: dtype of x (the fused-residual GEMM writes f32); y in `dtype`; y_bf16 (nullable, dtype MV_F16 only): bf16
+ * copy of y for the backward's weight-gradient product.  mean, rstd: f32 [M], kept for backward.  */
 int mv_layernorm_fwd(int dtype, const void* x, int x_dtype, const float* gamma, const float* beta,
-                     void* y, float* mean, float* rstd, int M, int H, float eps, void* stream);
+                     void* y, void* y_bf16, float* mean, float* rstd, int M, int H, float eps, void* stream);
 
 /* dx (dtype) = LN backward of dy (dtype) w.r.t. x; dgamma/dbeta (f32 [H]) are ACCUMULATED
  * (atomically) -- zero them first; colsum (f32 [H], nullable) accumulates sum_m dx[m,:]
@@ -205,11 +215,11 @@ int mv_layernorm_bwd(int dtype, const void* dy, const void* x, int x_dtype, cons
  *               E[txt[b,t]]+Ty[segment[b,t]]+P[t] ] )         L = N + T + 2
  * straight into the concatenated [B,L,H] buffer.  imgproj = feats.Wi^T + bi comes from mv_gemm.
  * Tables E, P, Ty and imgproj are in `dtype`; gamma/beta f32.  `pre` (f32 [B,L,H]) keeps the
- * pre-LayerNorm sums for the backward.                                                        */
+ * pre-LayerNorm sums for the backward.  x0_bf16 (nullable, dtype MV_F16 only): bf16 copy of x0.  */
 int mv_embed_fwd(int dtype, const int64_t* cls_tok, const int64_t* txt, const int64_t* segment,
                  const int64_t* img_pos, const int64_t* sep_tok, const void* imgproj,
                  const void* E, const void* P, const void* Ty, const float* gamma, const float* beta,
-                 void* x0, float* pre, float* mean, float* rstd,
+                 void* x0, void* x0_bf16, float* pre, float* mean, float* rstd,
                  int B, int N, int T, int H, int V, int maxpos, float eps,
                  float p_drop, unsigned long long drop_key, const int32_t* rowmap, int n_rows, void* stream);
 
@@ -312,9 +322,9 @@ int mv_dropout_mask(float p_drop, unsigned long long drop_key, size_t n, uint8_t
  *   m = b1*m+(1-b1)*g; v = b2*v+(1-b2)*g*g; p -= lr*sqrt(1-b2^t)/(1-b1^t) * m/(sqrt(v)+eps);
  *   p -= lr*wd*p            (eps added BEFORE the bias correction, decoupled decay)
  * over one flat f32 buffer of n elements (all parameters live in one flat buffer);
- * g is multiplied by grad_scale first; `shadow` (nullable) receives the bf16 copy of the
- * updated parameters that the MFMA kernels read.                                              */
-int mv_adamw_step(float* p, const float* g, float* m, float* v, void* shadow_bf16, size_t n,
+ * g is multiplied by grad_scale first; shadow_bf16 / shadow_f16 (nullable) receive the 16-bit copies of
+ * the updated parameters that the MFMA kernels read (bf16: gradient products, f16: forward).   */
+int mv_adamw_step(float* p, const float* g, float* m, float* v, void* shadow_bf16, void* shadow_f16, size_t n,
                   float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                   int correct_bias, float grad_scale, void* stream);
 

@@ -13,7 +13,7 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libmedvill_hip.so")
 
-MV_F32, MV_BF16 = 0, 1
+MV_F32, MV_BF16, MV_F16 = 0, 1, 2
 EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RES, EPI_DGELU, EPI_RES, EPI_BIAS_TANH, EPI_BIAS_GELU_D, EPI_MUL, EPI_BIAS_RELU, EPI_BIAS_RES_RELU = range(11)
 _ERR = {-1: "MV_E_ARG (null pointer / bad size)", -2: "MV_E_SHAPE (unsupported shape or alignment)",
         -3: "MV_E_DTYPE", -4: "MV_E_WORKSPACE (workspace too small)"}
@@ -28,18 +28,18 @@ PROTOTYPES = {
     "mv_get_impl": [],
     "mv_build_info": [],
     "mv_set_gemm_variant": [i32, i32],
-    "mv_gemm": [i32, i32, i32, i32, i32, i32, vp, i32, vp, i32, vp, i32, i32, vp, i32, vp, i32, i32, vp, i32, i32, vp, sz,
-                i32, f32, u64, vp],
+    "mv_gemm": [i32, i32, i32, i32, i32, i32, vp, i32, vp, i32, vp, i32, i32, vp, i32, vp, i32, i32, vp, i32, vp, i32, i32,
+                i32, vp, sz, i32, f32, u64, vp],
     "mv_mask_pack": [vp, i32, i32, i32, vp, vp, vp],
     "mv_mask_build": [vp, i32, i32, vp, vp, vp],
     "mv_mlm_draws": [u64, i32, i32, i32, vp, vp, vp],
     "mv_mlm_corrupt": [vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "mv_pack_plan": [vp, i32, i32, vp, vp, vp, vp],
-    "mv_attn_fwd": [i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, u64, vp, i32, vp],
+    "mv_attn_fwd": [i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, u64, vp, i32, vp],
     "mv_attn_bwd": [i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, u64, vp, i32, vp],
-    "mv_layernorm_fwd": [i32, vp, i32, vp, vp, vp, vp, vp, i32, i32, f32, vp],
+    "mv_layernorm_fwd": [i32, vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, f32, vp],
     "mv_layernorm_bwd": [i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, f32, u64, vp],
-    "mv_embed_fwd": [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, f32,
+    "mv_embed_fwd": [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, f32,
                      u64, vp, i32, vp],
     "mv_embed_bwd": [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32,
                      u64, vp, i32, vp],
@@ -60,7 +60,7 @@ PROTOTYPES = {
     "mv_bn_finalize": [vp, i32, i64, f32, f32, vp, vp, vp, vp, vp],
     "mv_bn_act": [i32, vp, i32, vp, vp, vp, vp, vp, vp, i64, i32, i32, vp],
     "mv_maxpool3x3s2": [i32, vp, vp, i32, i32, i32, i32, vp],
-    "mv_adamw_step": [vp, vp, vp, vp, vp, sz, f32, f32, f32, f32, f32, i32, i32, f32, vp],
+    "mv_adamw_step": [vp, vp, vp, vp, vp, vp, sz, f32, f32, f32, f32, f32, i32, i32, f32, vp],
 }
 _RESTYPE = {"mv_set_impl": None, "mv_set_gemm_variant": None, "mv_build_info": C.c_char_p}
 
@@ -85,7 +85,7 @@ def load(build_if_missing: bool = False):
         fn = getattr(lib, name)          # AttributeError if an exported symbol is missing
         fn.argtypes = args
         fn.restype = _RESTYPE.get(name, C.c_int)
-    if lib.mv_abi_version() != 1:
+    if lib.mv_abi_version() != 2:
         raise RuntimeError("libmedvill_hip.so ABI version mismatch")
     _lib = lib
     return lib
@@ -104,11 +104,13 @@ def dt_of(t: torch.Tensor) -> int:
         return MV_F32
     if t.dtype == torch.bfloat16:
         return MV_BF16
+    if t.dtype == torch.float16:
+        return MV_F16
     raise TypeError(f"unsupported dtype {t.dtype}")
 
 
 def torch_dtype(dt: int):
-    return torch.float32 if dt == MV_F32 else torch.bfloat16
+    return {MV_F32: torch.float32, MV_BF16: torch.bfloat16, MV_F16: torch.float16}[dt]
 
 
 def ptr(t):

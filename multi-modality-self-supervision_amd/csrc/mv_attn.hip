@@ -138,6 +138,7 @@ extern "C" int mv_mask_pack(const int64_t* mask, int mask_ndim, int B, int L, ui
 // =========================================================================================
 struct AttnArgs {
   const bf16_t* qkv; const bf16_t* ctx; const bf16_t* dctx; bf16_t* out; bf16_t* dqkv;
+  bf16_t* out2;   // forward, f16 operands only (nullable): bf16 copy of the context for the backward's gradient products
   const uint32_t* bits; const uint8_t* info; float* lse; const float* lse_in; const float* delta; float* delta_out;
   int B, L, A, H, W, T;
   float scale;
@@ -212,6 +213,25 @@ __device__ __forceinline__ bf16x8 pack8(const f32x16& v, int s2) {
   for (int j = 0; j < 8; ++j) r[j] = (bf16_t)v[8 * s2 + j];
   return r;
 }
+// 32x32x16 MFMA / accumulator packing in the operand encoding of the kernel: F16 = f16 bit patterns carried in bf16x8
+template <bool F16>
+__device__ __forceinline__ f32x16 mma32(bf16x8 a, bf16x8 b, f32x16 c) {
+  if constexpr (F16)
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+template <bool F16>
+__device__ __forceinline__ bf16x8 pack8t(const f32x16& v, int s2) {
+  if constexpr (F16) {
+    f16x8 r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = (f16_t)v[8 * s2 + j];
+    return __builtin_bit_cast(bf16x8, r);
+  } else {
+    return pack8(v, s2);
+  }
+}
 __device__ __forceinline__ bf16x8 load_rowfrag_global(__amdgpu_buffer_rsrc_t rs, unsigned bytes, size_t row, bool ok, int ld,
                                                       int col) {
   const unsigned off = (unsigned)((row * (size_t)ld + col) * 2);
@@ -254,6 +274,7 @@ __device__ __forceinline__ int next_tile(unsigned long long need, int after, int
 }
 
 // ---- forward --------------------------------------------------------------------------------
+template <bool F16>
 __global__ __launch_bounds__(256, 3) void attn_fwd_mfma_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 stages x (K 8 KiB + V 8 KiB)
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, h = lane >> 5;
@@ -309,7 +330,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_mfma_kernel(AttnArgs a) {
         for (int i = 0; i < 16; ++i) st[kk][i] = 0.f;
 #pragma unroll
         for (int s = 0; s < 4; ++s)
-          st[kk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(tK, 32 * kk, s, l31, h), qf[s], st[kk], 0, 0, 0);
+          st[kk] = mma32<F16>(frag_row(tK, 32 * kk, s, l31, h), qf[s], st[kk]);
       }
       const bool tail = (k0 + 64 > Lv);
       float mx = -INFINITY;
@@ -373,10 +394,10 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_mfma_kernel(AttnArgs a) {
       for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
-          const bf16x8 pf = pack8(st[kk], s2);
+          const bf16x8 pf = pack8t<F16>(st[kk], s2);
 #pragma unroll
           for (int dt = 0; dt < 2; ++dt)
-            o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(tV, 32 * dt, 32 * kk + 16 * s2, lane), pf, o[dt], 0, 0, 0);
+            o[dt] = mma32<F16>(frag_tr(tV, 32 * dt, 32 * kk + 16 * s2, lane), pf, o[dt]);
         }
     }
     if (nxt < nkt) {
@@ -391,13 +412,18 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_mfma_kernel(AttnArgs a) {
   const float ltot = lsum + __shfl_xor(lsum, 32, 64);
   const float inv = (a.drop.thr ? a.drop.inv_keep : 1.0f) / ltot;
   bf16_t* orow = a.out + (rowbase + q) * (size_t)H + head * 64;
+  bf16_t* orow2 = a.out2 ? a.out2 + (rowbase + q) * (size_t)H + head * 64 : nullptr;
 #pragma unroll
   for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      bf16x4 v = {(bf16_t)(o[dt][4 * g] * inv), (bf16_t)(o[dt][4 * g + 1] * inv), (bf16_t)(o[dt][4 * g + 2] * inv),
-                  (bf16_t)(o[dt][4 * g + 3] * inv)};
-      *(bf16x4*)(orow + 32 * dt + 8 * g + 4 * h) = v;
+      const f32x4 ov = {o[dt][4 * g] * inv, o[dt][4 * g + 1] * inv, o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv};
+      if constexpr (F16) {
+        st4<f16_t>((f16_t*)orow + 32 * dt + 8 * g + 4 * h, ov);
+        if (orow2) st4<bf16_t>(orow2 + 32 * dt + 8 * g + 4 * h, ov);
+      } else {
+        st4<bf16_t>(orow + 32 * dt + 8 * g + 4 * h, ov);
+      }
     }
   if (h == 0) a.lse[((size_t)b * a.A + head) * L + q] = (m2 + log2f(ltot)) * LN2;
 }
@@ -877,35 +903,46 @@ static int launch_simple_fwd(const void* qkv, const uint32_t* bits, void* ctx, f
   return MV_OK;
 }
 
-extern "C" int mv_attn_fwd(int dtype, const void* qkv, const uint32_t* bits, const uint8_t* tileinfo, void* ctx, float* lse,
-                           int B, int L, int A, int dh, float p_drop, unsigned long long drop_key, const int32_t* cu,
+extern "C" int mv_attn_fwd(int dtype, const void* qkv, const uint32_t* bits, const uint8_t* tileinfo, void* ctx, void* ctx_bf16,
+                           float* lse, int B, int L, int A, int dh, float p_drop, unsigned long long drop_key, const int32_t* cu,
                            int total_rows, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   const DropCfg drop = mv_make_drop(p_drop, drop_key);
   if ((size_t)B * A * L * ((L + 3) & ~3) >= (1ull << 34)) return MV_E_SHAPE;   // mask counter is 32 bits of (index >> 2)
   if (!qkv || !bits || !tileinfo || !ctx || !lse || B <= 0 || L <= 0 || A <= 0 || dh <= 0) return MV_E_ARG;
-  if (dtype != MV_F32 && dtype != MV_BF16) return MV_E_DTYPE;
+  if (!mv_dtype_ok(dtype)) return MV_E_DTYPE;
+  if (ctx_bf16 && dtype != MV_F16) return MV_E_DTYPE;     // the second context output is the bf16 copy of an f16 forward
   const int H = A * dh;
-  if (dtype == MV_BF16 && g_mv_impl == 0) {
+  if (mv_is16(dtype) && g_mv_impl == 0) {
     if (dh != 64) return MV_E_SHAPE;
     if (cu && (total_rows <= 0 || total_rows > B * L)) return MV_E_ARG;
     const size_t nrow = cu ? (size_t)total_rows : (size_t)B * L;
     const size_t bq = nrow * 3 * H * 2;
-    if (bq >= 0x7fffffffULL || (((uintptr_t)qkv) & 15) || (((uintptr_t)ctx) & 7)) return MV_E_SHAPE;
+    if (bq >= 0x7fffffffULL || (((uintptr_t)qkv) & 15) || (((uintptr_t)ctx) & 7) || (((uintptr_t)ctx_bf16) & 7)) return MV_E_SHAPE;
     AttnArgs a{};
     a.cu = cu;
-    a.qkv = (const bf16_t*)qkv; a.out = (bf16_t*)ctx; a.bits = bits; a.info = tileinfo; a.lse = lse;
+    a.qkv = (const bf16_t*)qkv; a.out = (bf16_t*)ctx; a.out2 = (bf16_t*)ctx_bf16; a.bits = bits; a.info = tileinfo; a.lse = lse;
     a.B = B; a.L = L; a.A = A; a.H = H; a.W = (L + 31) / 32; a.T = (L + 63) / 64;
     a.scale = 1.0f / sqrtf((float)dh);
     a.bytes_qkv = (unsigned)bq;
     a.drop = drop; a.Lp = (L + 3) & ~3;
     static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)attn_fwd_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 32768); attr = true; }
-    hipLaunchKernelGGL(attn_fwd_mfma_kernel, dim3((L + 127) / 128, A, B), dim3(256), 32768, stream, a);
+    if (!attr) {
+      (void)hipFuncSetAttribute((const void*)attn_fwd_mfma_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 32768);
+      (void)hipFuncSetAttribute((const void*)attn_fwd_mfma_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 32768);
+      attr = true;
+    }
+    if (dtype == MV_F16) hipLaunchKernelGGL(attn_fwd_mfma_kernel<true>, dim3((L + 127) / 128, A, B), dim3(256), 32768, stream, a);
+    else hipLaunchKernelGGL(attn_fwd_mfma_kernel<false>, dim3((L + 127) / 128, A, B), dim3(256), 32768, stream, a);
     MV_CHECK_LAUNCH();
     return MV_OK;
   }
   if (dh > 128 || cu) return MV_E_SHAPE;       // packed rows: MFMA kernels only
+  if (dtype == MV_F16) {                         // VALU cross-check of the f16 forward (mv_set_impl(1))
+    int rc = launch_simple_fwd<f16_t>(qkv, bits, ctx, lse, B, L, A, dh, drop, stream);
+    if (rc == MV_OK && ctx_bf16) rc = mv_cast(ctx, MV_F16, ctx_bf16, MV_BF16, (size_t)B * L * H, stream_);
+    return rc;
+  }
   return dtype == MV_F32 ? launch_simple_fwd<float>(qkv, bits, ctx, lse, B, L, A, dh, drop, stream)
                          : launch_simple_fwd<bf16_t>(qkv, bits, ctx, lse, B, L, A, dh, drop, stream);
 }

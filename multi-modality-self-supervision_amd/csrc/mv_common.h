@@ -14,6 +14,11 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+// f16 encoding of the FORWARD operands of the 16-bit path (MV_F16): 11-bit significand instead of bf16's 8; the MFMA rate
+// is the same (v_mfma_f32_16x16x32_f16 / 32x32x16_f16), gradients keep the bf16 encoding for its exponent range
+typedef _Float16 f16_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
 
 #define MV_LDS __attribute__((address_space(3)))
 
@@ -31,15 +36,22 @@ __device__ __forceinline__ bf16_t f2bf(float x) { return (bf16_t)x; }
 template <typename T> __device__ __forceinline__ float ldf(const T* p);
 template <> __device__ __forceinline__ float ldf<float>(const float* p) { return *p; }
 template <> __device__ __forceinline__ float ldf<bf16_t>(const bf16_t* p) { return (float)*p; }
+template <> __device__ __forceinline__ float ldf<f16_t>(const f16_t* p) { return (float)*p; }
 template <typename T> __device__ __forceinline__ void stf(T* p, float v);
 template <> __device__ __forceinline__ void stf<float>(float* p, float v) { *p = v; }
 template <> __device__ __forceinline__ void stf<bf16_t>(bf16_t* p, float v) { *p = (bf16_t)v; }
+template <> __device__ __forceinline__ void stf<f16_t>(f16_t* p, float v) { *p = (f16_t)v; }
 
 // 4-wide vector access (pointer must be 4-element aligned)
 template <typename T> __device__ __forceinline__ f32x4 ld4(const T* p);
 template <> __device__ __forceinline__ f32x4 ld4<float>(const float* p) { return *(const f32x4*)p; }
 template <> __device__ __forceinline__ f32x4 ld4<bf16_t>(const bf16_t* p) {
   bf16x4 v = *(const bf16x4*)p;
+  f32x4 r = {(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+  return r;
+}
+template <> __device__ __forceinline__ f32x4 ld4<f16_t>(const f16_t* p) {
+  f16x4 v = *(const f16x4*)p;
   f32x4 r = {(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
   return r;
 }
@@ -50,13 +62,27 @@ template <> __device__ __forceinline__ void st4<bf16_t>(bf16_t* p, f32x4 v) {
   *(bf16x4*)p = r;
 }
 
-// runtime-typed scalar access (dtype: MV_F32 / MV_BF16)
+template <> __device__ __forceinline__ void st4<f16_t>(f16_t* p, f32x4 v) {
+  f16x4 r = {(f16_t)v[0], (f16_t)v[1], (f16_t)v[2], (f16_t)v[3]};
+  *(f16x4*)p = r;
+}
+
+// runtime-typed access (dtype: MV_F32 / MV_BF16 / MV_F16)
 __device__ __forceinline__ float ld_any(const void* p, size_t i, int dtype) {
-  return dtype == MV_F32 ? ((const float*)p)[i] : (float)((const bf16_t*)p)[i];
+  return dtype == MV_F32 ? ((const float*)p)[i] : dtype == MV_BF16 ? (float)((const bf16_t*)p)[i] : (float)((const f16_t*)p)[i];
 }
 __device__ __forceinline__ void st_any(void* p, size_t i, int dtype, float v) {
-  if (dtype == MV_F32) ((float*)p)[i] = v; else ((bf16_t*)p)[i] = (bf16_t)v;
+  if (dtype == MV_F32) ((float*)p)[i] = v; else if (dtype == MV_BF16) ((bf16_t*)p)[i] = (bf16_t)v; else ((f16_t*)p)[i] = (f16_t)v;
 }
+// 4 consecutive elements at element offset i (i % 4 == 0, base aligned for the vector width)
+__device__ __forceinline__ f32x4 ld4_any(const void* p, size_t i, int dtype) {
+  return dtype == MV_F32 ? ld4<float>((const float*)p + i) : dtype == MV_BF16 ? ld4<bf16_t>((const bf16_t*)p + i) : ld4<f16_t>((const f16_t*)p + i);
+}
+__device__ __forceinline__ void st4_any(void* p, size_t i, int dtype, f32x4 v) {
+  if (dtype == MV_F32) st4<float>((float*)p + i, v); else if (dtype == MV_BF16) st4<bf16_t>((bf16_t*)p + i, v); else st4<f16_t>((f16_t*)p + i, v);
+}
+__host__ __device__ __forceinline__ bool mv_is16(int dtype) { return dtype == MV_BF16 || dtype == MV_F16; }
+__host__ __device__ __forceinline__ bool mv_dtype_ok(int dtype) { return dtype == MV_F32 || dtype == MV_BF16 || dtype == MV_F16; }
 
 // erf by Abramowitz-Stegun 7.1.26 (|abs error| <= 1.5e-7, i.e. fp32 rounding level): 1 rcp + 1 exp + 6 fma instead
 // of libdevice erff's ~40-instruction branchy polynomial.  The GELU epilogues run it 16384 times per 128x128 tile.
@@ -155,4 +181,4 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
-static inline int mv_dtype_size(int dt) { return dt == MV_F32 ? 4 : 2; }
+static inline int mv_dtype_size(int dt) { return dt == MV_F32 ? 4 : 2; }   // MV_BF16 and MV_F16 are both 2 bytes

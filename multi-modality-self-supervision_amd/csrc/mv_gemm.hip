@@ -20,8 +20,10 @@
 
 struct GemmArgs {
   const void* A; const void* B; void* C; void* C2; const float* bias; const void* R;
-  int M, N, K, lda, ldb, ldc, ldc2, ldr;
-  int c_dtype, r_dtype, epi, accumulate, vec_ok;
+  void* C3;       // optional copy of C in a second 16-bit encoding (c3_dtype): the forward writes the f16 operand of the next
+                  // forward GEMM and the bf16 operand of the backward's weight-gradient GEMM from one accumulator tile
+  int M, N, K, lda, ldb, ldc, ldc2, ldr, ldc3;
+  int c_dtype, r_dtype, c3_dtype, epi, accumulate, vec_ok;
   int kchunk, splitk;
   float* ws;
   unsigned bytesA, bytesB;
@@ -75,6 +77,7 @@ __device__ __forceinline__ void epilogue4_slow(const GemmArgs& p, int m, int n, 
     }
     if (p.c_dtype == MV_F32 && p.accumulate) x += ((const float*)p.C)[co + i];
     st_any(p.C, co + i, p.c_dtype, x);
+    if (p.C3) st_any(p.C3, (size_t)m * p.ldc3 + n + i, p.c3_dtype, x);
   }
 }
 
@@ -90,7 +93,7 @@ __device__ __forceinline__ f32x4 epi_load_res4(const GemmArgs& p, int m, int n) 
   if (m >= p.M) return r;
   if (E == MV_EPI_BIAS_RES || E == MV_EPI_DGELU || E == MV_EPI_RES || E == MV_EPI_MUL || E == MV_EPI_BIAS_RES_RELU) {
     const size_t ro = (size_t)m * p.ldr + n;
-    r = (p.r_dtype == MV_F32) ? ld4<float>((const float*)p.R + ro) : ld4<bf16_t>((const bf16_t*)p.R + ro);
+    r = ld4_any(p.R, ro, p.r_dtype);
   } else if (E == MV_EPI_NONE) {
     if (p.c_dtype == MV_F32 && p.accumulate) r = *(const f32x4*)((const float*)p.C + (size_t)m * p.ldc + n);
   }
@@ -121,7 +124,7 @@ __device__ __forceinline__ void epilogue4v(const GemmArgs& p, int m, int n, f32x
   }
   if (E == MV_EPI_BIAS_GELU) {
     const size_t c2 = (size_t)m * p.ldc2 + n;
-    if (p.c_dtype == MV_F32) st4<float>((float*)p.C2 + c2, o); else st4<bf16_t>((bf16_t*)p.C2 + c2, o);
+    st4_any(p.C2, c2, p.c_dtype, o);
 #pragma unroll
     for (int i = 0; i < 4; ++i) o[i] = gelu_erf(o[i]);
   }
@@ -130,10 +133,10 @@ __device__ __forceinline__ void epilogue4v(const GemmArgs& p, int m, int n, f32x
 #pragma unroll
     for (int i = 0; i < 4; ++i) { float g_, d_; gelu_erf_and_grad(o[i], g_, d_); o[i] = g_; d[i] = d_; }
     const size_t c2 = (size_t)m * p.ldc2 + n;
-    if (p.c_dtype == MV_F32) st4<float>((float*)p.C2 + c2, d); else st4<bf16_t>((bf16_t*)p.C2 + c2, d);
+    st4_any(p.C2, c2, p.c_dtype, d);
   }
-  if (p.c_dtype == MV_F32) st4<float>((float*)p.C + co, o);
-  else st4<bf16_t>((bf16_t*)p.C + co, o);
+  st4_any(p.C, co, p.c_dtype, o);
+  if (p.C3) st4_any(p.C3, (size_t)m * p.ldc3 + n, p.c3_dtype, o);
 }
 
 // run BODY(E) with the run-time epilogue selector turned into a compile-time constant
@@ -159,6 +162,16 @@ __device__ __forceinline__ void store_partial4(const GemmArgs& p, int split, int
   float* w = p.ws + ((size_t)split * p.M + m) * p.N + n;
   if ((p.N & 3) == 0 && nv >= 4) { *(f32x4*)w = v; return; }
   for (int i = 0; i < (nv < 4 ? nv : 4); ++i) w[i] = v[i];
+}
+
+// one 16x16x32 MFMA on 16-bit operands held as bf16x8 bit patterns: F16 selects the f16 encoding (forward operands of
+// the MV_F16 path), otherwise bf16.  Same rate, same fragment layout.
+template <bool F16>
+__device__ __forceinline__ f32x4 mma16(bf16x8 a, bf16x8 b, f32x4 c) {
+  if constexpr (F16)
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -259,7 +272,7 @@ __device__ __forceinline__ bf16x8 load_frag(const char* tile, int base, int ks, 
 
 // SB: ONE 32-KiB LDS stage instead of two (the next K-tile waits in registers, two barriers per K-tile) so that three blocks
 // share a CU: 768 tile slots instead of 512, which turns 2.34 rounds of tiles (N = 768 at ~25k rows) into 1.56.
-template <bool TA, bool TB, bool CONV = false, bool SB = false>
+template <bool TA, bool TB, bool CONV = false, bool SB = false, bool F16 = false>
 __global__ __launch_bounds__(256, SB ? 3 : 2) void gemm_mfma_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -332,7 +345,7 @@ __global__ __launch_bounds__(256, SB ? 3 : 2) void gemm_mfma_kernel(GemmArgs p) 
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+          acc[i][j] = mma16<F16>(fb[j], fa[i], acc[i][j]);
     }
     if (SB) __syncthreads();                     // every wave is done reading the single stage before it is overwritten
     if (more) {
@@ -517,7 +530,7 @@ __device__ __forceinline__ bf16x8 g2_frag(const char* tile, int base, int l15, i
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <bool TA, bool TB, int NJ, int WN, int NSTAGE, int KS>
+template <bool TA, bool TB, int NJ, int WN, int NSTAGE, int KS, bool F16 = false>
 __global__ __launch_bounds__(128 * WN, 2) void gemm_ring_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NW = 2 * WN;                      // waves per block
@@ -605,7 +618,7 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_ring_kernel(GemmArgs p) {
   do {                                                                                           \
     _Pragma("unroll") for (int i = 0; i < 8; ++i)                                                \
     _Pragma("unroll") for (int j = 0; j < NJ; ++j)                                               \
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FB_[j], FA_[i], acc[i][j], 0, 0, 0); \
+        acc[i][j] = mma16<F16>(FB_[j], FA_[i], acc[i][j]);                                       \
   } while (0)
   {
     for (int s = 0; s < nst; ++s) {
@@ -885,41 +898,44 @@ static inline bool aligned_to(const void* p, size_t a) { return p == nullptr || 
 
 extern "C" int mv_gemm(int dtype, int ta, int tb, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
                        void* C, int ldc, int c_dtype, const float* bias, int epi, const void* R, int ldr, int r_dtype,
-                       void* C2, int ldc2, int splitk, float* ws, size_t ws_bytes, int accumulate, float p_drop,
-                       unsigned long long drop_key, void* stream_) {
+                       void* C2, int ldc2, void* C3, int ldc3, int c3_dtype, int splitk, float* ws, size_t ws_bytes,
+                       int accumulate, float p_drop, unsigned long long drop_key, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) return MV_E_ARG;
-  if (dtype != MV_F32 && dtype != MV_BF16) return MV_E_DTYPE;
-  if (c_dtype != MV_F32 && c_dtype != MV_BF16) return MV_E_DTYPE;
+  if (!mv_dtype_ok(dtype) || !mv_dtype_ok(c_dtype)) return MV_E_DTYPE;
+  if (C3 && (!mv_is16(c3_dtype) || ldc3 < N)) return MV_E_DTYPE;
   if (epi < 0 || epi > MV_EPI_BIAS_RES_RELU) return MV_E_ARG;
   const bool need_bias = (epi == MV_EPI_BIAS || epi == MV_EPI_BIAS_GELU || epi == MV_EPI_BIAS_RES || epi == MV_EPI_BIAS_TANH || epi == MV_EPI_BIAS_GELU_D || epi == MV_EPI_BIAS_RELU || epi == MV_EPI_BIAS_RES_RELU);
   const bool need_r = (epi == MV_EPI_BIAS_RES || epi == MV_EPI_DGELU || epi == MV_EPI_RES || epi == MV_EPI_MUL || epi == MV_EPI_BIAS_RES_RELU);
   if (need_bias && !bias) return MV_E_ARG;
-  if (need_r && (!R || (r_dtype != MV_F32 && r_dtype != MV_BF16))) return MV_E_ARG;
+  if (need_r && (!R || !mv_dtype_ok(r_dtype))) return MV_E_ARG;
   if ((epi == MV_EPI_BIAS_GELU || epi == MV_EPI_BIAS_GELU_D) && !C2) return MV_E_ARG;
   if (lda < (ta ? M : K) || ldb < (tb ? N : K) || ldc < N) return MV_E_SHAPE;
   if (need_r && ldr < N) return MV_E_SHAPE;
   if (splitk < 0) splitk = 1;
   if (splitk > 1 || accumulate) {
-    if (epi != MV_EPI_NONE || c_dtype != MV_F32) return MV_E_SHAPE;
+    if (epi != MV_EPI_NONE || c_dtype != MV_F32 || C3) return MV_E_SHAPE;
   }
   if (splitk > 1) {
     if (!ws || ws_bytes < (size_t)splitk * M * N * sizeof(float)) return MV_E_WORKSPACE;
   }
-  if (splitk == 0 && (dtype != MV_BF16 || g_mv_impl != 0)) splitk = 1;   // auto split-K only on the MFMA kernels
+  if (splitk == 0 && (!mv_is16(dtype) || g_mv_impl != 0)) splitk = 1;   // auto split-K only on the MFMA kernels
   GemmArgs p;
-  p.A = A; p.B = B; p.C = C; p.C2 = C2; p.bias = bias; p.R = R;
-  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldc2 = ldc2; p.ldr = ldr;
-  p.c_dtype = c_dtype; p.r_dtype = r_dtype; p.epi = epi; p.accumulate = accumulate;
+  p.A = A; p.B = B; p.C = C; p.C2 = C2; p.bias = bias; p.R = R; p.C3 = C3;
+  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldc2 = ldc2; p.ldr = ldr; p.ldc3 = ldc3;
+  p.c_dtype = c_dtype; p.r_dtype = r_dtype; p.c3_dtype = c3_dtype; p.epi = epi; p.accumulate = accumulate;
   p.splitk = splitk; p.ws = ws; p.dbg = g_mv_gemm_dbg;
   p.drop = mv_make_drop(epi == MV_EPI_BIAS_RES ? p_drop : 0.f, drop_key);
   if (p.drop.thr && (N & 3)) return MV_E_SHAPE;   // the mask is keyed on groups of 4 consecutive columns
   const size_t csz = (c_dtype == MV_F32) ? 16 : 8;
   const size_t rsz = (r_dtype == MV_F32) ? 16 : 8;
-  p.vec_ok = ((ldc & 3) == 0) && aligned_to(C, csz) && (!need_bias || aligned_to(bias, 16)) &&
+  p.vec_ok = ((ldc & 3) == 0) && aligned_to(C, csz) && (!C3 || (((ldc3 & 3) == 0) && aligned_to(C3, 8))) &&
+             (!need_bias || aligned_to(bias, 16)) &&
              (!need_r || (((ldr & 3) == 0) && aligned_to(R, rsz))) &&
              ((epi != MV_EPI_BIAS_GELU && epi != MV_EPI_BIAS_GELU_D) || (((ldc2 & 3) == 0) && aligned_to(C2, csz)));
-  const bool mfma = (dtype == MV_BF16) && (g_mv_impl == 0);
+  const bool mfma = mv_is16(dtype) && (g_mv_impl == 0);
+  const bool f16 = dtype == MV_F16;
+  if (mfma && f16 && (ta || tb)) return MV_E_DTYPE;   // f16 operands exist for the forward form y = x.W^T only
   if (mfma) {
     if ((lda & 7) || (ldb & 7) || !aligned_to(A, 16) || !aligned_to(B, 16)) return MV_E_SHAPE;
     const size_t bytesA = ((size_t)((ta ? K : M) - 1) * lda + (size_t)(((ta ? M : K) + 7) & ~7)) * 2;
@@ -1002,7 +1018,18 @@ extern "C" int mv_gemm(int dtype, int ta, int tb, int M, int N, int K, const voi
     if (variant == 24) LAUNCH_PRING(TA_, TB_, 4, 4, 2);          \
     else LAUNCH_RING(TA_, TB_, 4, 4, 2, 2);                      \
   } while (0)
-      if (!ta && !tb) LAUNCH_RING_V(false, false);
+      if (!ta && !tb) {
+        if (f16) {
+          constexpr size_t shm = (size_t)2 * 2 * (16384 + 16384);
+          static bool attr_set = false;
+          if (!attr_set) {
+            (void)hipFuncSetAttribute((const void*)gemm_ring_kernel<false, false, 4, 4, 2, 2, true>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+            attr_set = true;
+          }
+          hipLaunchKernelGGL((gemm_ring_kernel<false, false, 4, 4, 2, 2, true>), grid, dim3(512), shm, stream, p);
+        } else LAUNCH_RING_V(false, false);
+      }
       else if (!ta && tb) LAUNCH_RING_V(false, true);
       else if (ta && tb) LAUNCH_RING_V(true, true);
       else LAUNCH_RING_V(true, false);
@@ -1048,7 +1075,16 @@ extern "C" int mv_gemm(int dtype, int ta, int tb, int M, int N, int K, const voi
       // one LDS stage and three blocks per CU by default (10-15 % faster on the model's 768-column GEMMs at ~25k rows:
       // profiles/r01_gemm_variants.txt); the two-stage form stays reachable for cross-checks (mv_set_gemm_variant(., 32))
       const bool sb = g_mv_gemm_nj != 32;
-      if (!ta && !tb) { if (sb) LAUNCH_MFMA_SB(false, false); else LAUNCH_MFMA(false, false); }
+      if (f16) {
+        static bool attr_h = false;
+        if (!attr_h) {
+          (void)hipFuncSetAttribute((const void*)gemm_mfma_kernel<false, false, false, true, true>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, GT_STAGE_BYTES);
+          attr_h = true;
+        }
+        hipLaunchKernelGGL((gemm_mfma_kernel<false, false, false, true, true>), grid, block, GT_STAGE_BYTES, stream, p);
+      }
+      else if (!ta && !tb) { if (sb) LAUNCH_MFMA_SB(false, false); else LAUNCH_MFMA(false, false); }
       else if (!ta && tb) { if (sb) LAUNCH_MFMA_SB(false, true); else LAUNCH_MFMA(false, true); }
       else if (ta && tb) { if (sb) LAUNCH_MFMA_SB(true, true); else LAUNCH_MFMA(true, true); }
       else { if (sb) LAUNCH_MFMA_SB(true, false); else LAUNCH_MFMA(true, false); }
@@ -1063,6 +1099,7 @@ extern "C" int mv_gemm(int dtype, int ta, int tb, int M, int N, int K, const voi
     dim3 grid((N + 63) / 64, (M + 63) / 64, splitk), block(256);
     if (grid.y > 65535) return MV_E_SHAPE;
     if (dtype == MV_F32) hipLaunchKernelGGL(gemm_simple_kernel<float>, grid, block, 0, stream, p, ta, tb);
+    else if (dtype == MV_F16) hipLaunchKernelGGL(gemm_simple_kernel<f16_t>, grid, block, 0, stream, p, ta, tb);
     else hipLaunchKernelGGL(gemm_simple_kernel<bf16_t>, grid, block, 0, stream, p, ta, tb);
   }
   MV_CHECK_LAUNCH();

@@ -23,7 +23,8 @@
 template <typename TX, typename TY, int NC>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const TX* __restrict__ x, const float* __restrict__ g,
                                                      const float* __restrict__ bta, TY* __restrict__ y, float* __restrict__ mean,
-                                                     float* __restrict__ rstd, int M, int H, float eps) {
+                                                     float* __restrict__ rstd, int M, int H, float eps,
+                                                     bf16_t* __restrict__ y_bf16) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
@@ -57,6 +58,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TX* __restrict__ x, c
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = (v[n][e] - mu) * rs * gg[e] + bb[e];
       st4<TY>(yr + c, o);
+      if (y_bf16) st4<bf16_t>(y_bf16 + (size_t)row * H + c, o);
     }
   }
   if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
@@ -135,16 +137,18 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TD* __restrict__ dy, 
   }
 }
 
-extern "C" int mv_layernorm_fwd(int dtype, const void* x, int x_dtype, const float* gamma, const float* beta, void* y, float* mean,
-                                float* rstd, int M, int H, float eps, void* stream_) {
+extern "C" int mv_layernorm_fwd(int dtype, const void* x, int x_dtype, const float* gamma, const float* beta, void* y, void* y_bf16,
+                                float* mean, float* rstd, int M, int H, float eps, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!x || !gamma || !beta || !y || !mean || !rstd || M <= 0 || H <= 0) return MV_E_ARG;
   if ((H & 3) || H > MV_MAX_H) return MV_E_SHAPE;
+  if (y_bf16 && dtype != MV_F16) return MV_E_DTYPE;      // the second output is the bf16 copy of an f16 forward activation
   dim3 grid((M + 3) / 4), block(256);
-#define LNF(NC_) hipLaunchKernelGGL((ln_fwd_kernel<TX_, TY_, NC_>), grid, block, 0, stream, (const TX_*)x, gamma, beta, (TY_*)y, mean, rstd, M, H, eps)
+#define LNF(NC_) hipLaunchKernelGGL((ln_fwd_kernel<TX_, TY_, NC_>), grid, block, 0, stream, (const TX_*)x, gamma, beta, (TY_*)y, mean, rstd, M, H, eps, (bf16_t*)y_bf16)
   if (dtype == MV_F32 && x_dtype == MV_F32) { typedef float TX_; typedef float TY_; NC_DISPATCH(H, LNF); }
   else if (dtype == MV_BF16 && x_dtype == MV_F32) { typedef float TX_; typedef bf16_t TY_; NC_DISPATCH(H, LNF); }
   else if (dtype == MV_BF16 && x_dtype == MV_BF16) { typedef bf16_t TX_; typedef bf16_t TY_; NC_DISPATCH(H, LNF); }
+  else if (dtype == MV_F16 && x_dtype == MV_F32) { typedef float TX_; typedef f16_t TY_; NC_DISPATCH(H, LNF); }
   else return MV_E_DTYPE;
 #undef LNF
   MV_CHECK_LAUNCH();
@@ -200,7 +204,7 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(EmbArgs a, const T* __re
                                                         const T* __restrict__ P, const T* __restrict__ Ty,
                                                         const float* __restrict__ g, const float* __restrict__ bta,
                                                         T* __restrict__ x0, float* __restrict__ pre, float* __restrict__ mean,
-                                                        float* __restrict__ rstd, float eps, DropCfg drop) {
+                                                        float* __restrict__ rstd, float eps, DropCfg drop, bf16_t* __restrict__ x0_bf16) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= a.n_rows) return;
@@ -244,6 +248,7 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(EmbArgs a, const T* __re
       for (int e = 0; e < 4; ++e) o[e] = (v[n][e] - mu) * rs * gg[e] + bb[e];
       if (drop.thr) o = mv_drop4(o, (size_t)row * H + c, drop);
       st4<T>(x0 + (size_t)row * H + c, o);
+      if (x0_bf16) st4<bf16_t>(x0_bf16 + (size_t)row * H + c, o);
       *(f32x4*)(pre + (size_t)row * H + c) = v[n];
     }
   }
@@ -341,8 +346,8 @@ static int emb_check(int B, int N, int T, int H, int V, int maxpos) {
 
 extern "C" int mv_embed_fwd(int dtype, const int64_t* cls_tok, const int64_t* txt, const int64_t* segment, const int64_t* img_pos,
                             const int64_t* sep_tok, const void* imgproj, const void* E, const void* P, const void* Ty,
-                            const float* gamma, const float* beta, void* x0, float* pre, float* mean, float* rstd, int B, int N,
-                            int T, int H, int V, int maxpos, float eps, float p_drop, unsigned long long drop_key,
+                            const float* gamma, const float* beta, void* x0, void* x0_bf16, float* pre, float* mean, float* rstd,
+                            int B, int N, int T, int H, int V, int maxpos, float eps, float p_drop, unsigned long long drop_key,
                             const int32_t* rowmap, int n_rows, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!cls_tok || !txt || !segment || !sep_tok || !E || !P || !Ty || !gamma || !beta || !x0 || !pre || !mean || !rstd) return MV_E_ARG;
@@ -354,9 +359,11 @@ extern "C" int mv_embed_fwd(int dtype, const int64_t* cls_tok, const int64_t* tx
   EmbArgs a{cls_tok, txt, segment, img_pos, sep_tok, B, N, T, H, V, maxpos, N + T + 2, rowmap, rowmap ? n_rows : B * (N + T + 2)};
   dim3 grid((a.n_rows + 3) / 4), block(256);
   const DropCfg drop = mv_make_drop(p_drop, drop_key);
-#define EMF(NC_) hipLaunchKernelGGL((embed_fwd_kernel<T_, NC_>), grid, block, 0, stream, a, (const T_*)imgproj, (const T_*)E, (const T_*)P, (const T_*)Ty, gamma, beta, (T_*)x0, pre, mean, rstd, eps, drop)
+  if (x0_bf16 && dtype != MV_F16) return MV_E_DTYPE;
+#define EMF(NC_) hipLaunchKernelGGL((embed_fwd_kernel<T_, NC_>), grid, block, 0, stream, a, (const T_*)imgproj, (const T_*)E, (const T_*)P, (const T_*)Ty, gamma, beta, (T_*)x0, pre, mean, rstd, eps, drop, (bf16_t*)x0_bf16)
   if (dtype == MV_F32) { typedef float T_; NC_DISPATCH(H, EMF); }
   else if (dtype == MV_BF16) { typedef bf16_t T_; NC_DISPATCH(H, EMF); }
+  else if (dtype == MV_F16) { typedef f16_t T_; NC_DISPATCH(H, EMF); }
   else return MV_E_DTYPE;
 #undef EMF
   MV_CHECK_LAUNCH();
@@ -610,6 +617,7 @@ extern "C" int mv_gather_rows(int dtype, const void* src, int lds_, const int32_
   dim3 grid((R + 3) / 4), block(256);
   if (dtype == MV_F32) hipLaunchKernelGGL(gather_rows_kernel<float>, grid, block, 0, stream, (const float*)src, lds_, rows, R, H, (float*)dst, ldd);
   else if (dtype == MV_BF16) hipLaunchKernelGGL(gather_rows_kernel<bf16_t>, grid, block, 0, stream, (const bf16_t*)src, lds_, rows, R, H, (bf16_t*)dst, ldd);
+  else if (dtype == MV_F16) hipLaunchKernelGGL(gather_rows_kernel<f16_t>, grid, block, 0, stream, (const f16_t*)src, lds_, rows, R, H, (f16_t*)dst, ldd);
   else return MV_E_DTYPE;
   MV_CHECK_LAUNCH();
   return MV_OK;
@@ -840,6 +848,10 @@ extern "C" int mv_cast(const void* src, int src_dtype, void* dst, int dst_dtype,
   else if (src_dtype == MV_BF16 && dst_dtype == MV_F32) hipLaunchKernelGGL((cast_kernel<bf16_t, float>), dim3(blocks), dim3(256), 0, stream, (const bf16_t*)src, (float*)dst, n);
   else if (src_dtype == MV_F32 && dst_dtype == MV_F32) hipLaunchKernelGGL((cast_kernel<float, float>), dim3(blocks), dim3(256), 0, stream, (const float*)src, (float*)dst, n);
   else if (src_dtype == MV_BF16 && dst_dtype == MV_BF16) hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), dim3(blocks), dim3(256), 0, stream, (const bf16_t*)src, (bf16_t*)dst, n);
+  else if (src_dtype == MV_F32 && dst_dtype == MV_F16) hipLaunchKernelGGL((cast_kernel<float, f16_t>), dim3(blocks), dim3(256), 0, stream, (const float*)src, (f16_t*)dst, n);
+  else if (src_dtype == MV_F16 && dst_dtype == MV_F32) hipLaunchKernelGGL((cast_kernel<f16_t, float>), dim3(blocks), dim3(256), 0, stream, (const f16_t*)src, (float*)dst, n);
+  else if (src_dtype == MV_F16 && dst_dtype == MV_BF16) hipLaunchKernelGGL((cast_kernel<f16_t, bf16_t>), dim3(blocks), dim3(256), 0, stream, (const f16_t*)src, (bf16_t*)dst, n);
+  else if (src_dtype == MV_BF16 && dst_dtype == MV_F16) hipLaunchKernelGGL((cast_kernel<bf16_t, f16_t>), dim3(blocks), dim3(256), 0, stream, (const bf16_t*)src, (f16_t*)dst, n);
   else return MV_E_DTYPE;
   MV_CHECK_LAUNCH();
   return MV_OK;
@@ -849,8 +861,8 @@ extern "C" int mv_cast(const void* src, int src_dtype, void* dst, int dst_dtype,
 // fused HF AdamW over the flat parameter buffer  (train_origin.py:60,131)
 // =========================================================================================
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                                                    float* __restrict__ v, bf16_t* __restrict__ shadow, size_t n, float step_size,
-                                                    float b1, float b2, float eps, float lr_wd, float gscale) {
+                                                    float* __restrict__ v, bf16_t* __restrict__ shadow, f16_t* __restrict__ shadow16,
+                                                    size_t n, float step_size, float b1, float b2, float eps, float lr_wd, float gscale) {
   const size_t n4 = n / 4;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
     f32x4 pp = *(const f32x4*)(p + 4 * i), gg = *(const f32x4*)(g + 4 * i), mm = *(const f32x4*)(m + 4 * i), vv = *(const f32x4*)(v + 4 * i);
@@ -865,6 +877,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     }
     *(f32x4*)(p + 4 * i) = pp; *(f32x4*)(m + 4 * i) = mm; *(f32x4*)(v + 4 * i) = vv;
     if (shadow) st4<bf16_t>(shadow + 4 * i, pp);
+    if (shadow16) st4<f16_t>(shadow16 + 4 * i, pp);
   }
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
     const size_t i = n4 * 4 + threadIdx.x;
@@ -874,21 +887,23 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     x -= lr_wd * x;
     p[i] = x; m[i] = mm; v[i] = vv;
     if (shadow) shadow[i] = (bf16_t)x;
+    if (shadow16) shadow16[i] = (f16_t)x;
   }
 }
 
-extern "C" int mv_adamw_step(float* p, const float* g, float* m, float* v, void* shadow_bf16, size_t n, float lr, float beta1,
-                             float beta2, float eps, float weight_decay, int step, int correct_bias, float grad_scale, void* stream_) {
+extern "C" int mv_adamw_step(float* p, const float* g, float* m, float* v, void* shadow_bf16, void* shadow_f16, size_t n, float lr,
+                             float beta1, float beta2, float eps, float weight_decay, int step, int correct_bias, float grad_scale,
+                             void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!p || !g || !m || !v || n == 0 || step < 1) return MV_E_ARG;
   if ((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) return MV_E_SHAPE;
-  if (shadow_bf16 && (((uintptr_t)shadow_bf16) & 7)) return MV_E_SHAPE;
+  if ((shadow_bf16 && (((uintptr_t)shadow_bf16) & 7)) || (shadow_f16 && (((uintptr_t)shadow_f16) & 7))) return MV_E_SHAPE;
   double ss = lr;
   if (correct_bias) ss = ss * sqrt(1.0 - pow((double)beta2, step)) / (1.0 - pow((double)beta1, step));
   int blocks = (int)((n / 4 + 255) / 256);
   if (blocks > 4096) blocks = 4096;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(256), 0, stream, p, g, m, v, (bf16_t*)shadow_bf16, n, (float)ss, beta1, beta2, eps,
+  hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(256), 0, stream, p, g, m, v, (bf16_t*)shadow_bf16, (f16_t*)shadow_f16, n, (float)ss, beta1, beta2, eps,
                      lr * weight_decay, grad_scale);
   MV_CHECK_LAUNCH();
   return MV_OK;

@@ -91,7 +91,9 @@ class _Sub(nn.Module):
 class CXRBERT(nn.Module):
     """Multimodal BERT: Masked Language Model + Image Text Matching (cxrbert_origin.py:132-149)."""
 
-    def __init__(self, config, args=None, dtype=torch.bfloat16, device=None, img_encoder=None):
+    def __init__(self, config, args=None, dtype=torch.bfloat16, device=None, img_encoder=None, fwd_operand=None):
+        """dtype: torch.float32 (exact path) or torch.bfloat16 (16-bit MFMA path); fwd_operand: encoding of the forward
+        operands of the 16-bit path, "f16" (default) or "bf16" -- see engine.Engine."""
         super().__init__()
         self.cfg = model_config_from(config)
         self.config = config
@@ -100,7 +102,7 @@ class CXRBERT(nn.Module):
             # the reference's disturbing_mask branch is shape-inconsistent and cannot run
             raise NotImplementedError("disturbing_mask model branch: use the non-cross MASK pattern with the standard branch")
         dev = torch.device(device) if device is not None else torch.device("cuda" if torch.cuda.is_available() else "cpu")
-        self.engine = Engine(self.cfg, dtype=dtype, device=dev)
+        self.engine = Engine(self.cfg, dtype=dtype, device=dev, fwd_operand=fwd_operand)
         if isinstance(img_encoder, str):
             if img_encoder.lower() not in ("resnet50", "cnn"):
                 raise NotImplementedError(f"img_encoder {img_encoder!r}: only the ResNet-50 region encoder is mirrored")

@@ -24,7 +24,8 @@ from dataclasses import asdict, dataclass
 import torch
 
 from . import hip_ops as ops
-from ._lib import (EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_GELU_D, EPI_BIAS_RES, EPI_BIAS_TANH, EPI_MUL, EPI_NONE, EPI_RES, MV_BF16, MV_F32)
+from ._lib import (EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_GELU_D, EPI_BIAS_RES, EPI_BIAS_TANH, EPI_MUL, EPI_NONE, EPI_RES, MV_BF16, MV_F16,
+                   MV_F32)
 
 
 @dataclass
@@ -112,12 +113,30 @@ ALIASES = {  # reference state-dict aliases -> canonical tensor (cxrbert_origin.
 
 
 class Engine:
-    def __init__(self, cfg: ModelConfig, dtype=torch.bfloat16, device="cuda"):
+    """dtype = torch.float32: the exact path (VALU kernels).  dtype = torch.bfloat16: the 16-bit MFMA path -- fp32 master
+    weights, accumulation, residual sums, LayerNorm / softmax statistics, losses and optimizer; every MFMA operand is 16
+    bits wide.  `fwd_operand` picks the ENCODING of the forward operands of that path:
+      "f16"  (default) weights and stored activations that feed a forward product (y = x.W^T, Q.K^T, P.V) are f16 (11-bit
+             significand); every gradient product keeps bf16 operands (8-bit exponent), so a forward activation that the
+             backward needs as a gradient-product operand is stored twice, written from the same registers.  Both
+             encodings run the same MFMA at the same rate.  This is the path that meets the 1e-2 logit tolerance at
+             BERT-base (profiles/r02_bf16_error.txt: with bf16-encoded forward operands the weight rounding alone is
+             1.4e-2 max-abs);
+      "bf16" one bf16 copy of everything (no duplicate activations; the round-1 behaviour)."""
+
+    def __init__(self, cfg: ModelConfig, dtype=torch.bfloat16, device="cuda", fwd_operand=None):
         if dtype not in (torch.float32, torch.bfloat16):
             raise TypeError("compute dtype must be float32 or bfloat16")
+        if fwd_operand is None:
+            fwd_operand = os.environ.get("MV_FWD_OPERAND", "f16")
+        if fwd_operand not in ("f16", "bf16"):
+            raise ValueError("fwd_operand must be 'f16' or 'bf16'")
         self.cfg = cfg
-        self.adt = dtype
+        self.adt = dtype                 # encoding of gradients and of the activations the gradient products read
         self.dt = MV_F32 if dtype == torch.float32 else MV_BF16
+        self.dual = self.dt == MV_BF16 and fwd_operand == "f16"
+        self.fadt = torch.float16 if self.dual else dtype       # encoding of the forward operands
+        self.fdt = MV_F16 if self.dual else self.dt
         self.device = torch.device(device)
         self.layout, self.n_flat = param_layout(cfg)
         self.flat_p = torch.zeros(self.n_flat, dtype=torch.float32, device=self.device)
@@ -125,6 +144,7 @@ class Engine:
         self.flat_m = None
         self.flat_v = None
         self.shadow = torch.zeros(self.n_flat, dtype=torch.bfloat16, device=self.device) if self.dt == MV_BF16 else None
+        self.shadow_f = torch.zeros(self.n_flat, dtype=torch.float16, device=self.device) if self.dual else None
         self.shadow_dirty = True
         self._ws = {}
         self._gemm_ws = None
@@ -136,12 +156,15 @@ class Engine:
 
     # ------------------------------------------------------------------ storage
     def _bind(self):
-        self.p, self.w = {}, {}
+        # p: fp32 master weights; w: what the gradient products read (bf16 shadow); wf: what the forward products read
+        self.p, self.w, self.wf = {}, {}, {}
         src_w = self.shadow if self.dt == MV_BF16 else self.flat_p
+        src_f = self.shadow_f if self.dual else src_w
         for name, (off, shape) in self.layout.items():
             n = math.prod(shape)
             self.p[name] = self.flat_p[off:off + n].view(shape)
             self.w[name] = src_w[off:off + n].view(shape)
+            self.wf[name] = src_f[off:off + n].view(shape)
         self.g = {}
         if self.flat_g is not None:
             for name, (off, shape) in self.layout.items():
@@ -163,7 +186,7 @@ class Engine:
         if device == self.device:
             return self
         # host storage is allowed (state-dict I/O); every kernel call requires device tensors and raises otherwise
-        for k in ("flat_p", "flat_g", "flat_m", "flat_v", "shadow"):
+        for k in ("flat_p", "flat_g", "flat_m", "flat_v", "shadow", "shadow_f"):
             t = getattr(self, k)
             if t is not None:
                 setattr(self, k, t.to(device))
@@ -175,23 +198,26 @@ class Engine:
         return self
 
     def sync_shadow(self):
-        """bf16 mode: refresh the bf16 copy the MFMA kernels read from the fp32 master weights."""
+        """16-bit path: refresh the copies the MFMA kernels read from the fp32 master weights."""
         if self.dt == MV_BF16:
             ops.cast(self.flat_p, self.shadow, self.n_flat)
+        if self.dual:
+            ops.cast(self.flat_p, self.shadow_f, self.n_flat)
         self.shadow_dirty = False
 
     def zero_grad(self):
         self.ensure_grad()
         self.flat_g.zero_()
 
-    def qkv_views(self, l):
-        """fused [3H,H] weight (compute dtype), [3H] bias (f32) and their grads for layer l."""
+    def qkv_views(self, l, fwd=False):
+        """fused [3H,H] weight (forward encoding when `fwd`, else the gradient products' one), [3H] bias (f32) and their
+        grads for layer l."""
         H = self.cfg.hidden
         name = f"enc.encoder.layer.{l}.attention.self.query.weight"
         bname = f"enc.encoder.layer.{l}.attention.self.query.bias"
         off, _ = self.layout[name]
         boff, _ = self.layout[bname]
-        src_w = self.shadow if self.dt == MV_BF16 else self.flat_p
+        src_w = (self.shadow_f if (fwd and self.dual) else self.shadow) if self.dt == MV_BF16 else self.flat_p
         W = src_w[off:off + 3 * H * H].view(3 * H, H)
         b = self.flat_p[boff:boff + 3 * H]
         gW = gb = None
@@ -232,6 +258,12 @@ class Engine:
             self._ws[key] = t
         return t[:n].view(shape)
 
+    def _pair(self, key, shape):
+        """(forward-encoding buffer, gradient-product-encoding buffer) of one stored activation: two buffers on the f16
+        forward path, one and the same otherwise.  The second is passed to the producing kernel as its extra output."""
+        f = self._buf(key, shape, self.fadt)
+        return (f, self._buf(key + "_b", shape, self.adt)) if self.dual else (f, f)
+
     def _gemm_workspace(self, nfloat):
         if self._gemm_ws is None or self._gemm_ws.numel() < nfloat:
             self._gemm_ws = torch.empty(nfloat, dtype=torch.float32, device=self.device)
@@ -251,6 +283,8 @@ class Engine:
         families and carry no label, so they contribute nothing to the loss or to any gradient (include/medvill.h,
         'packed rows').  Hidden states are then [sum(vl), H] and the first return value is that packed matrix."""
         cfg, dt, adt, dev = self.cfg, self.dt, self.adt, self.device
+        fadt, dual = self.fadt, self.dual
+        wf = self.wf
         H, A, I, D = cfg.hidden, cfg.heads, cfg.intermediate, cfg.img_hidden
         dh = H // A
         B, T = input_txt.shape
@@ -287,16 +321,20 @@ class Engine:
         S["txt"] = input_txt.to(dev, i64).contiguous()
         S["segment"] = segment.to(dev, i64).contiguous()
         S["img_pos"] = img_pos.to(dev, i64).contiguous()
-        # region features -> compute dtype (kept: the image projection's weight gradient needs them)
+        # region features -> operand encodings (the gradient-product copy is kept: the image projection's weight
+        # gradient needs it)
         feats_in = img_feats.to(dev).contiguous().view(B * N, D)
-        if feats_in.dtype not in (f32, torch.bfloat16):
+        if feats_in.dtype not in (f32, torch.bfloat16, torch.float16):
             feats_in = feats_in.float()
-        if feats_in.dtype == adt:
-            feats = feats_in
-        else:
-            feats = self._buf("feats", (B * N, D), adt)
-            ops.cast(feats_in, feats, B * N * D)
-        S["feats"] = feats
+
+        def as_dtype(t, want, key):
+            if t.dtype == want:
+                return t
+            o = self._buf(key, tuple(t.shape), want)
+            ops.cast(t, o, t.numel())
+            return o
+        feats = S["feats"] = as_dtype(feats_in, adt, "feats")
+        feats_f = as_dtype(feats_in, fadt, "feats_f") if dual else feats
         # packed mask
         W32, Tt = (Lq + 31) // 32, (Lq + 63) // 64
         bits = self._buf("bits", (B, Lq, W32), torch.int32)
@@ -308,86 +346,101 @@ class Engine:
         S["bits"], S["tinfo"] = bits, tinfo
         # image projection + embeddings
         e = "enc.txt_embeddings."
-        imgproj = self._buf("imgproj", (B * N, H), adt)
-        ops.gemm(feats, self.w["enc.img_embeddings.img_embeddings.weight"], imgproj, M=B * N, N=H, K=D,
+        # Naming below: `x` / `x_b` etc. are the two encodings of one activation -- the forward operand (f16 on the default
+        # 16-bit path) and the copy the backward's gradient products read (bf16); they are the same buffer when the
+        # encodings coincide.  The saved-for-backward dictionaries keep the `_b` one.
+        xb2 = lambda f, b_: b_ if dual else None          # extra output of the producing kernel
+        imgproj = self._buf("imgproj", (B * N, H), fadt)
+        ops.gemm(feats_f, wf["enc.img_embeddings.img_embeddings.weight"], imgproj, M=B * N, N=H, K=D,
                  bias=self.p["enc.img_embeddings.img_embeddings.bias"], epi=EPI_BIAS)
-        x = self._buf("x0", (M, H), adt)
+        x, x_b = self._pair("x0", (M, H))
         pre0 = self._buf("pre0", (M, H), f32)
         mean0, rstd0 = self._buf("mean0", (M,), f32), self._buf("rstd0", (M,), f32)
-        ops.embed_fwd(dt, S["cls_tok"], S["txt"], S["segment"], S["img_pos"], S["sep_tok"], imgproj,
-                      self.w[e + "word_embeddings.weight"], self.w[e + "position_embeddings.weight"],
-                      self.w[e + "token_type_embeddings.weight"], self.p[e + "LayerNorm.weight"], self.p[e + "LayerNorm.bias"],
+        ops.embed_fwd(self.fdt, S["cls_tok"], S["txt"], S["segment"], S["img_pos"], S["sep_tok"], imgproj,
+                      wf[e + "word_embeddings.weight"], wf[e + "position_embeddings.weight"],
+                      wf[e + "token_type_embeddings.weight"], self.p[e + "LayerNorm.weight"], self.p[e + "LayerNorm.bias"],
                       x, pre0, mean0, rstd0, B, N, T, H, cfg.vocab_size, cfg.max_pos, cfg.ln_eps, p_drop=pd,
-                      drop_key=dk[(self.SITE_EMB, 0)], rowmap=rowmap, n_rows=M)
+                      drop_key=dk[(self.SITE_EMB, 0)], rowmap=rowmap, n_rows=M, x0_bf16=xb2(x, x_b))
         S["layers"] = []
         for l in range(cfg.layers):
             p = f"enc.encoder.layer.{l}."
-            Wqkv, bqkv, _, _ = self.qkv_views(l)
+            Wqkv, bqkv, _, _ = self.qkv_views(l, fwd=True)
             a_ = {}
-            a_["x"] = x
-            qkv = a_["qkv"] = self._buf(f"qkv{l}", (M, 3 * H), adt)
-            ops.gemm(x, Wqkv, qkv, M=M, N=3 * H, K=H, bias=bqkv, epi=EPI_BIAS)
-            ctx = a_["ctx"] = self._buf(f"ctx{l}", (M, H), adt)
+            a_["x"] = x_b
+            qkv, qkv_b = self._pair(f"qkv{l}", (M, 3 * H))
+            a_["qkv"] = qkv_b
+            ops.gemm(x, Wqkv, qkv, M=M, N=3 * H, K=H, bias=bqkv, epi=EPI_BIAS, c3=xb2(qkv, qkv_b))
+            ctx, ctx_b = self._pair(f"ctx{l}", (M, H))
+            a_["ctx"] = ctx_b
             lse = a_["lse"] = self._buf(f"lse{l}", (B, A, Lq), f32)
             ops.attn_fwd(qkv, bits, tinfo, ctx, lse, B, Lq, A, dh, p_drop=pd, drop_key=dk[(self.SITE_ATTN, l)], cu=cu,
-                         total_rows=M)
+                         total_rows=M, ctx_bf16=xb2(ctx, ctx_b))
             pre1 = a_["pre1"] = self._buf(f"pre1_{l}", (M, H), f32)
-            ops.gemm(ctx, self.w[p + "attention.output.dense.weight"], pre1, M=M, N=H, K=H,
+            ops.gemm(ctx, wf[p + "attention.output.dense.weight"], pre1, M=M, N=H, K=H,
                      bias=self.p[p + "attention.output.dense.bias"], epi=EPI_BIAS_RES, r=x, p_drop=pd,
                      drop_key=dk[(self.SITE_OUT1, l)])
-            a1 = a_["a"] = self._buf(f"a{l}", (M, H), adt)
+            a1, a1_b = self._pair(f"a{l}", (M, H))
+            a_["a"] = a1_b
             a_["mean1"], a_["rstd1"] = self._buf(f"mean1_{l}", (M,), f32), self._buf(f"rstd1_{l}", (M,), f32)
             ops.layernorm_fwd(pre1, self.p[p + "attention.output.LayerNorm.weight"], self.p[p + "attention.output.LayerNorm.bias"],
-                              a1, a_["mean1"], a_["rstd1"], M, H, cfg.ln_eps)
-            act = a_["i"] = self._buf(f"i{l}", (M, I), adt)
+                              a1, a_["mean1"], a_["rstd1"], M, H, cfg.ln_eps, y_bf16=xb2(a1, a1_b))
+            act, act_b = self._pair(f"i{l}", (M, I))
+            a_["i"] = act_b
             # the second output is gelu'(z), not z: the derivative shares the forward's exp / reciprocal, and the backward
-            # GEMM then only multiplies by it
-            dg = a_["dgelu"] = self._buf(f"dgelu{l}", (M, I), adt)
-            ops.gemm(a1, self.w[p + "intermediate.dense.weight"], act, M=M, N=I, K=H, bias=self.p[p + "intermediate.dense.bias"],
-                     epi=EPI_BIAS_GELU_D, c2=dg)
+            # GEMM then only multiplies by it (an elementwise operand: either encoding serves)
+            dg = a_["dgelu"] = self._buf(f"dgelu{l}", (M, I), fadt)
+            ops.gemm(a1, wf[p + "intermediate.dense.weight"], act, M=M, N=I, K=H, bias=self.p[p + "intermediate.dense.bias"],
+                     epi=EPI_BIAS_GELU_D, c2=dg, c3=xb2(act, act_b))
             pre2 = a_["pre2"] = self._buf(f"pre2_{l}", (M, H), f32)
-            ops.gemm(act, self.w[p + "output.dense.weight"], pre2, M=M, N=H, K=I, bias=self.p[p + "output.dense.bias"],
+            ops.gemm(act, wf[p + "output.dense.weight"], pre2, M=M, N=H, K=I, bias=self.p[p + "output.dense.bias"],
                      epi=EPI_BIAS_RES, r=a1, p_drop=pd, drop_key=dk[(self.SITE_OUT2, l)])
-            x = self._buf(f"x{l + 1}", (M, H), adt)
+            x, x_b = self._pair(f"x{l + 1}", (M, H))
             a_["mean2"], a_["rstd2"] = self._buf(f"mean2_{l}", (M,), f32), self._buf(f"rstd2_{l}", (M,), f32)
             ops.layernorm_fwd(pre2, self.p[p + "output.LayerNorm.weight"], self.p[p + "output.LayerNorm.bias"], x, a_["mean2"],
-                              a_["rstd2"], M, H, cfg.ln_eps)
+                              a_["rstd2"], M, H, cfg.ln_eps, y_bf16=xb2(x, x_b))
             S["layers"].append(a_)
-        S["hidden"] = x
-        pooled = S["pooled"] = self._buf("pooled", (B, H), adt)
+        S["hidden_f"], S["hidden"] = x, x_b
+        pooled, pooled_b = self._pair("pooled", (B, H))
+        S["pooled_f"], S["pooled"] = pooled, pooled_b
         if cu is None:
-            S["h0"], S["h0_ld"] = x, Lq * H             # first row of every sample, addressed in place
+            h0_f, S["h0"], S["h0_ld"] = x, x_b, Lq * H    # first row of every sample, addressed in place
         else:
-            S["h0"], S["h0_ld"] = self._buf("h0", (B, H), adt), H
-            ops.gather_rows(x, H, cu, B, H, S["h0"], H)
-        ops.gemm(S["h0"], self.w["enc.pooler.dense.weight"], pooled, M=B, N=H, K=H, lda=S["h0_ld"],
-                 bias=self.p["enc.pooler.dense.bias"], epi=EPI_BIAS_TANH)
+            h0_f, S["h0"] = self._pair("h0", (B, H))
+            S["h0_ld"] = H
+            ops.gather_rows(x, H, cu, B, H, h0_f, H)
+            if dual:
+                ops.gather_rows(x_b, H, cu, B, H, S["h0"], H)
+        ops.gemm(h0_f, wf["enc.pooler.dense.weight"], pooled, M=B, N=H, K=H, lda=S["h0_ld"],
+                 bias=self.p["enc.pooler.dense.bias"], epi=EPI_BIAS_TANH, c3=xb2(pooled, pooled_b))
         return (x.view(B, Lq, H) if cu is None else x), pooled
 
     # ------------------------------------------------------------------ heads (shared pieces)
     def _itm_forward(self):
         S, H = self.S, self.cfg.hidden
         itm = S["itm"] = self._buf("itm", (S["B"], 2), torch.float32)
-        ops.gemm(S["pooled"], self.w["itm.linear.weight"], itm, M=S["B"], N=2, K=H, bias=self.p["itm.linear.bias"], epi=EPI_BIAS)
+        ops.gemm(S["pooled_f"], self.wf["itm.linear.weight"], itm, M=S["B"], N=2, K=H, bias=self.p["itm.linear.bias"], epi=EPI_BIAS)
         return itm
 
-    def _mlm_forward(self, xr, R, tag, pad=True):
-        """xr [R,H] (compute dtype) -> logits [R, Vp] f32 (Vp = V rounded up to 8 when `pad`; pad columns unspecified)."""
+    def _mlm_forward(self, xr, xr_b, R, tag, pad=True):
+        """xr [R,H] (forward encoding; xr_b = its gradient-product copy) -> logits [R, Vp] f32 (Vp = V rounded up to 8
+        when `pad`; pad columns unspecified)."""
         cfg, H, V = self.cfg, self.cfg.hidden, self.cfg.vocab_size
         f32 = torch.float32
         Vp = (V + 7) // 8 * 8 if pad else V
         hs = self.S[tag] = {}
-        hs["xr"], hs["R"], hs["Vp"] = xr, R, Vp
+        hs["xr"], hs["R"], hs["Vp"] = xr_b, R, Vp
         tact = hs["tact"] = self._buf(tag + "tact", (R, H), f32)
         tz = hs["tz"] = self._buf(tag + "tz", (R, H), f32)
-        ops.gemm(xr, self.w["mlm.predictions.transform.dense.weight"], tact, M=R, N=H, K=H,
+        ops.gemm(xr, self.wf["mlm.predictions.transform.dense.weight"], tact, M=R, N=H, K=H,
                  bias=self.p["mlm.predictions.transform.dense.bias"], epi=EPI_BIAS_GELU, c2=tz)
-        t = hs["t"] = self._buf(tag + "t", (R, H), self.adt)
+        t, t_b = self._pair(tag + "t", (R, H))
+        hs["t"] = t_b
         hs["mean"], hs["rstd"] = self._buf(tag + "mean", (R,), f32), self._buf(tag + "rstd", (R,), f32)
         ops.layernorm_fwd(tact, self.p["mlm.predictions.transform.LayerNorm.weight"],
-                          self.p["mlm.predictions.transform.LayerNorm.bias"], t, hs["mean"], hs["rstd"], R, H, cfg.head_ln_eps)
+                          self.p["mlm.predictions.transform.LayerNorm.bias"], t, hs["mean"], hs["rstd"], R, H, cfg.head_ln_eps,
+                          y_bf16=t_b if self.dual else None)
         logits = hs["logits"] = torch.empty((R, Vp), dtype=f32, device=self.device)
-        ops.gemm(t, self.w["enc.txt_embeddings.word_embeddings.weight"], logits, M=R, N=V, K=H, ldc=Vp,
+        ops.gemm(t, self.wf["enc.txt_embeddings.word_embeddings.weight"], logits, M=R, N=V, K=H, ldc=Vp,
                  bias=self.p["mlm.predictions.bias"], epi=EPI_BIAS)
         return logits
 
@@ -445,7 +498,7 @@ class Engine:
     def heads_full(self):
         """(mlm [B,L,V] f32, itm [B,2] f32) over ALL positions -- the CXRBERT.forward contract."""
         S, V = self.S, self.cfg.vocab_size
-        logits = self._mlm_forward(S["hidden"], S["M"], "hf_", pad=False)
+        logits = self._mlm_forward(S["hidden_f"], S["hidden"], S["M"], "hf_", pad=False)
         itm = self._itm_forward()
         return logits.view(S["B"], S["L"], V), itm.clone()
 
@@ -485,9 +538,11 @@ class Engine:
             dhid = S["dhidden"] = self._buf("dhidden", (M, H), self.adt)
             dhid.zero_()
         if R > 0:
-            xr = self._buf("ht_xr", (R, H), self.adt)
-            ops.gather_rows(S["hidden"], H, label_rows, R, H, xr, H)
-            logits = self._mlm_forward(xr, R, "ht_")
+            xr, xr_b = self._pair("ht_xr", (R, H))
+            ops.gather_rows(S["hidden_f"], H, label_rows, R, H, xr, H)
+            if self.dual:
+                ops.gather_rows(S["hidden"], H, label_rows, R, H, xr_b, H)
+            logits = self._mlm_forward(xr, xr_b, R, "ht_")
             Vp = logits.shape[1]
             dl = torch.empty((R, Vp), dtype=self.adt, device=self.device) if compute_grad else None
             ops.ce_fwd_bwd(logits, Vp, label_ids, R, V, stats[0:3], dl, Vp, grad_scale_dev=mlm_scale_dev,
@@ -612,5 +667,5 @@ class Engine:
         """HF AdamW over the whole flat buffer in one kernel; also refreshes the bf16 shadow."""
         self.ensure_opt()
         ops.adamw_step(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.shadow, self.n_flat, lr, betas[0], betas[1], eps,
-                       weight_decay, step, correct_bias, grad_scale)
+                       weight_decay, step, correct_bias, grad_scale, shadow_f16=self.shadow_f)
         self.shadow_dirty = False

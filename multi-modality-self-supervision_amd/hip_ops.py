@@ -6,7 +6,7 @@ import torch
 
 from . import _lib as L
 from ._lib import (EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_GELU_D, EPI_BIAS_RELU, EPI_BIAS_RES, EPI_BIAS_RES_RELU, EPI_BIAS_TANH, EPI_DGELU,  # noqa: F401
-                   EPI_MUL, EPI_NONE, EPI_RES, MV_BF16,
+                   EPI_MUL, EPI_NONE, EPI_RES, MV_BF16, MV_F16,
                    MV_F32)
 
 
@@ -15,21 +15,23 @@ def _lib():
 
 
 def gemm(a, b, c, *, ta=False, tb=False, M, N, K, lda=None, ldb=None, ldc=None, bias=None, epi=EPI_NONE, r=None, ldr=None,
-         c2=None, ldc2=None, splitk=1, ws=None, accumulate=False, p_drop=0.0, drop_key=0):
-    """c[M,N] = epi(op(a)[M,K] . op(b)[K,N]); see mv_gemm in include/medvill.h."""
-    L.require_cuda(a, b, c, bias, r, c2, ws)
+         c2=None, ldc2=None, c3=None, ldc3=None, splitk=1, ws=None, accumulate=False, p_drop=0.0, drop_key=0):
+    """c[M,N] = epi(op(a)[M,K] . op(b)[K,N]); c3 (optional): the same result in a second 16-bit encoding; see mv_gemm in
+    include/medvill.h."""
+    L.require_cuda(a, b, c, bias, r, c2, c3, ws)
     lda = lda if lda is not None else (M if ta else K)
     ldb = ldb if ldb is not None else (N if tb else K)
     ldc = ldc if ldc is not None else N
     ldr = ldr if ldr is not None else N
     ldc2 = ldc2 if ldc2 is not None else N
+    ldc3 = ldc3 if ldc3 is not None else N
     if a.dtype != b.dtype:
         raise TypeError("gemm operands must share a dtype")
     if bias is not None and bias.dtype != torch.float32:
         raise TypeError("bias must be f32")
     rc = _lib().mv_gemm(L.dt_of(a), int(ta), int(tb), M, N, K, L.ptr(a), lda, L.ptr(b), ldb, L.ptr(c), ldc, L.dt_of(c),
-                        L.ptr(bias), epi, L.ptr(r), ldr, L.dt_of(r) if r is not None else 0, L.ptr(c2), ldc2, splitk,
-                        L.ptr(ws), (ws.numel() * 4) if ws is not None else 0, int(accumulate), float(p_drop), int(drop_key),
+                        L.ptr(bias), epi, L.ptr(r), ldr, L.dt_of(r) if r is not None else 0, L.ptr(c2), ldc2,
+                        L.ptr(c3), ldc3, L.dt_of(c3) if c3 is not None else 0, splitk, L.ptr(ws), (ws.numel() * 4) if ws is not None else 0, int(accumulate), float(p_drop), int(drop_key),
                         L.stream_ptr())
     L.check(rc, f"mv_gemm(M={M},N={N},K={K},ta={ta},tb={tb},epi={epi})")
     return c
@@ -110,8 +112,10 @@ def pack_plan(desc, B, Lq):
     return cu, rowmap, inv
 
 
-def attn_fwd(qkv, bits, tileinfo, ctx, lse, B, Lq, A, dh, p_drop=0.0, drop_key=0, cu=None, total_rows=0):
-    rc = _lib().mv_attn_fwd(L.dt_of(qkv), L.ptr(qkv), L.ptr(bits), L.ptr(tileinfo), L.ptr(ctx), L.ptr(lse), B, Lq, A, dh,
+def attn_fwd(qkv, bits, tileinfo, ctx, lse, B, Lq, A, dh, p_drop=0.0, drop_key=0, cu=None, total_rows=0, ctx_bf16=None):
+    if ctx.dtype != qkv.dtype or (ctx_bf16 is not None and ctx_bf16.dtype != torch.bfloat16):
+        raise TypeError("attn_fwd: ctx shares qkv's encoding; the second output is bf16")
+    rc = _lib().mv_attn_fwd(L.dt_of(qkv), L.ptr(qkv), L.ptr(bits), L.ptr(tileinfo), L.ptr(ctx), L.ptr(ctx_bf16), L.ptr(lse), B, Lq, A, dh,
                             float(p_drop), int(drop_key), L.ptr(cu), int(total_rows), L.stream_ptr())
     L.check(rc, "mv_attn_fwd")
 
@@ -123,8 +127,10 @@ def attn_bwd(qkv, ctx, dctx, lse, bits, tileinfo, dqkv, delta, B, Lq, A, dh, p_d
     L.check(rc, "mv_attn_bwd")
 
 
-def layernorm_fwd(x, gamma, beta, y, mean, rstd, M, H, eps):
-    rc = _lib().mv_layernorm_fwd(L.dt_of(y), L.ptr(x), L.dt_of(x), L.ptr(gamma), L.ptr(beta), L.ptr(y), L.ptr(mean),
+def layernorm_fwd(x, gamma, beta, y, mean, rstd, M, H, eps, y_bf16=None):
+    if y_bf16 is not None and y_bf16.dtype != torch.bfloat16:
+        raise TypeError("layernorm_fwd: the second output is bf16")
+    rc = _lib().mv_layernorm_fwd(L.dt_of(y), L.ptr(x), L.dt_of(x), L.ptr(gamma), L.ptr(beta), L.ptr(y), L.ptr(y_bf16), L.ptr(mean),
                                  L.ptr(rstd), M, H, float(eps), L.stream_ptr())
     L.check(rc, "mv_layernorm_fwd")
 
@@ -137,9 +143,11 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dx, dgamma, dbeta, colsum, M, H, dx_
 
 
 def embed_fwd(dt, cls_tok, txt, segment, img_pos, sep_tok, imgproj, E, P, Ty, gamma, beta, x0, pre, mean, rstd, B, N, T, H, V,
-              maxpos, eps, p_drop=0.0, drop_key=0, rowmap=None, n_rows=0):
+              maxpos, eps, p_drop=0.0, drop_key=0, rowmap=None, n_rows=0, x0_bf16=None):
+    if any(L.dt_of(t) != dt for t in (E, P, Ty, x0)) or (imgproj is not None and L.dt_of(imgproj) != dt):
+        raise TypeError("embed_fwd: tables, imgproj and x0 must be in the encoding `dt`")
     rc = _lib().mv_embed_fwd(dt, L.ptr(cls_tok), L.ptr(txt), L.ptr(segment), L.ptr(img_pos), L.ptr(sep_tok), L.ptr(imgproj),
-                             L.ptr(E), L.ptr(P), L.ptr(Ty), L.ptr(gamma), L.ptr(beta), L.ptr(x0), L.ptr(pre), L.ptr(mean),
+                             L.ptr(E), L.ptr(P), L.ptr(Ty), L.ptr(gamma), L.ptr(beta), L.ptr(x0), L.ptr(x0_bf16), L.ptr(pre), L.ptr(mean),
                              L.ptr(rstd), B, N, T, H, V, maxpos, float(eps), float(p_drop), int(drop_key), L.ptr(rowmap), int(n_rows),
                              L.stream_ptr())
     L.check(rc, "mv_embed_fwd")
@@ -258,8 +266,8 @@ def cast2d(src, lds, dst, ldd, rows, cols):
     L.check(rc, "mv_cast2d")
 
 
-def adamw_step(p, g, m, v, shadow, n, lr, b1, b2, eps, wd, step, correct_bias=True, grad_scale=1.0):
-    rc = _lib().mv_adamw_step(L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), L.ptr(shadow), n, float(lr), float(b1), float(b2),
+def adamw_step(p, g, m, v, shadow, n, lr, b1, b2, eps, wd, step, correct_bias=True, grad_scale=1.0, shadow_f16=None):
+    rc = _lib().mv_adamw_step(L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), L.ptr(shadow), L.ptr(shadow_f16), n, float(lr), float(b1), float(b2),
                               float(eps), float(wd), int(step), int(correct_bias), float(grad_scale), L.stream_ptr())
     L.check(rc, "mv_adamw_step")
 

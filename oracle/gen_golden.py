@@ -18,6 +18,11 @@ Fixtures:
                  summaries, both losses, per-parameter gradient norms + sampled entries
   c1v1k_full.npz same model with V=1024: full logits
   base_s2s.npz   BERT-base L=512 B=1: losses, ITM logits, logit summaries
+  base_full.npz  BERT-base L=512 B=2 ragged, bidirectional (BASELINE config 2's family) + gradients of every parameter
+  base_noncross.npz  BERT-base L=512 B=1, non-cross modality mask (config 4; n2 = 38 is not tile-aligned)
+  base768_s2s.npz    BERT-base L=768 (100 regions + 665 text, max_position_embeddings 768) B=1, seq2seq (config 5)
+
+    python oracle/gen_golden.py --only base_full,base_noncross     # regenerate a subset
   adamw.npz      3-step HF-AdamW known-answer test computed with python floats
 """
 from __future__ import annotations
@@ -176,7 +181,7 @@ def grad_summary(grads: dict, shapes, seed=99):
                 grad_idx=np.stack(idx), grad_vals=np.stack(vals))
 
 
-def run_case(cx, CfgCls, cfg, B, N, S, family, seed, with_grads, full_logits=False, store_hidden=True):
+def run_case(cx, CfgCls, cfg, B, N, S, family, seed, with_grads, full_logits=False, store_hidden=True, ncols=64):
     params = O.make_params(cfg, seed=seed)
     batch = synth.make_batch(cfg, B, N, S, family, seed=seed)
     model = build_reference_model(cx, CfgCls, cfg, N, params)
@@ -197,7 +202,7 @@ def run_case(cx, CfgCls, cfg, B, N, S, family, seed, with_grads, full_logits=Fal
     out["in_mask_bits"] = D.pack_bits(batch["attn_mask"])
     if store_hidden:
         out["hidden"] = hidden.numpy()
-    cols = (np.abs(O.splitmix_uniform(4242, 64)) * cfg.vocab_size).astype(np.int64) % cfg.vocab_size
+    cols = (np.abs(O.splitmix_uniform(4242, ncols)) * cfg.vocab_size).astype(np.int64) % cfg.vocab_size
     out.update(logits_summary(mlm.detach(), np.unique(cols)))
     if full_logits:
         out["mlm"] = mlm.detach().numpy()
@@ -323,29 +328,54 @@ def gen_adamw(out_path):
     print("adamw ->", out_path)
 
 
-def main():
+def main(argv=()):
+    only = None
+    if "--only" in argv:
+        only = set(argv[list(argv).index("--only") + 1].split(","))
+    want = lambda name: only is None or name in only
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
     torch.set_num_threads(8)
     cx, CfgCls = install_shims()
-    gen_masks(os.path.join(OUT, "masks.npz"))
-    gen_adamw(os.path.join(OUT, "adamw.npz"))
+    if want("masks"):
+        gen_masks(os.path.join(OUT, "masks.npz"))
+    if want("adamw"):
+        gen_adamw(os.path.join(OUT, "adamw.npz"))
     c1 = O.CONFIGS["c1"]
     for fam in ("full", "s2s", "bar", "noncross", "1d"):
+        if not want(f"c1_{fam}"):
+            continue
         r = run_case(cx, CfgCls, c1, B=4, N=16, S=45, family=fam, seed=11, with_grads=(fam in ("full", "s2s")))
         np.savez_compressed(os.path.join(OUT, f"c1_{fam}.npz"), **r)
         print("c1", fam, "mlm_loss", float(r["mlm_loss"]), "itm_loss", float(r["itm_loss"]))
     c1v = O.OracleConfig(**{**c1.to_dict(), "vocab_size": 1024})
-    r = run_case(cx, CfgCls, c1v, B=4, N=16, S=45, family="full", seed=12, with_grads=True, full_logits=True)
-    np.savez_compressed(os.path.join(OUT, "c1v1k_full.npz"), **r)
+    if want("c1v1k_full"):
+        r = run_case(cx, CfgCls, c1v, B=4, N=16, S=45, family="full", seed=12, with_grads=True, full_logits=True)
+        np.savez_compressed(os.path.join(OUT, "c1v1k_full.npz"), **r)
     # odd, non-tile-aligned geometry (L=37) to pin ragged handling
-    r = run_case(cx, CfgCls, c1v, B=3, N=5, S=29, family="bar", seed=13, with_grads=True, full_logits=True)
-    np.savez_compressed(os.path.join(OUT, "c1v1k_bar_ragged.npz"), **r)
+    if want("c1v1k_bar_ragged"):
+        r = run_case(cx, CfgCls, c1v, B=3, N=5, S=29, family="bar", seed=13, with_grads=True, full_logits=True)
+        np.savez_compressed(os.path.join(OUT, "c1v1k_bar_ragged.npz"), **r)
     base = O.CONFIGS["base"]
-    r = run_case(cx, CfgCls, base, B=1, N=36, S=473, family="s2s", seed=21, with_grads=False, store_hidden=False)
-    np.savez_compressed(os.path.join(OUT, "base_s2s.npz"), **r)
-    print("base s2s", float(r["mlm_loss"]), float(r["itm_loss"]))
+    if want("base_s2s"):
+        r = run_case(cx, CfgCls, base, B=1, N=36, S=473, family="s2s", seed=21, with_grads=False, store_hidden=False)
+        np.savez_compressed(os.path.join(OUT, "base_s2s.npz"), **r)
+        print("base s2s", float(r["mlm_loss"]), float(r["itm_loss"]))
+    # BASELINE.json configs 2, 4 and 5 at their own scale (256 logit columns per position)
+    if want("base_full"):
+        r = run_case(cx, CfgCls, base, B=2, N=36, S=473, family="full", seed=22, with_grads=True, store_hidden=False, ncols=256)
+        np.savez_compressed(os.path.join(OUT, "base_full.npz"), **r)
+        print("base full", float(r["mlm_loss"]), float(r["itm_loss"]))
+    if want("base_noncross"):
+        r = run_case(cx, CfgCls, base, B=1, N=36, S=473, family="noncross", seed=23, with_grads=False, store_hidden=False, ncols=256)
+        np.savez_compressed(os.path.join(OUT, "base_noncross.npz"), **r)
+        print("base noncross", float(r["mlm_loss"]), float(r["itm_loss"]))
+    if want("base768_s2s"):
+        b768 = O.CONFIGS["base768"]
+        r = run_case(cx, CfgCls, b768, B=1, N=100, S=665, family="s2s", seed=24, with_grads=False, store_hidden=False, ncols=256)
+        np.savez_compressed(os.path.join(OUT, "base768_s2s.npz"), **r)
+        print("base768 s2s", float(r["mlm_loss"]), float(r["itm_loss"]))
 
 
 if __name__ == "__main__":
-    main()
+    main(sys.argv[1:])

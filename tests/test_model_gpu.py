@@ -34,8 +34,8 @@ def load_case(golden_dir, name):
     return z, meta, cfg, P, {k: torch.from_numpy(v) for k, v in batch.items()}
 
 
-def make_model(cfg, P, dtype):
-    m = mv.CXRBERT(cfg_dict(cfg), None, dtype=dtype, device=DEV)
+def make_model(cfg, P, dtype, fwd_operand=None):
+    m = mv.CXRBERT(cfg_dict(cfg), None, dtype=dtype, device=DEV, fwd_operand=fwd_operand)
     m.load_state_dict(P, strict=True)
     m.eval()            # parity runs with dropout off, like the golden vectors (the reference in .eval())
     return m
@@ -66,7 +66,7 @@ def test_forward_matches_reference_golden(golden_dir, name, dtype, tol):
     e_hid = float(np.abs(hid.float().cpu().numpy() - z["hidden"]).max())
     print(f"{name} {dtype}: |dlogits|max={e_log:.2e} |ditm|={e_itm:.2e} |dhidden|={e_hid:.2e}")
     assert e_log < tol and e_itm < tol
-    assert e_hid < (tol if dtype == torch.float32 else 5e-2)       # hidden states are O(3): bf16 storage ulp 1.6e-2
+    assert e_hid < tol                 # hidden states are O(3); the 16-bit path returns them in the f16 encoding
     if "mlm" in z:
         assert float(np.abs(mlm.numpy() - z["mlm"]).max()) < tol
     assert float(np.abs(torch.logsumexp(mlm, -1).numpy() - z["lse"]).max()) < tol
@@ -156,30 +156,75 @@ def test_train_steps_follow_the_oracle(golden_dir):
     assert worst < 2e-4          # 3 updates of size <= 1e-3 each; fp32 rounding in the gradients only
 
 
-def test_bert_base_l512_against_reference_golden(golden_dir):
-    """BERT-base, L=512 (36 regions + 476), s2s mask, B=1: the reference's own numbers."""
-    z, meta, cfg, P, b = load_case(golden_dir, "base_s2s")
+BASE_CASES = ["base_s2s", "base_full", "base_noncross", "base768_s2s"]     # BASELINE.json configs 3 / 2 / 4 / 5 at scale
+
+
+@pytest.mark.parametrize("name", BASE_CASES)
+def test_bert_base_against_reference_golden(golden_dir, name):
+    """BERT-base at the benchmark's own scale against the reference's own numbers: L=512 seq2seq (B=1), L=512
+    bidirectional (B=2, ragged), L=512 non-cross (n2 = 38, not tile-aligned: the block-sparse path) and L=768 seq2seq
+    (max_position_embeddings 768).  Both paths are held to north_star's tolerances on EVERY stored logit:
+    1e-3 (fp32) and 1e-2 (16-bit path: f16 forward operands)."""
+    z, meta, cfg, P, b = load_case(golden_dir, name)
     cols = torch.from_numpy(z["cols"].astype(np.int64))
-    for dtype, tol in ((torch.float32, FP32_TOL), (torch.bfloat16, None)):
+    for dtype, tol in ((torch.float32, FP32_TOL), (torch.bfloat16, BF16_TOL)):
         model = make_model(cfg, P, dtype)
         with torch.no_grad():
             mlm, itm = fwd(model, b)
         mlm, itm = mlm.float().cpu(), itm.float().cpu()
         d = np.abs(mlm[..., cols].numpy() - z["logits_cols"])
+        dl = np.abs(torch.logsumexp(mlm, -1).numpy() - z["lse"])
         ml, il = O.losses(mlm, itm, b["txt_labels"], b["is_aligned"])
-        print(f"base_s2s {dtype}: logits max-abs {d.max():.3e} mean-abs {d.mean():.3e} p99.9 {np.quantile(d, 0.999):.3e} "
-              f"(logit std {z['logits_cols'].std():.3f}); itm {np.abs(itm.numpy() - z['itm']).max():.2e}; "
+        print(f"{name} {dtype}: logits max-abs {d.max():.3e} mean-abs {d.mean():.3e} p99.9 {np.quantile(d, 0.999):.3e} "
+              f"(logit std {z['logits_cols'].std():.3f}); lse {dl.max():.2e}; itm {np.abs(itm.numpy() - z['itm']).max():.2e}; "
               f"mlm_loss {float(ml):.5f} vs {float(z['mlm_loss']):.5f}")
-        if tol is not None:
-            assert d.max() < tol and np.abs(itm.numpy() - z["itm"]).max() < tol
-            assert abs(float(ml) - float(z["mlm_loss"])) < tol
-        else:
-            # bf16 operands at BERT-base depth: SURVEY 7(h) measured 2.9e-2 max-abs for a plain bf16 autocast of the
-            # REFERENCE itself; we hold the bf16 path to the 1e-2 target on the mean and to 5e-2 on the max.
-            assert d.mean() < BF16_TOL and d.max() < 5e-2
-            assert abs(float(ml) - float(z["mlm_loss"])) < BF16_TOL
+        assert d.max() < tol and dl.max() < tol and np.abs(itm.numpy() - z["itm"]).max() < tol
+        assert abs(float(ml) - float(z["mlm_loss"])) < tol and abs(float(il) - float(z["itm_loss"])) < tol
+        assert (mlm.argmax(-1).numpy() == z["argmax"]).mean() > (0.9999 if dtype == torch.float32 else 0.995)
         del model
         torch.cuda.empty_cache()
+
+
+def test_pure_bf16_forward_operands_stay_within_their_measured_bound(golden_dir):
+    """fwd_operand="bf16" (every operand bf16-encoded, no duplicate activations) is kept as an option.  At BERT-base it
+    CANNOT meet 1e-2: rounding the weights alone to bf16 moves the logits by 1.4e-2 (profiles/r02_bf16_error.txt).
+    This test pins what it does reach so that a regression is caught; the tolerance of the contract is asserted on the
+    default path above."""
+    z, meta, cfg, P, b = load_case(golden_dir, "base_s2s")
+    cols = torch.from_numpy(z["cols"].astype(np.int64))
+    model = make_model(cfg, P, torch.bfloat16, fwd_operand="bf16")
+    with torch.no_grad():
+        mlm, itm = fwd(model, b)
+    d = np.abs(mlm.float().cpu()[..., cols].numpy() - z["logits_cols"])
+    print(f"base_s2s pure-bf16 operands: logits max-abs {d.max():.3e} mean-abs {d.mean():.3e} p99.9 {np.quantile(d, 0.999):.3e}")
+    assert d.mean() < 6e-3 and d.max() < 3.5e-2
+
+
+@pytest.mark.parametrize("dtype,rtol", [(torch.float32, 1e-3), (torch.bfloat16, 4e-2)])
+def test_bert_base_gradients_against_reference_golden(golden_dir, dtype, rtol):
+    """Config 2's family at scale (BERT-base, L=512, bidirectional, B=2 ragged): the fused training step's gradient of
+    EVERY parameter against the reference's loss.backward() (norm + 16 sampled entries per tensor)."""
+    z, meta, cfg, P, b = load_case(golden_dir, "base_full")
+    model = make_model(cfg, P, dtype)
+    stats = mv.TrainStep(model, lr=0.0, pack_rows=False)(dict(b), train=True).cpu()
+    tol = FP32_TOL if dtype == torch.float32 else BF16_TOL
+    assert abs(float(stats[0] / stats[1]) - float(z["mlm_loss"])) < tol and abs(float(stats[3] / stats[4]) - float(z["itm_loss"])) < tol
+    names = [str(n) for n in z["grad_names"]]
+    gmax = float(z["grad_norms"].max())
+    worst = 0.0
+    for i, k in enumerate(names):
+        g = model.engine.g[k].float().cpu()
+        ref_norm = float(z["grad_norms"][i])
+        got = g.reshape(-1)[torch.from_numpy(z["grad_idx"][i])].numpy()
+        floor = (1e-5 if dtype == torch.float32 else 3e-2) * gmax
+        efloor = floor if dtype == torch.float32 else 8 * floor / np.sqrt(g.numel())
+        scale = max(ref_norm / np.sqrt(g.numel()), float(np.abs(z["grad_vals"][i]).max()), efloor)
+        e1 = abs(float(g.double().norm()) - ref_norm) / max(ref_norm, floor)
+        e2 = float(np.abs(got - z["grad_vals"][i]).max()) / scale
+        worst = max(worst, e1, e2 * 0.25)
+        assert e1 < rtol, (k, e1, ref_norm)
+        assert e2 < 4 * rtol + 1e-6, (k, e2)
+    print(f"base_full {dtype}: worst gradient deviation {worst:.2e}")
 
 
 def test_dropout_training_step_against_oracle_with_the_same_masks(golden_dir):

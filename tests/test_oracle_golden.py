@@ -128,17 +128,31 @@ def test_gradients_match_reference(golden_dir, name):
     assert np.abs(dE - z["dE_special_rows"]).max() <= 2e-6 * max(1.0, np.abs(z["dE_special_rows"]).max())
 
 
-def test_bert_base_l512_matches_reference(golden_dir):
-    z, meta = _load(golden_dir, "base_s2s.npz")
+@pytest.mark.parametrize("name", ["base_s2s", "base_full", "base_noncross", "base768_s2s"])
+def test_bert_base_matches_reference(golden_dir, name):
+    """BERT-base at the scale of BASELINE.json configs 3 / 2 / 4 / 5 (L = 512 seq2seq, bidirectional B=2 ragged,
+    non-cross; L = 768 seq2seq with max_position_embeddings 768)."""
+    z, meta = _load(golden_dir, name + ".npz")
     cfg, P, b = _oracle_inputs(z, meta)
-    with torch.no_grad():
+    with_grads = "grad_names" in z
+    if with_grads:
+        for w in P.values():
+            w.requires_grad_(True)
+    with torch.set_grad_enabled(with_grads):
         mlm, itm = O.forward(P, cfg, b["cls_tok"], b["input_txt"], b["attn_mask"], b["segment"], b["img_feats"],
                              b["img_pos"], b["sep_tok"])
         ml, il = O.losses(mlm, itm, b["txt_labels"], b["is_aligned"])
     cols = torch.from_numpy(z["cols"].astype(np.int64))
-    assert np.abs(mlm[..., cols].numpy() - z["logits_cols"]).max() < 1e-4
-    assert np.abs(itm.numpy() - z["itm"]).max() < 1e-4
+    assert np.abs(mlm.detach()[..., cols].numpy() - z["logits_cols"]).max() < 1e-4
+    assert np.abs(itm.detach().numpy() - z["itm"]).max() < 1e-4
     assert abs(float(ml) - float(z["mlm_loss"])) < 1e-4 and abs(float(il) - float(z["itm_loss"])) < 1e-4
+    if with_grads:
+        (ml + il).backward()
+        for i, k in enumerate(str(n) for n in z["grad_names"]):
+            ref_norm = float(z["grad_norms"][i])
+            assert abs(float(P[k].grad.double().norm()) - ref_norm) <= 2e-4 * max(ref_norm, 1e-6) + 1e-7, k
+            got = P[k].grad.reshape(-1)[torch.from_numpy(z["grad_idx"][i])].numpy()
+            assert np.abs(got - z["grad_vals"][i]).max() <= 2e-5 * max(1.0, np.abs(z["grad_vals"][i]).max()) + 1e-7, k
 
 
 # ------------------------------------------------------------------ optimizer KAT
