@@ -572,3 +572,128 @@ def test_adamw_known_answer(golden_dir):
         ops.adamw_step(p, g, m, v, sh, 16, lr, b1, b2, eps, wd, t)
         assert np.abs(p.cpu().numpy() - z["p"][t - 1]).max() < 2e-6
     assert torch.equal(sh, p.to(torch.bfloat16))
+
+
+# ------------------------------------------------------------------------------------------ f16 forward operands
+# The forward products of the 16-bit path read f16-encoded operands (MV_F16) and write a forward activation twice: the
+# f16 copy for the next forward product and the bf16 copy for the backward's gradient products (include/medvill.h).
+@pytest.mark.parametrize("impl", ["mfma", "mfma256k64", "simple"])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 256), (130, 70, 200), (1024, 768, 768), (64, 2, 768), (515, 2304, 264), (1030, 3072, 768)])
+def test_gemm_f16_operands(impl, M, N, K):
+    ops.set_impl(1 if impl == "simple" else 0)
+    ops.set_gemm_variant(*VARIANT.get(impl, (0, 0)))
+    try:
+        pad = lambda n: (n + 7) // 8 * 8
+        lda, ldb = pad(K) + 8, pad(K) + 16
+        a, b = rnd((M, lda), torch.float16, 1), rnd((N, ldb), torch.float16, 2)
+        a[:, K:] = 0
+        b[:, K:] = 0
+        c = torch.full((M, N + 3), 7.0, dtype=torch.float32, device=DEV)
+        ops.gemm(a, b, c, M=M, N=N, K=K, lda=lda, ldb=ldb, ldc=N + 3)
+        ref = a[:, :K].double() @ b[:, :K].double().t()
+        assert relerr(c[:, :N], ref) < 2e-5 * math.sqrt(K)
+        assert (c[:, N:] == 7.0).all()
+        # the gradient forms have no f16 variant: refused, never silently computed in another encoding
+        if impl != "simple":
+            with pytest.raises(RuntimeError, match="MV_E_DTYPE"):
+                ops.gemm(a, b, torch.zeros((K, K), dtype=torch.float32, device=DEV), ta=True, tb=True, M=8, N=8, K=8, lda=lda, ldb=ldb, ldc=K)
+    finally:
+        ops.set_impl(0)
+        ops.set_gemm_variant(0, 0)
+
+
+@pytest.mark.parametrize("impl", ["mfma", "mfma256k64"])
+@pytest.mark.parametrize("epi", [EPI_BIAS, EPI_BIAS_RES, EPI_BIAS_GELU_D, EPI_BIAS_TANH])
+@pytest.mark.parametrize("M,N,K", [(256, 384, 128), (200, 132, 72), (300, 1024, 768)])
+def test_gemm_f16_dual_outputs(impl, epi, M, N, K):
+    """C (f16) and C3 (bf16) are the same fp32 result rounded to each encoding; the residual operand may be f16."""
+    a, b = rnd((M, K), torch.float16, 3, 0.5), rnd((N, K), torch.float16, 4, 0.5)
+    bias, r = rnd((N,), torch.float32, 5), rnd((M, N), torch.float16, 6)
+    c = torch.zeros((M, N), dtype=torch.float16, device=DEV)
+    c2 = torch.zeros((M, N), dtype=torch.float16, device=DEV)
+    c3 = torch.zeros((M, N), dtype=torch.bfloat16, device=DEV)
+    ops.set_gemm_variant(*VARIANT.get(impl, (0, 0)))
+    try:
+        ops.gemm(a, b, c, M=M, N=N, K=K, bias=bias, epi=epi, r=r, c2=c2, c3=c3)
+    finally:
+        ops.set_gemm_variant(0, 0)
+    y = a.double() @ b.double().t() + bias.double()
+    ref = {EPI_BIAS: y, EPI_BIAS_RES: y + r.double(), EPI_BIAS_GELU_D: gelu(y), EPI_BIAS_TANH: torch.tanh(y)}[epi]
+    assert relerr(c, ref) < 1.5e-3 and relerr(c3, ref) < 1e-2
+    if epi == EPI_BIAS_GELU_D:
+        assert relerr(c2, dgelu(y)) < 1.5e-3
+    # both copies come from the same accumulator: the bf16 copy equals the f16 copy's value up to one bf16 rounding
+    assert float((c3.double() - c.double()).abs().max()) <= float(ref.abs().max()) * 2.0 ** -8
+
+
+@pytest.mark.parametrize("impl", ["mfma", "simple"])
+@pytest.mark.parametrize("fam,B,A,N,S", [("full", 2, 2, 16, 45), ("s2s", 2, 4, 36, 473), ("noncross", 2, 2, 16, 45), ("mixed", 4, 3, 36, 150),
+                                         ("bar", 3, 2, 5, 29)])
+def test_attention_fwd_f16(impl, fam, B, A, N, S):
+    """f16 q / k / v / P operands: 8x tighter than the bf16 kernel on the same inputs; the bf16 context copy and the
+    backward on the bf16 copy of qkv stay consistent with it."""
+    ops.set_impl(1 if impl == "simple" else 0)
+    try:
+        dh, Lq = 64, N + S + 3
+        H = A * dh
+        mask = _masks(fam, B, N, S).to(DEV)
+        qkv = rnd((B, Lq, 3 * H), torch.float16, 21, 1.0)
+        bits = torch.zeros((B, Lq, (Lq + 31) // 32), dtype=torch.int32, device=DEV)
+        tinfo = torch.zeros((B, (Lq + 63) // 64, (Lq + 63) // 64), dtype=torch.uint8, device=DEV)
+        ops.mask_pack(mask, bits, tinfo)
+        ctx = torch.zeros((B, Lq, H), dtype=torch.float16, device=DEV)
+        ctx_b = torch.zeros((B, Lq, H), dtype=torch.bfloat16, device=DEV)
+        lse = torch.zeros((B, A, Lq), dtype=torch.float32, device=DEV)
+        ops.attn_fwd(qkv.view(B * Lq, 3 * H), bits, tinfo, ctx, lse, B, Lq, A, dh, ctx_bf16=ctx_b)
+        rctx, rlse = attn_ref(qkv.double(), mask, A)
+        assert relerr(ctx, rctx) < 2e-3
+        assert float((lse.double() - rlse).abs().max()) < 1e-3
+        assert relerr(ctx_b, rctx) < 1e-2 and float((ctx_b.double() - ctx.double()).abs().max()) <= float(rctx.abs().max()) * 2.0 ** -8
+        if impl == "mfma":
+            # the gradient products read the bf16 copies (as the engine does): same tolerance as the all-bf16 kernels
+            qkv_b, dctx = qkv.to(torch.bfloat16), rnd((B, Lq, H), torch.bfloat16, 22, 1.0)
+            dqkv = torch.zeros((B, Lq, 3 * H), dtype=torch.bfloat16, device=DEV)
+            delta = torch.zeros((B, A, Lq), dtype=torch.float32, device=DEV)
+            ops.attn_bwd(qkv_b.view(B * Lq, 3 * H), ctx_b, dctx, lse, bits, tinfo, dqkv, delta, B, Lq, A, dh)
+            qd = qkv.double().requires_grad_(True)
+            (attn_ref(qd, mask, A)[0] * dctx.double()).sum().backward()
+            assert relerr(dqkv, qd.grad) < 2e-2
+    finally:
+        ops.set_impl(0)
+
+
+def test_layernorm_embed_adamw_cast_f16():
+    M, H = 513, 768
+    x = rnd((M, H), torch.float32, 31, 2.0) + 0.5
+    g, b = rnd((H,), torch.float32, 32) * 0.1 + 1.0, rnd((H,), torch.float32, 33) * 0.1
+    y, yb = torch.zeros((M, H), dtype=torch.float16, device=DEV), torch.zeros((M, H), dtype=torch.bfloat16, device=DEV)
+    mean, rstd = torch.zeros(M, device=DEV), torch.zeros(M, device=DEV)
+    ops.layernorm_fwd(x, g, b, y, mean, rstd, M, H, 1e-12, y_bf16=yb)
+    ref = torch.nn.functional.layer_norm(x.double(), (H,), g.double(), b.double(), 1e-12)
+    assert relerr(y, ref) < 1e-3 and relerr(yb, ref) < 1e-2
+    with pytest.raises(RuntimeError, match="MV_E_DTYPE"):      # the bf16 copy exists for f16 outputs only
+        ops.layernorm_fwd(x, g, b, yb, mean, rstd, M, H, 1e-12, y_bf16=torch.zeros_like(yb))
+    # casts between the three encodings
+    src = rnd((1000, 7), torch.float32, 40)
+    h = torch.zeros((1000, 7), dtype=torch.float16, device=DEV)
+    ops.cast(src, h, src.numel())
+    assert torch.equal(h, src.to(torch.float16))
+    bb = torch.zeros((1000, 7), dtype=torch.bfloat16, device=DEV)
+    ops.cast(h, bb, h.numel())
+    assert torch.equal(bb, h.to(torch.bfloat16))
+    f = torch.zeros((1000, 7), dtype=torch.float32, device=DEV)
+    ops.cast(h, f, h.numel())
+    assert torch.equal(f, h.float())
+    # gather of 16-bit rows is encoding-agnostic
+    rows = torch.tensor([5, 0, -1, 999], dtype=torch.int32, device=DEV)
+    h8 = rnd((1000, 8), torch.float16, 41)
+    out = torch.ones((4, 8), dtype=torch.float16, device=DEV)
+    ops.gather_rows(h8, 8, rows, 4, 8, out, 8)
+    assert torch.equal(out[0], h8[5]) and torch.equal(out[3], h8[999]) and bool((out[2] == 0).all())
+    # AdamW refreshes both shadows
+    n = 1003
+    p, gr = rnd((n,), torch.float32, 50), rnd((n,), torch.float32, 51)
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    sb, sh = torch.zeros(n, dtype=torch.bfloat16, device=DEV), torch.zeros(n, dtype=torch.float16, device=DEV)
+    ops.adamw_step(p, gr, m, v, sb, n, 1e-3, 0.9, 0.999, 1e-6, 0.0, 1, shadow_f16=sh)
+    assert torch.equal(sb, p.to(torch.bfloat16)) and torch.equal(sh, p.to(torch.float16))
