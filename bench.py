@@ -1,34 +1,36 @@
 #!/usr/bin/env python3
 """Benchmark of the MedViLL / CXRBERT pretraining step on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W            (N = 1)
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
+    python bench.py --gpus N --steps K --warmup W
 
-One "step" = the loop body of models/train_origin.py:95-146 on one synthetic mini-batch that is
-already resident in HBM: forward, CE(mlm, ignore -100) + CE(itm), backward, HF AdamW, the
-ITM/MLM accuracy counters, and (N > 1) the RCCL gradient all-reduce.  Workload = BASELINE.json
-configs[1]: BERT-base (12L/12H/768), L = 512 (36 regions + 476 text), bidirectional mask, bf16
-MFMA path, batch 64 per GPU (weak scaling), random-init weights, synthetic inputs.
+N = 1 runs in this process.  N > 1 needs one process per GPU: when WORLD_SIZE is not set, this script starts
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py ...` itself as a CHILD process (before
+anything here touches the GPU) and relays rank 0's JSON line; launched under torchrun it reads RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_* from the environment.
+
+One "step" = the loop body of models/train_origin.py:95-146 on one synthetic mini-batch that is already resident in
+HBM: forward, CE(mlm, ignore -100) + CE(itm), backward, HF AdamW, the ITM/MLM accuracy counters, and (N > 1) the RCCL
+gradient all-reduce.  Workload = BASELINE.json configs[1]: BERT-base (12L/12H/768), L = 512 (36 regions + 476 text),
+bidirectional mask, 16-bit MFMA path, batch 64 per GPU (weak scaling), random-init weights, synthetic inputs.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline     whole-step model FLOPs (dense MFU convention, 364.076 GFLOP/sample)
-               against the dense bf16 MFMA peak, plus the dominant kernel (the MFMA GEMM) timed
-               alone with HIP events on its own stream;
-  cpu_baseline the CPU oracle (a port; the reference's Python cannot travel) timed on the host
-               cores on a bounded sample (B = 2, same shape).
+  roofline     the dominant kernel (the FFN-up MFMA GEMM with its fused epilogue) timed alone with HIP events on its
+               stream, against the dense bf16 MFMA peak; `roofline.step` carries the whole step: `frac` = EXECUTED FLOP
+               rate / peak, `dense_frac` = SURVEY 8d's dense MFU convention (364.076 GFLOP/sample);
+  cpu_baseline the CPU oracle (a port; the reference's Python cannot travel) timed on the host cores on a bounded
+               sample (B = 2, same shape).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
-
-PEAK_BF16_TFLOPS = 2500.0       # MI355X dense bf16 MFMA (MI355X_MICROARCH.md); never the 2:1-sparse figure
+PEAK_BF16_TFLOPS = 2500.0       # MI355X dense bf16 / f16 MFMA (MI355X_MICROARCH.md); never the 2:1-sparse figure
 CONFIGS = {
     "c2": dict(name="BERT-base L512 (36 regions + 476 text) bidirectional", N=36, S=473, family="full", max_pos=512),
     "c3": dict(name="BERT-base L512 Bi+Seq2Seq mixed 75/25", N=36, S=473, family="mixed", max_pos=512),
@@ -44,6 +46,7 @@ def flops_fwd_per_sample(H, I, V, D, layers, L, N):
 def cpu_baseline(cfgname, steps=3):
     """The oracle's training step (forward + both CE + autograd backward + HF AdamW, dropout on like
     the reference's train mode) on the host cores; B = 2."""
+    import torch
     from oracle import cxrbert_oracle as O
     from oracle import synth
     c = CONFIGS[cfgname]
@@ -80,34 +83,66 @@ def cpu_baseline(cfgname, steps=3):
                        f"same shape ({c['name']}); host CPU: {model}")
 
 
+def pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/, written by
+    profiles/tools/pmc_traffic.py from separate FETCH_SIZE / WRITE_SIZE runs): an offline measurement of the same
+    kernel on the same shape, not of this run.  None when the file is absent."""
+    p = os.path.join(ROOT, "profiles", "r02_dominant_kernel_pmc.json")
+    try:
+        with open(p) as f:
+            d = json.load(f)
+        return float(d["hbm_bytes_per_launch"]), d.get("note", "")
+    except (OSError, KeyError, ValueError):
+        return None, "no committed PMC pass for this build"
+
+
 def time_dominant_kernel(eng, B, L):
-    """The FFN-up projection GEMM ([B*L,768] x [3072,768]^T + bias + GELU) alone, HIP events on its stream."""
+    """The FFN-up projection of one layer ([B*L,768] x [3072,768]^T + bias, GELU and GELU' epilogue, all the outputs the
+    training step writes) alone: HIP events around 20 launches on the stream it is launched on."""
+    import torch
     import medvill_amd.hip_ops as ops
-    from medvill_amd._lib import EPI_BIAS_GELU_D as EPI_BIAS_GELU
+    from medvill_amd._lib import EPI_BIAS_GELU_D
     M, H, I = B * L, eng.cfg.hidden, eng.cfg.intermediate
     p = "enc.encoder.layer.0."
-    x = eng._buf("x0", (M, H), eng.adt)
-    out, z = eng._buf("i0", (M, I), eng.adt), eng._buf("dgelu0", (M, I), eng.adt)
+    x = eng._buf("a0", (M, H), eng.fadt)
+    out, out_b = eng._pair("i0", (M, I))
+    dg = eng._buf("dgelu0", (M, I), eng.fadt)
+    w, bias = eng.wf[p + "intermediate.dense.weight"], eng.p[p + "intermediate.dense.bias"]
+    c3 = out_b if eng.dual else None
     st = torch.cuda.current_stream()
     reps = 20
+
+    def launch():
+        ops.gemm(x, w, out, M=M, N=I, K=H, bias=bias, epi=EPI_BIAS_GELU_D, c2=dg, c3=c3)
     for _ in range(3):
-        ops.gemm(x, eng.w[p + "intermediate.dense.weight"], out, M=M, N=I, K=H, bias=eng.p[p + "intermediate.dense.bias"],
-                 epi=EPI_BIAS_GELU, c2=z)
+        launch()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(st)
     for _ in range(reps):
-        ops.gemm(x, eng.w[p + "intermediate.dense.weight"], out, M=M, N=I, K=H, bias=eng.p[p + "intermediate.dense.bias"],
-                 epi=EPI_BIAS_GELU, c2=z)
+        launch()
     e1.record(st)
     e1.synchronize()
     ms = e0.elapsed_time(e1) / reps
     fl = 2.0 * M * H * I
-    return dict(kernel="gemm_ring_kernel<NT, 256x256x64> 32768x3072x768 +bias+GELU (writes gelu(z) and gelu'(z))", ms=ms,
-                tflops=fl / ms / 1e9, algorithmic_flop=fl,
-                algorithmic_bytes=2.0 * (M * H + I * H + 2 * M * I),
-                hbm_traffic_pmc_bytes=6.24e8,
-                traffic_note="rocprofv3 --pmc, separate passes: FETCH_SIZE 110,887 KB x2 (gfx950 wide-read correction) = 221.8 MB "
-                             "+ WRITE_SIZE 393,216 KB = 402.7 MB per launch (profiles/r01_gemm_pmc.txt)")
+    nout = 3 if eng.dual else 2
+    enc = "f16" if eng.dual else "bf16"
+    traffic, note = pmc_traffic()
+    return dict(kernel=f"gemm_ring_kernel<NT, 256x256x64, {enc} operands> {M}x{I}x{H} +bias+GELU (writes gelu(z) and gelu'(z)"
+                       + (" in f16 and gelu(z) again in bf16 for the weight-gradient product)" if eng.dual else ")"),
+                ms=ms, tflops=fl / ms / 1e9, algorithmic_flop=fl, algorithmic_bytes=2.0 * (M * H + I * H + nout * M * I),
+                hbm_traffic_pmc_bytes=traffic, traffic_note=note)
+
+
+def spawn_ranks(args):
+    """--gpus N > 1 without a torch.distributed environment: start the N ranks as a child job (never exec: nothing in
+    this process has touched the GPU, and it stays that way) and relay its output."""
+    port = int(os.environ.get("MASTER_PORT", "0")) or (29500 + os.getpid() % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run(cmd, env=env)
+    raise SystemExit(r.returncode)
 
 
 def main():
@@ -118,18 +153,26 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="per-GPU mini-batch")
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary timings (padded / BAR / non-cross / full-length / bf16 operands)")
+    ap.add_argument("--fwd-operand", default=None, choices=["f16", "bf16"], help="encoding of the forward MFMA operands (default f16)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs a torch.distributed launch with WORLD_SIZE={args.gpus} (got {world})")
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import torch
     # rehearsal hooks for a 1-GPU box: MV_DIST_BACKEND=gloo MV_SINGLE_DEVICE=1 run every rank on cuda:0 over gloo
     if os.environ.get("MV_SINGLE_DEVICE") == "1":
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    backend = None
+    rccl_ranks = 1
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -138,68 +181,76 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
+        probe = torch.ones(1, device=dev)
+        dist.all_reduce(probe)                                       # the communicator really spans `world` ranks
+        rccl_ranks = int(round(float(probe[0])))
+        assert rccl_ranks == dist.get_world_size() == world
 
     import medvill_amd as mv
     c = CONFIGS[args.config]
     cfg = mv.ModelConfig(max_pos=c["max_pos"])
-    torch.manual_seed(1234)                                 # identical init on every rank: no parameter broadcast
-    model = mv.CXRBERT(cfg, None, dtype=torch.bfloat16, device=dev)
+    torch.manual_seed(1234)                                 # identical init on every rank (checked by TrainStep's checksum)
+    model = mv.CXRBERT(cfg, None, dtype=torch.bfloat16, device=dev, fwd_operand=args.fwd_operand)
     model.train()                                           # dropout 0.1 at every site, like the reference's train()
     step = mv.TrainStep(model, lr=1e-5, distributed=(world > 1))
     B, N, S = args.batch, c["N"], c["S"]
     L = N + S + 3
-    # a few distinct resident batches so that successive steps do not see identical data
-    batches = [mv.data.synthetic_batch(cfg.vocab_size, B, N, S, c["family"], seed=1234 + 1000 * i + rank, device=dev)
-               for i in range(4)]
+
+    def make_batches(family, lengths=None, n=4):
+        # a few distinct resident batches so that successive steps do not see identical data
+        return [mv.data.synthetic_batch(cfg.vocab_size, B, N, S, family, seed=1234 + 1000 * i + rank, device=dev, lengths=lengths)
+                for i in range(n)]
+    batches = make_batches(c["family"])
 
     def sync():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        step(batches[i % len(batches)])
-    sync()
-    print(f"[bench] rank {rank}: warm-up done", file=sys.stderr, flush=True)
-    t0 = time.perf_counter()
-    stats = None
-    for i in range(args.steps):
-        stats = step(batches[i % len(batches)])
-    sync()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t[0])
-    ms_per_step = dt / args.steps * 1e3
-    print(f"[bench] rank {rank}: {ms_per_step:.2f} ms/step", file=sys.stderr, flush=True)
-    value = world * B * args.steps / dt
-    st = stats.cpu()
-    packed = model.engine.S.get("cu") is not None
-    padded_ms = None
-    if packed:
-        # for transparency: the same step with padding removal switched off (every padded position computed, like the
-        # reference does), timed after the headline region on the same batches; reported as config.padded_*
-        step.pack_rows = False
-        n2 = max(2, min(args.steps, 5))
-        for i in range(2):
-            step(batches[i % len(batches)])
+    def timed(st, bs, warm, n):
+        """ms per step of `n` steps after `warm` untimed ones; barrier + device sync on both sides, max over ranks."""
+        for i in range(warm):
+            st(bs[i % len(bs)])
         sync()
-        t1 = time.perf_counter()
-        for i in range(n2):
-            step(batches[i % len(batches)])
+        t0 = time.perf_counter()
+        out = None
+        for i in range(n):
+            out = st(bs[i % len(bs)])
         sync()
-        d2 = time.perf_counter() - t1
+        dt = time.perf_counter() - t0
         if world > 1:
-            t = torch.tensor([d2], dtype=torch.float64, device=dev)
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-            d2 = float(t[0])
-        padded_ms = d2 / n2 * 1e3
-        step.pack_rows = True
+            dt = float(t[0])
+        return dt / n * 1e3, out
+
+    step.time_exchange = world > 1
+    ms_per_step, stats = timed(step, batches, args.warmup, args.steps)
+    print(f"[bench] rank {rank}: {ms_per_step:.2f} ms/step", file=sys.stderr, flush=True)
+    value = world * B / (ms_per_step / 1e3)
+    st = stats.cpu()
+    exposed_ms = step.exchange_exposed_ms() if world > 1 else 0.0
+    packed = model.engine.S.get("cu") is not None
+
+    extras = {}
+    if not args.no_extras:
+        n2 = max(2, min(args.steps, 5))
+        if packed:
+            # the same step with padding removal switched off (every padded position computed, like the reference does)
+            step.pack_rows = False
+            extras["padded_ms_per_step"], _ = timed(step, batches, 2, n2)
+            step.pack_rows = True
+        if args.config == "c2":
+            # every sample at full length (vl = L): the headline's rows are ragged, these are not
+            extras["full_length_ms_per_step"], _ = timed(step, make_batches(c["family"], lengths=[S] * B, n=2), 2, n2)
+            # the reference's DEFAULT mask (BAR, main_origin.py:91) and config 4's non-cross mask: padding is visible in
+            # both, so they always run the padded layout
+            extras["bar_ms_per_step"], _ = timed(step, make_batches("bar", n=2), 2, n2)
+            extras["noncross_ms_per_step"], _ = timed(step, make_batches("noncross", n=2), 2, n2)
     if rank == 0:
         f_fwd = flops_fwd_per_sample(cfg.hidden, cfg.intermediate, cfg.vocab_size, cfg.img_hidden, cfg.layers, L, N)
         f_step = 3.0 * f_fwd
-        achieved = value / world * f_step / 1e12
+        dense = value / world * f_step / 1e12
         # executed FLOPs: the MLM head runs on the labelled rows only (unlabelled rows have zero loss and gradient), and
         # with padding removal the encoder runs on the valid rows only (positions after the text [SEP] are invisible to
         # every valid query in the full / seq2seq families and carry no label)
@@ -209,32 +260,48 @@ def main():
         rows_mean = float(vls.mean())
         f_enc = cfg.layers * (rows_mean * (8.0 * Hh * Hh + 4.0 * Hh * Ii) + 4.0 * float((vls * vls).mean()) * Hh)
         f_exec = 3.0 * (2.0 * N * cfg.img_hidden * Hh + f_enc + 2.0 * Hh * Hh + n_lab * (2.0 * Hh * Hh + 2.0 * Hh * Vv) + 4.0 * Hh)
+        executed = value / world * f_exec / 1e12
         kern = time_dominant_kernel(model.engine, B, L)
+        eng = model.engine
+        pps = lambda ms: (world * B / (ms / 1e3)) if ms else None
         out = {
             "metric": "image-text pairs/sec pretraining step, BERT-base seq512", "value": value, "unit": "pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16/f16" if eng.dual else "bf16", "data": "synthetic",
             "config": {"workload": c["name"], "per_gpu_batch": B, "global_batch": B * world, "seq_len": L, "regions": N,
                        "mask": c["family"], "layers": cfg.layers, "hidden": cfg.hidden, "vocab": cfg.vocab_size,
                        "parallelism": f"dp{world}", "optimizer": "HF AdamW fused", "dropout": cfg.dropout,
+                       "precision": ("16-bit MFMA operands, fp32 accumulate / residual sums / statistics / optimizer; forward operands "
+                                     "f16-encoded, gradient-product operands bf16-encoded (BERT-base logits 3.5e-3 max-abs from the "
+                                     "reference; bf16-encoded forward operands give 2.6e-2: profiles/r02_bf16_error.txt)") if eng.dual
+                       else "16-bit MFMA operands, all bf16-encoded",
                        "rows": (f"padding removed: encoder on the valid rows only (mean {rows_mean:.1f} of {L} positions per sample; "
                                 "results equal the padded run)") if packed else "padded",
-                       "padded_ms_per_step": padded_ms, "padded_pairs_per_s": (world * B / (padded_ms / 1e3)) if padded_ms else None,
+                       "padded_ms_per_step": extras.get("padded_ms_per_step"), "padded_pairs_per_s": pps(extras.get("padded_ms_per_step")),
+                       "full_length_ms_per_step": extras.get("full_length_ms_per_step"),
+                       "full_length_pairs_per_s": pps(extras.get("full_length_ms_per_step")),
+                       "bar_mask_ms_per_step": extras.get("bar_ms_per_step"), "bar_mask_pairs_per_s": pps(extras.get("bar_ms_per_step")),
+                       "noncross_mask_ms_per_step": extras.get("noncross_ms_per_step"),
+                       "noncross_mask_pairs_per_s": pps(extras.get("noncross_ms_per_step")),
+                       "rccl_ranks": rccl_ranks, "dist_backend": backend, "allreduce_exposed_ms": exposed_ms,
                        "mlm_loss": float(st[0] / max(float(st[1]), 1.0)), "itm_loss": float(st[3] / max(float(st[4]), 1.0))},
             # dominant kernel (the FFN-up GEMM, largest single share of the step): algorithmic FLOPs per launch / its
             # average duration, HIP events around 20 launches on its own stream (time_dominant_kernel); traffic = HBM bytes
-            # per launch from rocprofv3 PMC passes of the same kernel (profiles/r01_gemm_pmc.txt)
+            # per launch from the committed rocprofv3 PMC passes of the same kernel and shape (profiles/), not of this run
             "roofline": {"bound": "mfma", "achieved": kern["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": kern["tflops"] / PEAK_BF16_TFLOPS, "traffic": kern["hbm_traffic_pmc_bytes"],
                          "kernel": kern,
-                         "step": {"achieved": achieved, "frac": achieved / PEAK_BF16_TFLOPS, "flop_per_sample": f_step,
-                                  "convention": "dense model FLOPs of the whole step, backward = 2 x forward (SURVEY 8d)",
-                                  "executed_tflops": value / world * f_exec / 1e12}},
+                         "step": {"achieved": executed, "frac": executed / PEAK_BF16_TFLOPS,
+                                  "convention": "EXECUTED FLOPs of the whole step (valid rows, labelled rows) / dense 16-bit MFMA peak",
+                                  "dense_tflops": dense, "dense_frac": dense / PEAK_BF16_TFLOPS, "flop_per_sample_dense": f_step,
+                                  "dense_convention": "dense model FLOPs, backward = 2 x forward (SURVEY 8d), whatever was skipped"}},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.config)
         print(json.dumps(out), flush=True)
     if world > 1:
+        torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 
 

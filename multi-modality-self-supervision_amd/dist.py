@@ -9,7 +9,9 @@ needs:
   * sum all-reduce of the flat fp32 gradient, cut into contiguous buckets (heads, one per
     encoder layer, embeddings) that are launched on a side stream as soon as the backward has
     finished them, so the exchange overlaps the remaining backward kernels.
-Parameters are never broadcast after construction: identical init + identical updates.
+Parameters are never broadcast after construction: identical init + identical updates; `check_replicas` proves the
+"identical init" half once, at TrainStep construction, with an all-reduced checksum (a per-rank seed would otherwise
+diverge silently).
 """
 from __future__ import annotations
 
@@ -45,6 +47,22 @@ class GradAllReducer:
         self.works = []
         self._pending_hi = None
         self._pending_ev = []
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.timing = False            # bench: record how long the compute stream waits for the exchange in finish()
+        self._exposed = []
+
+    def check_replicas(self, flat_p: torch.Tensor):
+        """Raise unless every rank holds the same parameters (sum and sum of squares, all-reduced MIN and MAX)."""
+        if self.world == 1:
+            return
+        d = flat_p.double()
+        c = torch.stack([d.sum(), (d * d).sum()])
+        lo, hi = c.clone(), c.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.group)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.group)
+        if not torch.equal(lo, hi):
+            raise RuntimeError("data-parallel replicas start from different parameters (seed torch identically on every rank "
+                               f"before building the model, or load the same checkpoint): checksum range {lo.tolist()} .. {hi.tolist()}")
 
     def global_counts(self, n_labelled: int, batch: int, device):
         """-> f32[2] device tensor (n_labelled_global, B_global); one small all-reduce."""
@@ -89,7 +107,23 @@ class GradAllReducer:
 
     def finish(self):
         """Make the current stream wait for every outstanding bucket."""
+        timed = self.timing and self.cuda and self.works
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(torch.cuda.current_stream())
         for w in self.works:
             w.wait()
+        if timed:
+            e1.record(torch.cuda.current_stream())
+            self._exposed.append((e0, e1))
         self.works.clear()
         self._pending_hi = None
+
+    def exposed_ms(self):
+        """Mean time per step the compute stream spent waiting in finish() (events recorded while `timing`)."""
+        if not self._exposed:
+            return 0.0
+        torch.cuda.synchronize()
+        v = [a.elapsed_time(b) for a, b in self._exposed]
+        self._exposed.clear()
+        return sum(v) / len(v)

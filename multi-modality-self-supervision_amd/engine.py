@@ -150,8 +150,10 @@ class Engine:
         self._gemm_ws = None
         self._side = None             # side HIP stream for the weight-gradient GEMMs of the backward
         self.training = False         # dropout is active only when True (CXRBERT.train() / TrainStep(train=True))
-        self.drop_seed = 0x5DEECE66D
-        self.drop_counter = 0         # advanced once per forward: every step draws fresh masks
+        # dropout stream: keyed by torch's seed (set_seed of utils/utils.py:9-16 -> torch.manual_seed), a per-rank offset
+        # added by TrainStep under data parallelism, and a counter advanced once per forward (every step draws fresh masks)
+        self.drop_seed = (torch.initial_seed() ^ 0x5DEECE66D) & 0xFFFFFFFFFFFFFFFF
+        self.drop_counter = 0
         self._bind()
 
     # ------------------------------------------------------------------ storage
@@ -344,6 +346,9 @@ class Engine:
         else:
             ops.mask_pack(attn_mask.to(dev), bits, tinfo)
         S["bits"], S["tinfo"] = bits, tinfo
+        if bits.is_cuda:
+            S["bits_ev"] = torch.cuda.Event()
+            S["bits_ev"].record(torch.cuda.current_stream())
         # image projection + embeddings
         e = "enc.txt_embeddings."
         # Naming below: `x` / `x_b` etc. are the two encodings of one activation -- the forward operand (f16 on the default

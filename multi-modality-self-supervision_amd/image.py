@@ -68,8 +68,29 @@ class ImageEncoder_cnn(nn.Module):
         self._wcache = {}
         self._bncache = {}
         self._foldcache = {}
+        self.weights_loaded = False       # True once trained weights arrived: the reference builds resnet50(pretrained=True)
         self.fold_bn = True               # eval(), bf16: BatchNorm folded into the convolutions' weights and epilogues (test switch)
         self.implicit_conv = True         # bf16 path: mv_conv2d instead of mv_im2col + mv_gemm (test switch)
+
+    # ---- weights: the reference's trunk is torchvision's pretrained resnet50 (models/image.py:50-52)
+    _TV_PREFIX = {"conv1.": "model.0.", "bn1.": "model.1.", "layer1.": "model.4.", "layer2.": "model.5.", "layer3.": "model.6.",
+                  "layer4.": "model.7."}
+
+    def load_torchvision_state_dict(self, sd, strict=True):
+        """Load a torchvision `resnet50` state dict (keys conv1.*, bn1.*, layer1-4.*, fc.* -- e.g. the file behind
+        `resnet50(pretrained=True)`); `fc.*` is dropped like the reference's `children()[:-2]` does."""
+        mapped = {}
+        for k, v in sd.items():
+            for src, dst in self._TV_PREFIX.items():
+                if k.startswith(src):
+                    mapped[dst + k[len(src):]] = v
+                    break
+        return self.load_state_dict(mapped, strict=strict)
+
+    def load_state_dict(self, sd, strict=True, **kw):
+        r = super().load_state_dict(sd, strict=strict, **kw)
+        self.weights_loaded = True
+        return r
 
     # ---- weights in GEMM layout: [Cout, kh*kw*Cin_padded], (ky, kx, c) order, compute dtype
     def _w2d(self, conv: nn.Conv2d, cin_pad: int):

@@ -34,8 +34,15 @@ class TrainStep:
         self.pack_rows = pack_rows
         self.eng.ensure_opt()
         self.dp = None
+        self.time_exchange = False
         if distributed:
             self.dp = GradAllReducer(self.eng.flat_g, self.eng.layout, self.eng.n_flat, self.eng.cfg.layers, group=group)
+            self.dp.check_replicas(self.eng.flat_p)
+            # every rank draws its own dropout masks (the same key would repeat rank 0's masks on every shard)
+            self.eng.drop_seed = (self.eng.drop_seed + 0x9E3779B97F4A7C15 * (self.dp.rank + 1)) & 0xFFFFFFFFFFFFFFFF
+
+    def exchange_exposed_ms(self):
+        return self.dp.exposed_ms() if self.dp is not None else 0.0
 
     def _prep(self, batch):
         dev = self.eng.device
@@ -44,25 +51,42 @@ class TrainStep:
             rows, ids = D.label_index(batch["txt_labels"])
         return rows.to(dev), ids.to(dev), batch["is_aligned"].to(dev, torch.int32)
 
-    def __call__(self, batch, train=True):
+    def __call__(self, batch, train=True, verify=None):
         """batch: dict with the reference's batch fields (cls_tok, input_txt, attn_mask, segment,
         img_feats, img_pos, sep_tok, txt_labels, is_aligned) [+ label_rows/label_ids].
         Returns the device tensor stats f32[6] = [mlm_nll_sum, n_lab, mlm_correct, itm_nll_sum, B, itm_correct]
-        (local to this rank); no host sync happens here."""
+        (local to this rank); no host sync happens here.
+        verify (optional callable -> bool): called after the forward and backward have been enqueued and before the
+        optimizer; when it returns False the step is redone with batch["attn_mask"] instead of batch["attn_desc"]
+        (CXRBERT_Trainer uses it to check, off the critical path, that descriptors it derived from a materialised
+        mask describe that mask bit for bit)."""
+        stats = self._run(batch, train, use_desc=True)
+        if verify is not None and not verify():
+            stats = self._run(batch, train, use_desc=False)
+        if train:
+            self.step_cnt += 1
+            self.eng.adamw_step(self.step_cnt, lr=self.lr, betas=self.betas, eps=self.eps, weight_decay=self.wd)
+        return stats
+
+    def _run(self, batch, train, use_desc):
         eng = self.eng
+        if self.dp is not None:
+            self.dp.timing = self.time_exchange
         rows, ids, aligned = self._prep(batch)
         eng.training = bool(train and self.model.training)      # dropout like the reference's model.train()
         if train:
             eng.flat_g.zero_()
-        desc = batch.get("attn_desc")
+        desc = batch.get("attn_desc") if use_desc else None
         pack = bool(self.pack_rows and desc is not None and eng.adt == torch.bfloat16 and desc.packable())
-        eng.encoder_forward(batch["cls_tok"], batch["input_txt"], desc if pack else batch["attn_mask"], batch["segment"],
+        mask = desc if desc is not None else batch["attn_mask"]      # descriptors when there are any: no [B,L,L] traffic
+        eng.encoder_forward(batch["cls_tok"], batch["input_txt"], mask, batch["segment"],
                             batch["img_feats"], batch["img_pos"], batch["sep_tok"], pack=pack)
         R, B = int(rows.numel()), int(aligned.numel())
         # loss normalisation = the reference's means over the GLOBAL mini-batch (train_origin.py:120-126)
         mlm_dev = itm_dev = None
         mlm_scale, itm_scale = 1.0 / max(R, 1), 1.0 / B
-        if self.dp is not None and self.dp.world > 1:
+        if train and self.dp is not None and self.dp.world > 1:      # eval: local sums only, no collective (ranks may
+            # hold different numbers of eval batches)
             inv = torch.reciprocal(torch.clamp(self.dp.global_counts(R, B, eng.device), min=1.0))
             mlm_dev, itm_dev = inv[0:1], inv[1:2]
         if not self.mlm_task:
@@ -75,8 +99,6 @@ class TrainStep:
             eng.encoder_backward(bucket_hook=self.dp.hook if self.dp is not None else None)
             if self.dp is not None:
                 self.dp.finish()
-            self.step_cnt += 1
-            eng.adamw_step(self.step_cnt, lr=self.lr, betas=self.betas, eps=self.eps, weight_decay=self.wd)
         return stats
 
 
@@ -93,16 +115,27 @@ class CXRBERT_Trainer:
         if not (torch.cuda.is_available() and getattr(args, "with_cuda", True)):
             raise RuntimeError("CXRBERT_Trainer needs an MI355X (ROCm) device; there is no CPU path")
         self.device = torch.device("cuda", torch.cuda.current_device())
+        # cxrbert_origin.py:59-65: anything but 'ViT' is the ResNet-50 region encoder; it is only built when the loader
+        # will hand over pixels (args.pixels / an explicit request), since feature batches never touch it
+        want_cnn = bool(getattr(args, "pixels", False)) and getattr(args, "img_encoder", "random-pixel") != "ViT"
+        cnn = "resnet50" if want_cnn else None
         if getattr(args, "weight_load", False):
-            self.model = CXRBERT.from_pretrained(args.pre_trained_model_path, args=args, dtype=dtype, device=self.device)
+            # train_origin.py:28-34; the checkpoint's enc.img_encoder.* weights are restored into the region encoder
+            self.model = CXRBERT.from_pretrained(args.pre_trained_model_path, args=args, dtype=dtype, device=self.device, img_encoder=cnn)
             print("training restart with mid epoch")
         else:
             if config is None:
                 config = BERT_CONFIGS.get(getattr(args, "bert_model", "bert-base-scratch"), BERT_CONFIGS["bert-base-scratch"])
-            # cxrbert_origin.py:59-65: anything but 'ViT' is the ResNet-50 region encoder; it is only built when the loader
-            # will hand over pixels (args.pixels / an explicit request), since feature batches never touch it
-            want_cnn = bool(getattr(args, "pixels", False)) and getattr(args, "img_encoder", "random-pixel") != "ViT"
-            self.model = CXRBERT(config, args, dtype=dtype, device=self.device, img_encoder="resnet50" if want_cnn else None)
+            self.model = CXRBERT(config, args, dtype=dtype, device=self.device, img_encoder=cnn)
+            tv = getattr(args, "resnet50_weights", None)       # path to torchvision's resnet50 state dict (no network here)
+            if want_cnn and tv:
+                self.model.img_encoder.load_torchvision_state_dict(torch.load(tv, map_location="cpu"))
+        if want_cnn and not self.model.img_encoder.weights_loaded:
+            import warnings
+            warnings.warn("pixel input with a ResNet-50 region encoder that holds RANDOM weights: the reference uses torchvision's "
+                          "resnet50(pretrained=True), frozen.  Pass args.resnet50_weights=<torchvision state dict> or load a "
+                          "checkpoint that carries enc.img_encoder.*; the frozen random CNN only yields noise features.",
+                          RuntimeWarning, stacklevel=2)
         self.train_data, self.test_data = train_dataloader, test_dataloader
         self.distributed = torch.distributed.is_available() and torch.distributed.is_initialized() \
             and torch.distributed.get_world_size() > 1
@@ -110,9 +143,80 @@ class CXRBERT_Trainer:
         self.itm_task = _str2bool(getattr(args, "itm_task", True))
         self.step = TrainStep(self.model, lr=getattr(args, "lr", 1e-5), distributed=self.distributed, mlm_task=self.mlm_task,
                               itm_task=self.itm_task)
+        self.recognise_masks = True     # derive {family, n2, vl} descriptors from the Dataset's materialised masks (verified)
+        self.n_recognised = 0
+        self._vstream = None
         self.log_freq = getattr(args, "log_freq", 10)
         self.logger = logger            # optional callable(dict, step=epoch): stands in for wandb.log
         print("Total Parameters:", sum(p.nelement() for p in self.model.parameters()))
+
+    def _recognise_masks(self, attn_masks, input_ids, N):
+        """The reference Dataset ships a materialised int64 mask per sample (dataset_origin.py:138-176: 134 MB per batch at
+        B=64, L=512).  Its five families are closed forms of {family, n2, vl}: derive the descriptors from a few probe
+        entries on the host (two rows and a column per sample), let the step run on them (packed rows, mask bits built on
+        the device) and check them against EVERY entry of the shipped matrix on the device, on a side stream, off the
+        critical path (`verify`).  A mask outside the families -- or any mismatch -- falls back to the matrix itself.
+        Returns (MaskDesc, verify callable) or (None, None)."""
+        m = attn_masks
+        if not torch.is_tensor(m) or m.dtype != torch.int64 or m.dim() not in (2, 3):
+            return None, None
+        B, L = m.shape[0], m.shape[-1]
+        S = L - N - 3
+        n2 = N + 2
+        if S < 1 or input_ids.shape[1] != S + 1:
+            return None, None
+        mh = m if not m.is_cuda else None
+        ids = input_ids.cpu()
+        n_ids = (ids != 0).sum(1).to(torch.int64)          # [PAD] = 0 after the text [SEP]
+        vl = n2 + n_ids
+        j = torch.arange(L).view(1, L)
+        full_row = (j < vl.view(B, 1)).to(torch.int64)
+        if m.dim() == 2:
+            fams = ["1d"] * B if mh is not None and torch.equal(mh, full_row) else None
+        else:
+            if mh is None:
+                return None, None
+            r0, rl, cl = mh[:, 0, :], mh[:, L - 1, :], mh[:, :, L - 1]
+            img_row = (j < n2).to(torch.int64).expand(B, L)
+            ones = torch.ones((B, L), dtype=torch.int64)
+            i = torch.arange(L).view(1, L)
+            fams = []
+            for b in range(B):
+                if torch.equal(r0[b], full_row[b]) and torch.equal(rl[b], full_row[b]):
+                    fams.append("full")
+                elif torch.equal(r0[b], img_row[b]) and torch.equal(rl[b], ones[b]):
+                    fams.append("s2s")
+                elif torch.equal(r0[b], ones[b]) and torch.equal(rl[b], ones[b]) and torch.equal(cl[b], ((i[0] < n2) | (i[0] == L - 1)).to(torch.int64)):
+                    fams.append("bar")
+                elif torch.equal(r0[b], img_row[b]) and torch.equal(rl[b], (j[0] >= n2).to(torch.int64)):
+                    fams.append("noncross")
+                else:
+                    fams = None
+                    break
+        if fams is None:
+            return None, None
+        desc = D.MaskDesc.make(fams, N, S, n_ids, self.device)
+        state = {}
+
+        def verify():
+            # after the step's kernels are enqueued: ship the matrix on the side stream, pack it, compare with the bits the
+            # forward built from the descriptors (still in the engine's workspace), read one flag
+            from . import hip_ops as ops
+            eng = self.model.engine
+            if self._vstream is None:
+                self._vstream = torch.cuda.Stream(device=self.device)
+            ev = eng.S["bits_ev"]                  # recorded right after the forward built its mask bits
+            with torch.cuda.stream(self._vstream):
+                md = m.to(self.device, non_blocking=True)
+                W32, Tt = (L + 31) // 32, (L + 63) // 64
+                bits = torch.empty((B, L, W32), dtype=torch.int32, device=self.device)
+                tinfo = torch.empty((B, Tt, Tt), dtype=torch.uint8, device=self.device)
+                ops.mask_pack(md, bits, tinfo)
+                self._vstream.wait_event(ev)
+                same = torch.equal(bits, eng.S["bits"][:B])       # host sync on this stream only
+            state["ok"] = bool(same)
+            return state["ok"]
+        return desc, verify
 
     def _to_batch(self, data):
         cls_tok, input_ids, txt_labels, attn_masks, img, segment, is_aligned, sep_tok = data[:8]
@@ -122,14 +226,23 @@ class CXRBERT_Trainer:
             with torch.no_grad():
                 img = self.model.img_encoder(img.to(self.device))
         feats, pos = img            # (region feats [B,N,2048], region positions [B,N])
-        return dict(cls_tok=cls_tok, input_txt=input_ids, attn_mask=attn_masks, segment=segment, img_feats=feats, img_pos=pos,
-                    sep_tok=sep_tok, txt_labels=txt_labels, is_aligned=is_aligned)
+        batch = dict(cls_tok=cls_tok, input_txt=input_ids, attn_mask=attn_masks, segment=segment, img_feats=feats, img_pos=pos,
+                     sep_tok=sep_tok, txt_labels=txt_labels, is_aligned=is_aligned)
+        if isinstance(attn_masks, D.MaskDesc):             # a loader that already ships descriptors
+            batch["attn_desc"], batch["attn_mask"] = attn_masks, None
+            return batch, None
+        desc, verify = self._recognise_masks(attn_masks, input_ids, feats.shape[1]) if self.recognise_masks else (None, None)
+        if desc is not None:
+            batch["attn_desc"] = desc
+            self.n_recognised += 1
+        return batch, verify
 
     def _run_epoch(self, loader, epoch, train):
         tot = torch.zeros(6, dtype=torch.float64)
         losses, mlm_l, itm_l = [], [], []
         for i, data in enumerate(loader):
-            stats = self.step(self._to_batch(data), train=train).double().cpu()   # the one sync per step
+            batch, verify = self._to_batch(data)
+            stats = self.step(batch, train=train, verify=verify).double().cpu()   # the one sync per step
             tot += stats
             ml = float(stats[0] / max(stats[1], 1.0))
             il = float(stats[3] / max(stats[4], 1.0))
@@ -157,12 +270,15 @@ class CXRBERT_Trainer:
 
     def save(self, epoch, file_path):
         save_path_per_ep = os.path.join(file_path, str(epoch))
-        if not os.path.exists(save_path_per_ep):
-            os.makedirs(save_path_per_ep, exist_ok=True)
-            os.chmod(save_path_per_ep, 0o777)
-        self.model.save_pretrained(save_path_per_ep)
-        print(f"EP: {epoch} Model saved on {save_path_per_ep}")
-        os.chmod(save_path_per_ep + "/pytorch_model.bin", 0o777)
+        if not self.distributed or torch.distributed.get_rank() == 0:     # replicas are identical: one writer
+            if not os.path.exists(save_path_per_ep):
+                os.makedirs(save_path_per_ep, exist_ok=True)
+                os.chmod(save_path_per_ep, 0o777)
+            self.model.save_pretrained(save_path_per_ep)
+            print(f"EP: {epoch} Model saved on {save_path_per_ep}")
+            os.chmod(save_path_per_ep + "/pytorch_model.bin", 0o777)
+        if self.distributed:
+            torch.distributed.barrier()
 
 
 BERT_CONFIGS = {   # offline stand-ins for BertConfig.from_pretrained(...) at train_origin.py:36-47

@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Per-step, per-queue summary of a rocprofv3 --kernel-trace CSV of bench.py: finds the optimizer launches (one per step), cuts
+the trace into steps and prints, for the chosen step, wall time, per-queue busy time, time with >= 2 kernels in flight, and the
+per-kernel totals split by queue.   usage: trace_steps.py <kernel_trace.csv> [step_index]"""
+import csv
+import collections
+import sys
+
+
+def short(n):
+    n = n.replace("void ", "")
+    for k in ("gemm_pring_kernel", "gemm_ring_kernel", "gemm_mfma_kernel", "attn_bwd_dkv", "attn_bwd_dq", "attn_fwd", "ln_bwd_kernel",
+              "ln_fwd_kernel", "splitk_reduce", "colsum_kernel", "adamw_kernel", "embed_bwd", "embed_fwd", "ce_vec", "gather_rows",
+              "scatter_rows", "cast_kernel", "dact", "mask_build", "mask_tileinfo", "pack_plan", "FillFunctor", "attn_bwd_fused", "gemm_p8"):
+        if k in n:
+            if k.startswith("gemm_"):
+                return n[n.index(k):].split("(")[0][:60]
+            return k
+    return n[:50]
+
+
+def main():
+    rows = []
+    with open(sys.argv[1]) as f:
+        for r in csv.DictReader(f):
+            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Queue_Id"], r["Kernel_Name"],
+                         int(r["Grid_Size_X"]) // max(1, int(r["Workgroup_Size_X"]))))
+    rows.sort()
+    opt = [i for i, r in enumerate(rows) if "adamw_kernel" in r[3]]
+    k = int(sys.argv[2]) if len(sys.argv) > 2 else len(opt) // 2 - 1
+    lo, hi = (opt[k - 1] + 1 if k > 0 else 0), opt[k] + 1
+    step = rows[lo:hi]
+    t0, t1 = step[0][0], step[-1][1]
+    print(f"steps found: {len(opt)}; step {k}: {len(step)} launches, wall {(t1 - t0) / 1e6:.2f} ms")
+    ev = []
+    for s, e, q, n, g in step:
+        ev.append((s, 1))
+        ev.append((e, -1))
+    ev.sort()
+    depth, last, busy, multi = 0, t0, 0, 0
+    for t, d in ev:
+        if depth >= 1:
+            busy += t - last
+        if depth >= 2:
+            multi += t - last
+        depth += d
+        last = t
+    print(f"any kernel running {busy / 1e6:.2f} ms, >= 2 running {multi / 1e6:.2f} ms, idle {(t1 - t0 - busy) / 1e6:.2f} ms")
+    perq = collections.defaultdict(float)
+    perk = collections.defaultdict(lambda: [0, 0.0])
+    for s, e, q, n, g in step:
+        perq[q] += (e - s) / 1e6
+        key = (q, short(n))
+        perk[key][0] += 1
+        perk[key][1] += (e - s) / 1e3
+    print("busy ms per queue:", {q: round(v, 2) for q, v in perq.items()})
+    print(f"{'queue':>5} {'kernel':60s} {'calls':>5} {'total_us':>10} {'avg_us':>8}")
+    for (q, n), (c, t) in sorted(perk.items(), key=lambda x: -x[1][1]):
+        print(f"{q:>5} {n:60s} {c:5d} {t:10.1f} {t / c:8.1f}")
+
+
+if __name__ == "__main__":
+    main()

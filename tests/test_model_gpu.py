@@ -419,6 +419,46 @@ def test_packing_is_refused_where_padding_is_visible():
     assert model.engine.S["cu"] is None
 
 
+@pytest.mark.parametrize("family", ["full", "s2s", "bar", "noncross", "1d", "mixed"])
+def test_trainer_derives_descriptors_from_reference_masks_and_verifies_them(family):
+    """The reference Dataset ships materialised int64 masks (dataset_origin.py:138-176).  The drop-in trainer derives the
+    {family, n2, vl} descriptors from them, runs on those (packed rows where padding is invisible) and checks every mask
+    entry on the device off the critical path; a mask outside the families makes the step fall back to the matrix."""
+    from types import SimpleNamespace
+    V, B, N, S = 2048, 4, 6, 41
+    cfgd = dict(vocab_size=V, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=512,
+                max_position_embeddings=64)
+    b = mv.data.synthetic_batch(V, B, N, S, family, seed=7, device="cpu")
+    tup = lambda m: (b["cls_tok"], b["input_txt"], b["txt_labels"], m, (b["img_feats"], b["img_pos"]), b["segment"], b["is_aligned"],
+                     b["sep_tok"], torch.zeros(B))
+    args = SimpleNamespace(with_cuda=True, weight_load=False, bert_model="custom", lr=0.0, log_freq=10, mlm_task=True, itm_task=True,
+                           cuda_devices=[0], dropout_prob=0.1)
+    torch.manual_seed(3)
+    tr = mv.CXRBERT_Trainer(args, [tup(b["attn_mask"])], None, config=cfgd, dtype=torch.bfloat16)
+    tr.model.eval()
+    got = tr._run_epoch(tr.train_data, 0, False)
+    assert tr.n_recognised == 1
+    packable = family in ("full", "s2s", "1d", "mixed")
+    assert (tr.model.engine.S["cu"] is not None) == packable              # the fast layout is really the one that ran
+    tr.recognise_masks = False
+    ref = tr._run_epoch(tr.train_data, 0, False)
+    assert tr.model.engine.S["cu"] is None
+    for k in ref:
+        assert abs(got[k] - ref[k]) < 2e-3, (k, got[k], ref[k])
+    if b["attn_mask"].dim() == 3:
+        # one entry flipped deep inside the matrix: the probes still say `family`, the device check does not
+        bad = b["attn_mask"].clone()
+        bad[1, N + 9, N + 5] ^= 1
+        tr.recognise_masks = True
+        tr.train_data = [tup(bad)]
+        got_bad = tr._run_epoch(tr.train_data, 0, False)
+        assert tr.n_recognised == 2 and tr.model.engine.S["cu"] is None      # descriptors were derived, then rejected
+        tr.recognise_masks = False
+        ref_bad = tr._run_epoch(tr.train_data, 0, False)
+        for k in ref_bad:
+            assert got_bad[k] == ref_bad[k], k
+
+
 def test_trainer_mirror_runs_an_epoch_and_saves(tmp_path):
     """CXRBERT_Trainer(args, train_dl, test_dl).train(epoch) / .save(epoch, path) as main_origin.py:57-62 drives it,
     fed with the reference's 9-tuple batches (dataset_origin.py:181) on the host."""
