@@ -455,8 +455,8 @@ def test_trainer_derives_descriptors_from_reference_masks_and_verifies_them(fami
         assert tr.n_recognised == 2 and tr.model.engine.S["cu"] is None      # descriptors were derived, then rejected
         tr.recognise_masks = False
         ref_bad = tr._run_epoch(tr.train_data, 0, False)
-        for k in ref_bad:
-            assert got_bad[k] == ref_bad[k], k
+        for k in ref_bad:            # same kernels on the same inputs (float atomics in the loss sums: last-bit differences)
+            assert abs(got_bad[k] - ref_bad[k]) < 1e-5, k
 
 
 def test_trainer_mirror_runs_an_epoch_and_saves(tmp_path):
