@@ -143,6 +143,7 @@ struct AttnArgs {
   int B, L, A, H, W, T;
   float scale;
   unsigned bytes_qkv, bytes_ctx;
+  unsigned bytes_stat, bytes_bits;     // sizes of lse / delta ([B,A,L] f32) and of the mask words, for the LDS-DMA descriptors
   DropCfg drop;   // attention-probability dropout; mask index = ((b*A + h)*L + q)*Lp + k, Lp = L rounded up to 4
   int Lp;
   // packed rows (nullable): sample b owns rows cu[b] .. cu[b+1]-1 of qkv / ctx / dctx / out / dqkv, i.e. only its first
@@ -150,8 +151,10 @@ struct AttnArgs {
   const int32_t* cu;
 };
 // keep-bits of the 4 consecutive keys k4..k4+3 (k4 % 4 == 0) of query row q
+// (the mask counter is (linear index) >> 2 with linear index = ((b*A + h)*L + q)*Lp + k4 < 2^34 (checked on the host); Lp and k4
+// are multiples of 4, so the counter is (bh*L + q)*(Lp/4) + k4/4 in plain 32-bit arithmetic -- no 64-bit multiplies per hash)
 __device__ __forceinline__ unsigned attn_drop_hash(const DropCfg& d, size_t bh, int L, int Lp, int q, int k4) {
-  return mv_hash32((unsigned)(((bh * L + q) * (size_t)Lp + k4) >> 2), d.k0, d.k1);
+  return mv_hash32(((unsigned)bh * (unsigned)L + (unsigned)q) * ((unsigned)Lp >> 2) + ((unsigned)k4 >> 2), d.k0, d.k1);
 }
 
 // value of lane `e` of each quad (DPP quad_perm broadcast); e is a compile-time constant after unrolling
@@ -193,6 +196,33 @@ __device__ __forceinline__ void tile_store(const u32x4 (&reg)[2], char* tile, in
     *(u32x4*)(tile + att_off(idx >> 3, idx & 7)) = reg[i];
   }
 }
+// The same tile, HBM -> LDS directly (LDS-DMA, `buffer_load ... lds`, 16 B per lane): 8 pieces of 1 KiB = 8 rows each; wave
+// `wid` of NW issues pieces wid, wid + NW, ...  The LDS image of a piece is lane-linear, so the chunk swizzle of att_off() is
+// applied to the per-lane SOURCE address; rows past `nrows` are zero-filled (out-of-range buffer offset).  No registers hold
+// the tile, so a ring of several stages can be in flight: the kernels below keep NS - 1 tiles ahead of the one they compute on
+// and retire them with counted `s_waitcnt vmcnt(N)` + one raw s_barrier per tile.
+template <int NW>
+__device__ __forceinline__ void tile_dma(__amdgpu_buffer_rsrc_t rs, unsigned bytes, size_t rowbase, int row0, int nrows, int ld,
+                                         int col0, char* tile, int wid, int lane) {
+#pragma unroll
+  for (int i = 0; i < 8 / NW; ++i) {
+    const int pc = wid + NW * i;
+    const int r = pc * 8 + (lane >> 3), ch = (lane & 7) ^ att_f(r);
+    const bool ok = (row0 + r) < nrows;
+    const unsigned off = (unsigned)(((rowbase + row0 + r) * (size_t)ld + col0 + ch * 8) * 2);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (MV_LDS void*)(tile + pc * 1024), 16, ok ? off : bytes, 0, 0, 0);
+  }
+}
+template <int N> __device__ __forceinline__ void att_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// wait until at most `younger` stages (of PPW LDS-DMA instructions per wave each) are still in flight
+template <int PPW>
+__device__ __forceinline__ void att_wait_stage(int younger) {
+  if (younger <= 0) att_wait_vmcnt<0>();
+  else if (younger == 1) att_wait_vmcnt<PPW>();
+  else if (younger == 2) att_wait_vmcnt<2 * PPW>();
+  else att_wait_vmcnt<3 * PPW>();
+}
+
 // row-read fragment  X[idx = base + (lane&31)][k = 16*s + 8*h + j]
 __device__ __forceinline__ bf16x8 frag_row(const char* tile, int base, int s, int l31, int h) {
   return *(const bf16x8*)(tile + att_off(base + l31, 2 * s + h));
@@ -274,10 +304,12 @@ __device__ __forceinline__ int next_tile(unsigned long long need, int after, int
 }
 
 // ---- forward --------------------------------------------------------------------------------
+#define FWD_NS 3      // 48 KiB of LDS per block: three blocks per CU
 template <bool F16>
 __global__ __launch_bounds__(256, 3) void attn_fwd_mfma_kernel(AttnArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 stages x (K 8 KiB + V 8 KiB)
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, h = lane >> 5;
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // FWD_NS stages x (K 8 KiB + V 8 KiB)
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int head = blockIdx.y, b = blockIdx.z;
   const int L = a.L, H = a.H, ld = 3 * a.H, T = a.T;
   const int qb0 = blockIdx.x * 128, q0 = qb0 + wid * 32, q = q0 + l31;
@@ -301,24 +333,26 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_mfma_kernel(AttnArgs a) {
   const int nkt = (Lv + 63) / 64;
   const int ta = qb0 >> 6;
   const TileMasks tmk = load_tile_masks_q(a.info, b, T, ta, min(q0 >> 6, T - 1), lane);
+  // K/V ring: the needed key tiles (set bits of tmk.need) are requested FWD_NS - 1 ahead of the one being computed on
   int cur = next_tile(tmk.need, -1, nkt);
-  u32x4 rk[2], rv[2];
-  if (cur < nkt) {
-    tile_load(rk, rs, a.bytes_qkv, rowbase, cur * 64, Lv, ld, H + head * 64, tid);
-    tile_load(rv, rs, a.bytes_qkv, rowbase, cur * 64, Lv, ld, 2 * H + head * 64, tid);
-    tile_store(rk, smem, tid);
-    tile_store(rv, smem + 8192, tid);
-  }
-  __syncthreads();
-  int buf = 0;
+  int iss = cur, issued = 0, done = 0;
+  auto issue = [&]() {
+    char* st_ = smem + (issued % FWD_NS) * 16384;
+    tile_dma<4>(rs, a.bytes_qkv, rowbase, iss * 64, Lv, ld, H + head * 64, st_, wid, lane);
+    tile_dma<4>(rs, a.bytes_qkv, rowbase, iss * 64, Lv, ld, 2 * H + head * 64, st_ + 8192, wid, lane);
+    ++issued;
+    iss = next_tile(tmk.need, iss, nkt);
+  };
+#pragma unroll
+  for (int i = 0; i < FWD_NS - 1; ++i)
+    if (iss < nkt) issue();
   const uint32_t* myw = a.bits + (lrow + (q_ok ? q : 0)) * a.W;
   while (cur < nkt) {
-    const int nxt = next_tile(tmk.need, cur, nkt);
-    if (nxt < nkt) {
-      tile_load(rk, rs, a.bytes_qkv, rowbase, nxt * 64, Lv, ld, H + head * 64, tid);
-      tile_load(rv, rs, a.bytes_qkv, rowbase, nxt * 64, Lv, ld, 2 * H + head * 64, tid);
-    }
-    const char* tK = smem + buf * 16384;
+    att_wait_stage<4>(issued - done - 1);           // this wave's pieces of tile `cur` have landed ...
+    __builtin_amdgcn_s_barrier();                   // ... and everybody's; everybody is done reading the slot refilled next
+    __builtin_amdgcn_sched_barrier(0);
+    if (iss < nkt) issue();
+    const char* tK = smem + (done % FWD_NS) * 16384;
     const char* tV = tK + 8192;
     const int cls = !wave_on ? 0 : (((tmk.w_is1 >> cur) & 1) ? 1 : (((tmk.w_nz >> cur) & 1) ? 2 : 0));
     if (wave_on && cls != 0) {
@@ -400,13 +434,8 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_mfma_kernel(AttnArgs a) {
             o[dt] = mma32<F16>(frag_tr(tV, 32 * dt, 32 * kk + 16 * s2, lane), pf, o[dt]);
         }
     }
-    if (nxt < nkt) {
-      tile_store(rk, smem + (buf ^ 1) * 16384, tid);
-      tile_store(rv, smem + (buf ^ 1) * 16384 + 8192, tid);
-    }
-    __syncthreads();
-    buf ^= 1;
-    cur = nxt;
+    cur = next_tile(tmk.need, cur, nkt);
+    ++done;
   }
   if (!q_ok) return;
   const float ltot = lsum + __shfl_xor(lsum, 32, 64);
@@ -429,9 +458,64 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_mfma_kernel(AttnArgs a) {
 }
 
 // ---- backward: dQ ----------------------------------------------------------------------------
+// One 64-key tile of the dQ pass for a wave's 32 queries.  MASKED: the tile needs its mask words (class 2; a ragged
+// TAIL tile is always run as masked), DROP: attention dropout is on -- compile-time, so the per-element loops are
+// straight-line code the scheduler can interleave with the MFMAs.
+template <bool MASKED, bool DROP, bool TAIL>
+__device__ __forceinline__ void dq_tile(const AttnArgs& a, const char* tK, const char* tV, const bf16x8 (&qf)[4], const bf16x8 (&dof)[4],
+                                        f32x16 (&dq)[2], const uint32_t* myw, bool q_ok, int q, int b, int head, int k0, int Lv,
+                                        float lse2, float dlt, float c2, int lane) {
+  const int l31 = lane & 31, h = lane >> 5;
+  const float dlt_s = dlt * a.scale;                          // ds = p * (dp' - delta) * scale, with the scale folded in
+  const float dscale = DROP ? a.drop.inv_keep * a.scale : a.scale;
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) {
+    f32x16 st, dp;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { st[i] = 0.f; dp[i] = 0.f; }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(tK, 32 * kk, s, l31, h), qf[s], st, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(tV, 32 * kk, s, l31, h), dof[s], dp, 0, 0, 0);
+    }
+    uint32_t w = 0xffffffffu;
+    if (MASKED) { const int wi = (k0 >> 5) + kk; w = (q_ok && wi < a.W) ? myw[wi] : 0xffffffffu; }
+    unsigned hq[4];
+    if (DROP) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        hq[g] = attn_drop_hash(a.drop, (size_t)b * a.A + head, a.L, a.Lp, q_ok ? q : 0, k0 + 32 * kk + 8 * g + 4 * h);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int kr = acc_row(r, h);
+      float pv;
+      if (!MASKED) {
+        pv = fexp2(fmaf(st[r], c2, -lse2));
+      } else {
+        const float v = fmaf(st[r], c2, ((w >> kr) & 1u) ? 0.f : MASK_ADD * LOG2E);
+        pv = fexp2(v - lse2);
+      }
+      if (TAIL) pv = (k0 + 32 * kk + kr >= Lv) ? 0.f : pv;
+      float dpr = dp[r];
+      if (DROP) dpr = mv_keep(hq[r >> 2], r & 3, a.drop.thr) ? dpr : 0.f;
+      st[r] = pv * fmaf(dpr, dscale, -dlt_s);
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const bf16x8 dsf = pack8(st, s2);
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+        dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(tK, 32 * dt, 32 * kk + 16 * s2, lane), dsf, dq[dt], 0, 0, 0);
+    }
+  }
+}
+
+#define DQ_NS 4       // 64 KiB of LDS per block, two blocks per CU (register-limited)
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_mfma_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, h = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int head = blockIdx.y, b = blockIdx.z;
   const int L = a.L, H = a.H, ld = 3 * a.H, T = a.T;
   const int qb0 = blockIdx.x * 128, q0 = qb0 + wid * 32, q = q0 + l31;
@@ -474,75 +558,42 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_mfma_kernel(AttnArgs a) {
   const int ta = qb0 >> 6;
   const TileMasks tmk = load_tile_masks_q(a.info, b, T, ta, min(q0 >> 6, T - 1), lane);
   int cur = next_tile(tmk.need, -1, nkt);
-  u32x4 rk[2], rv[2];
-  if (cur < nkt) {
-    tile_load(rk, rs, a.bytes_qkv, rowbase, cur * 64, Lv, ld, H + head * 64, tid);
-    tile_load(rv, rs, a.bytes_qkv, rowbase, cur * 64, Lv, ld, 2 * H + head * 64, tid);
-    tile_store(rk, smem, tid);
-    tile_store(rv, smem + 8192, tid);
-  }
-  __syncthreads();
-  int buf = 0;
+  int iss = cur, issued = 0, done = 0;
+  auto issue = [&]() {
+    char* st_ = smem + (issued % DQ_NS) * 16384;
+    tile_dma<4>(rs, a.bytes_qkv, rowbase, iss * 64, Lv, ld, H + head * 64, st_, wid, lane);
+    tile_dma<4>(rs, a.bytes_qkv, rowbase, iss * 64, Lv, ld, 2 * H + head * 64, st_ + 8192, wid, lane);
+    ++issued;
+    iss = next_tile(tmk.need, iss, nkt);
+  };
+#pragma unroll
+  for (int i = 0; i < DQ_NS - 1; ++i)
+    if (iss < nkt) issue();
   const uint32_t* myw = a.bits + (lrow + (q_ok ? q : 0)) * a.W;
   while (cur < nkt) {
-    const int nxt = next_tile(tmk.need, cur, nkt);
-    if (nxt < nkt) {
-      tile_load(rk, rs, a.bytes_qkv, rowbase, nxt * 64, Lv, ld, H + head * 64, tid);
-      tile_load(rv, rs, a.bytes_qkv, rowbase, nxt * 64, Lv, ld, 2 * H + head * 64, tid);
-    }
-    const char* tK = smem + buf * 16384;
+    att_wait_stage<4>(issued - done - 1);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (iss < nkt) issue();
+    const char* tK = smem + (done % DQ_NS) * 16384;
     const char* tV = tK + 8192;
     const int cls = !wave_on ? 0 : (((tmk.w_is1 >> cur) & 1) ? 1 : (((tmk.w_nz >> cur) & 1) ? 2 : 0));
     if (wave_on && cls != 0) {
       const int k0 = cur * 64;
       const bool tail = (k0 + 64 > Lv);
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        f32x16 st, dp;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { st[i] = 0.f; dp[i] = 0.f; }
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(tK, 32 * kk, s, l31, h), qf[s], st, 0, 0, 0);
-          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(tV, 32 * kk, s, l31, h), dof[s], dp, 0, 0, 0);
-        }
-        uint32_t w = 0xffffffffu;
-        if (cls != 1) { const int wi = (k0 >> 5) + kk; w = (q_ok && wi < a.W) ? myw[wi] : 0xffffffffu; }
-        unsigned hcur = 0;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int kr = acc_row(r, h);
-          float pv;
-          if (cls == 1) {
-            pv = fexp2(fmaf(st[r], c2, -lse2));
-          } else {
-            const float v = fmaf(st[r], c2, ((w >> kr) & 1u) ? 0.f : MASK_ADD * LOG2E);
-            pv = fexp2(v - lse2);
-          }
-          if (tail && (k0 + 32 * kk + kr >= Lv)) pv = 0.f;
-          float dpr = dp[r];
-          if (a.drop.thr) {
-            if ((r & 3) == 0) hcur = attn_drop_hash(a.drop, (size_t)b * a.A + head, L, a.Lp, q_ok ? q : 0, k0 + 32 * kk + kr);
-            dpr = mv_keep(hcur, r & 3, a.drop.thr) ? dpr * a.drop.inv_keep : 0.f;
-          }
-          st[r] = pv * (dpr - dlt) * a.scale;
-        }
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-          const bf16x8 dsf = pack8(st, s2);
-#pragma unroll
-          for (int dt = 0; dt < 2; ++dt)
-            dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(tK, 32 * dt, 32 * kk + 16 * s2, lane), dsf, dq[dt], 0, 0, 0);
-        }
+      // one wave-uniform dispatch per tile: the element loops below contain no branches
+      const int variant = (cls == 1 ? 0 : 1) | (a.drop.thr ? 2 : 0) | (tail ? 4 : 0);
+      switch (variant) {
+        case 0: dq_tile<false, false, false>(a, tK, tV, qf, dof, dq, myw, q_ok, q, b, head, k0, Lv, lse2, dlt, c2, lane); break;
+        case 1: dq_tile<true, false, false>(a, tK, tV, qf, dof, dq, myw, q_ok, q, b, head, k0, Lv, lse2, dlt, c2, lane); break;
+        case 2: dq_tile<false, true, false>(a, tK, tV, qf, dof, dq, myw, q_ok, q, b, head, k0, Lv, lse2, dlt, c2, lane); break;
+        case 3: dq_tile<true, true, false>(a, tK, tV, qf, dof, dq, myw, q_ok, q, b, head, k0, Lv, lse2, dlt, c2, lane); break;
+        case 4: case 5: dq_tile<true, false, true>(a, tK, tV, qf, dof, dq, myw, q_ok, q, b, head, k0, Lv, lse2, dlt, c2, lane); break;
+        default: dq_tile<true, true, true>(a, tK, tV, qf, dof, dq, myw, q_ok, q, b, head, k0, Lv, lse2, dlt, c2, lane); break;
       }
     }
-    if (nxt < nkt) {
-      tile_store(rk, smem + (buf ^ 1) * 16384, tid);
-      tile_store(rv, smem + (buf ^ 1) * 16384 + 8192, tid);
-    }
-    __syncthreads();
-    buf ^= 1;
-    cur = nxt;
+    cur = next_tile(tmk.need, cur, nkt);
+    ++done;
   }
   if (!q_ok) return;
   bf16_t* orow = a.dqkv + (rowbase + q) * (size_t)ld + head * 64;
@@ -558,9 +609,74 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_mfma_kernel(AttnArgs a) {
 // ---- backward: dK, dV --------------------------------------------------------------------------
 // LDS stage layout: Q tile 8 KiB | dO tile 8 KiB | lse2[64] f32 | delta[64] f32 | words[64][4] u32
 #define KV_STAGE (8192 + 8192 + 256 + 256 + 1024)
+// One 64-query tile of the dK/dV pass for a wave's 32 keys (key on the lane).  MASKED: class-2 tile (mask words from LDS);
+// DROP: attention dropout on -- compile-time, so the element loops are branch-free.
+template <bool MASKED, bool DROP>
+__device__ __forceinline__ void dkv_tile(const AttnArgs& a, const char* tQ, const char* tD, const float* s_lse, const float* s_dl,
+                                         const uint32_t* s_w, const bf16x8 (&kf)[4], const bf16x8 (&vf)[4], f32x16 (&dk)[2],
+                                         f32x16 (&dv)[2], int b, int head, int cur, int key, int wid, float c2, int lane) {
+  const int l31 = lane & 31, h = lane >> 5;
+  const float dscale = DROP ? a.drop.inv_keep * a.scale : a.scale;
+#pragma unroll
+  for (int qq = 0; qq < 2; ++qq) {
+    f32x16 sc, dp;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { sc[i] = 0.f; dp[i] = 0.f; }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(tQ, 32 * qq, s, l31, h), kf[s], sc, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(tD, 32 * qq, s, l31, h), vf[s], dp, 0, 0, 0);
+    }
+    f32x16& pv = dp;                          // P (dropped-out) overwrites dP element by element
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int qr0 = 32 * qq + 8 * g + 4 * h;      // 4 consecutive query rows of this register quad
+      f32x4 l4 = *(const f32x4*)(s_lse + qr0);      // natural-log row statistics as the forward wrote them
+      f32x4 d4 = *(const f32x4*)(s_dl + qr0);
+      l4 *= LOG2E;
+      d4 *= a.scale;
+      unsigned hq = 0;
+      if (DROP)
+        hq = attn_drop_hash(a.drop, (size_t)b * a.A + head, a.L, a.Lp, min(cur * 64 + qr0 + (l31 & 3), a.L - 1), min(key, a.L - 1) & ~3);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int r = 4 * g + e;
+        float p;                              // rows q >= Lv: dO row and delta are zero, so whatever p is, nothing is added
+        if (!MASKED) {
+          p = fexp2(fmaf(sc[r], c2, -l4[e]));
+        } else {
+          const uint32_t w = s_w[(qr0 + e) * 4 + wid];
+          p = fexp2(fmaf(sc[r], c2, ((w >> l31) & 1u) ? 0.f : MASK_ADD * LOG2E) - l4[e]);
+        }
+        if (DROP) {
+          // the 4 lanes of a quad hold keys 4j..4j+3 = ONE mask group per query: lane e' of the quad hashed query
+          // qr0+e' (hq above); fetch the hash of query qr0+e from lane e of the quad (DPP quad broadcast)
+          const bool keep = mv_keep(quad_bcast(hq, e), l31 & 3, a.drop.thr);
+          sc[r] = p * fmaf(keep ? dp[r] : 0.f, dscale, -d4[e]);
+          pv[r] = keep ? p * a.drop.inv_keep : 0.f;
+        } else {
+          sc[r] = p * fmaf(dp[r], dscale, -d4[e]);
+          pv[r] = p;
+        }
+      }
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const bf16x8 pf = pack8(pv, s2);
+      const bf16x8 dsf = pack8(sc, s2);
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(tD, 32 * dt, 32 * qq + 16 * s2, lane), pf, dv[dt], 0, 0, 0);
+        dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(tQ, 32 * dt, 32 * qq + 16 * s2, lane), dsf, dk[dt], 0, 0, 0);
+      }
+    }
+  }
+}
+#define DKV_NS 4      // 70 KiB of LDS per block, two blocks per CU (register-limited)
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_mfma_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, h = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int head = blockIdx.y, b = blockIdx.z;
   const int L = a.L, H = a.H, ld = 3 * a.H, T = a.T;
   const int kb0 = blockIdx.x * 128, k0w = kb0 + wid * 32, key = k0w + l31;
@@ -588,37 +704,42 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_mfma_kernel(AttnArgs a) {
   const int kw0 = kb0 >> 5;           // first of the block's 4 mask words
   const size_t sbase = ((size_t)b * a.A + head) * L;
 
-  u32x4 rq[2], rd[2];
-  float r_lse = 0.f, r_dl = 0.f;
-  uint32_t r_w = 0;
-  auto stage_load_all = [&](int t) {
-    tile_load(rq, rs, a.bytes_qkv, rowbase, t * 64, Lv, ld, head * 64, tid);
-    tile_load(rd, rsd, a.bytes_ctx, rowbase, t * 64, Lv, H, head * 64, tid);
-    const int qi = t * 64 + (tid & 63);
-    if (tid < 64) r_lse = (qi < Lv) ? a.lse_in[sbase + qi] * LOG2E : INFINITY;
-    else if (tid < 128) r_dl = (qi < Lv) ? a.delta[sbase + qi] : 0.f;
-    {
-      const int qq = t * 64 + (tid >> 2), wi = kw0 + (tid & 3);
-      r_w = (qq < Lv && wi < a.W) ? a.bits[(lrow + qq) * a.W + wi] : 0u;
-    }
-  };
-  auto stage_store_all = [&](char* st) {
-    tile_store(rq, st, tid);
-    tile_store(rd, st + 8192, tid);
-    if (tid < 64) ((float*)(st + 16384))[tid] = r_lse;
-    else if (tid < 128) ((float*)(st + 16384 + 256))[tid - 64] = r_dl;
-    ((uint32_t*)(st + 16384 + 512))[tid] = r_w;
-  };
-
+  // Q / dO tiles, their softmax statistics and this key block's mask words all arrive by LDS-DMA into a ring of DKV_NS
+  // stages (rows past Lv are zero-filled: a zero dO row and a zero delta make that row contribute nothing to dK or dV)
+  __amdgpu_buffer_rsrc_t rsl = __builtin_amdgcn_make_buffer_rsrc((void*)a.lse_in, 0, a.bytes_stat, 0x00020000);
+  __amdgpu_buffer_rsrc_t rsdl = __builtin_amdgcn_make_buffer_rsrc((void*)a.delta, 0, a.bytes_stat, 0x00020000);
+  __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)a.bits, 0, a.bytes_bits, 0x00020000);
   const TileMasks tmk = load_tile_masks_k(a.info, b, T, ka, min(k0w >> 6, T - 1), lane);
   int cur = next_tile(tmk.need, -1, nqt);
-  if (cur < nqt) { stage_load_all(cur); stage_store_all(smem); }
-  __syncthreads();
-  int buf = 0;
+  int iss = cur, issued = 0, done = 0;
+  auto issue = [&]() {
+    char* st_ = smem + (issued % DKV_NS) * KV_STAGE;
+    tile_dma<4>(rs, a.bytes_qkv, rowbase, iss * 64, Lv, ld, head * 64, st_, wid, lane);
+    tile_dma<4>(rsd, a.bytes_ctx, rowbase, iss * 64, Lv, H, head * 64, st_ + 8192, wid, lane);
+    {   // 64 rows x 4 mask words: 256 dwords, 64 per wave
+      const int idx = wid * 64 + lane, qq = iss * 64 + (idx >> 2), wi = kw0 + (idx & 3);
+      const bool ok = qq < Lv && wi < a.W;
+      const unsigned off = (unsigned)(((lrow + qq) * (size_t)a.W + wi) * 4);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (MV_LDS void*)(st_ + 16384 + 512 + wid * 256), 4, ok ? off : a.bytes_bits, 0, 0, 0);
+    }
+    {   // lse (even waves) / delta (odd waves) of the 64 query rows; issued by every wave so that the counted waits are uniform
+      const int qi = iss * 64 + lane;
+      const unsigned off = (unsigned)((sbase + qi) * 4);
+      if (wid & 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsdl, (MV_LDS void*)(st_ + 16384 + 256), 4, qi < Lv ? off : a.bytes_stat, 0, 0, 0);
+      else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsl, (MV_LDS void*)(st_ + 16384), 4, qi < Lv ? off : a.bytes_stat, 0, 0, 0);
+    }
+    ++issued;
+    iss = next_tile(tmk.need, iss, nqt);
+  };
+#pragma unroll
+  for (int i = 0; i < DKV_NS - 1; ++i)
+    if (iss < nqt) issue();
   while (cur < nqt) {
-    const int nxt = next_tile(tmk.need, cur, nqt);
-    if (nxt < nqt) stage_load_all(nxt);
-    const char* st = smem + buf * KV_STAGE;
+    att_wait_stage<6>(issued - done - 1);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (iss < nqt) issue();
+    const char* st = smem + (done % DKV_NS) * KV_STAGE;
     const char* tQ = st;
     const char* tD = st + 8192;
     const float* s_lse = (const float*)(st + 16384);
@@ -626,62 +747,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_mfma_kernel(AttnArgs a) {
     const uint32_t* s_w = (const uint32_t*)(st + 16384 + 512);
     const int cls = !wave_on ? 0 : (((tmk.w_is1 >> cur) & 1) ? 1 : (((tmk.w_nz >> cur) & 1) ? 2 : 0));
     if (wave_on && cls != 0) {
-#pragma unroll
-      for (int qq = 0; qq < 2; ++qq) {
-        f32x16 sc, dp;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { sc[i] = 0.f; dp[i] = 0.f; }
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(tQ, 32 * qq, s, l31, h), kf[s], sc, 0, 0, 0);
-          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(tD, 32 * qq, s, l31, h), vf[s], dp, 0, 0, 0);
-        }
-        f32x16 pv;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int qr0 = 32 * qq + 8 * g + 4 * h;      // 4 consecutive query rows of this register quad
-          const f32x4 l4 = *(const f32x4*)(s_lse + qr0);
-          const f32x4 d4 = *(const f32x4*)(s_dl + qr0);
-          unsigned hq = 0;
-          if (a.drop.thr)
-            hq = attn_drop_hash(a.drop, (size_t)b * a.A + head, L, a.Lp, min(cur * 64 + qr0 + (l31 & 3), L - 1), min(key, L - 1) & ~3);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int r = 4 * g + e;
-            float p;                              // rows q >= L carry lse = +inf -> p = 0
-            if (cls == 1) {
-              p = fexp2(fmaf(sc[r], c2, -l4[e]));
-            } else {
-              const uint32_t w = s_w[(qr0 + e) * 4 + wid];
-              p = fexp2(fmaf(sc[r], c2, ((w >> l31) & 1u) ? 0.f : MASK_ADD * LOG2E) - l4[e]);
-            }
-            float keepf = 1.0f;
-            if (a.drop.thr) {
-              // the 4 lanes of a quad hold keys 4j..4j+3 = ONE mask group per query: lane e' of the quad hashed query
-              // qr0+e' (hq below); fetch the hash of query qr0+e from lane e of the quad (DPP quad broadcast)
-              const unsigned hh = quad_bcast(hq, e);
-              keepf = mv_keep(hh, l31 & 3, a.drop.thr) ? a.drop.inv_keep : 0.f;
-            }
-            pv[r] = p * keepf;
-            sc[r] = p * (keepf * dp[r] - d4[e]) * a.scale;
-          }
-        }
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-          const bf16x8 pf = pack8(pv, s2);
-          const bf16x8 dsf = pack8(sc, s2);
-#pragma unroll
-          for (int dt = 0; dt < 2; ++dt) {
-            dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(tD, 32 * dt, 32 * qq + 16 * s2, lane), pf, dv[dt], 0, 0, 0);
-            dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(tQ, 32 * dt, 32 * qq + 16 * s2, lane), dsf, dk[dt], 0, 0, 0);
-          }
-        }
+      const int variant = (cls == 1 ? 0 : 1) | (a.drop.thr ? 2 : 0);        // one wave-uniform dispatch per tile
+      switch (variant) {
+        case 0: dkv_tile<false, false>(a, tQ, tD, s_lse, s_dl, s_w, kf, vf, dk, dv, b, head, cur, key, wid, c2, lane); break;
+        case 1: dkv_tile<true, false>(a, tQ, tD, s_lse, s_dl, s_w, kf, vf, dk, dv, b, head, cur, key, wid, c2, lane); break;
+        case 2: dkv_tile<false, true>(a, tQ, tD, s_lse, s_dl, s_w, kf, vf, dk, dv, b, head, cur, key, wid, c2, lane); break;
+        default: dkv_tile<true, true>(a, tQ, tD, s_lse, s_dl, s_w, kf, vf, dk, dv, b, head, cur, key, wid, c2, lane); break;
       }
     }
-    if (nxt < nqt) stage_store_all(smem + (buf ^ 1) * KV_STAGE);
-    __syncthreads();
-    buf ^= 1;
-    cur = nxt;
+    cur = next_tile(tmk.need, cur, nqt);
+    ++done;
   }
   if (!k_ok) return;
   bf16_t* krow = a.dqkv + (rowbase + key) * (size_t)ld + H + head * 64;
@@ -928,12 +1003,12 @@ extern "C" int mv_attn_fwd(int dtype, const void* qkv, const uint32_t* bits, con
     a.drop = drop; a.Lp = (L + 3) & ~3;
     static bool attr = false;
     if (!attr) {
-      (void)hipFuncSetAttribute((const void*)attn_fwd_mfma_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 32768);
-      (void)hipFuncSetAttribute((const void*)attn_fwd_mfma_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 32768);
+      (void)hipFuncSetAttribute((const void*)attn_fwd_mfma_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, FWD_NS * 16384);
+      (void)hipFuncSetAttribute((const void*)attn_fwd_mfma_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, FWD_NS * 16384);
       attr = true;
     }
-    if (dtype == MV_F16) hipLaunchKernelGGL(attn_fwd_mfma_kernel<true>, dim3((L + 127) / 128, A, B), dim3(256), 32768, stream, a);
-    else hipLaunchKernelGGL(attn_fwd_mfma_kernel<false>, dim3((L + 127) / 128, A, B), dim3(256), 32768, stream, a);
+    if (dtype == MV_F16) hipLaunchKernelGGL(attn_fwd_mfma_kernel<true>, dim3((L + 127) / 128, A, B), dim3(256), FWD_NS * 16384, stream, a);
+    else hipLaunchKernelGGL(attn_fwd_mfma_kernel<false>, dim3((L + 127) / 128, A, B), dim3(256), FWD_NS * 16384, stream, a);
     MV_CHECK_LAUNCH();
     return MV_OK;
   }
@@ -988,17 +1063,18 @@ extern "C" int mv_attn_bwd(int dtype, const void* qkv, const void* ctx, const vo
     a.B = B; a.L = L; a.A = A; a.H = H; a.W = (L + 31) / 32; a.T = (L + 63) / 64;
     a.scale = 1.0f / sqrtf((float)dh);
     a.bytes_qkv = (unsigned)bq; a.bytes_ctx = (unsigned)bc;
+    a.bytes_stat = (unsigned)((size_t)B * A * L * 4); a.bytes_bits = (unsigned)((size_t)B * L * a.W * 4);
     a.drop = drop; a.Lp = (L + 3) & ~3;
     static bool attr = false;
     if (!attr) {
-      (void)hipFuncSetAttribute((const void*)attn_bwd_dq_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 32768);
-      (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * KV_STAGE);
+      (void)hipFuncSetAttribute((const void*)attn_bwd_dq_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DQ_NS * 16384);
+      (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DKV_NS * KV_STAGE);
       attr = true;
     }
     dim3 grid((L + 127) / 128, A, B);
-    hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel, grid, dim3(256), 32768, stream, a);
+    hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel, grid, dim3(256), DQ_NS * 16384, stream, a);
     MV_CHECK_LAUNCH();
-    hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel, grid, dim3(256), 2 * KV_STAGE, stream, a);
+    hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel, grid, dim3(256), DKV_NS * KV_STAGE, stream, a);
     MV_CHECK_LAUNCH();
     return MV_OK;
   }

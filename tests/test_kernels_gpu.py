@@ -578,7 +578,8 @@ def test_adamw_known_answer(golden_dir):
 # The forward products of the 16-bit path read f16-encoded operands (MV_F16) and write a forward activation twice: the
 # f16 copy for the next forward product and the bf16 copy for the backward's gradient products (include/medvill.h).
 @pytest.mark.parametrize("impl", ["mfma", "mfma256k64", "simple"])
-@pytest.mark.parametrize("M,N,K", [(256, 256, 256), (130, 70, 200), (1024, 768, 768), (64, 2, 768), (515, 2304, 264), (1030, 3072, 768)])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 256), (130, 70, 200), (1024, 768, 768), (64, 2, 768), (515, 2304, 264), (1030, 3072, 768),
+                                   (2100, 3072, 64), (700, 520, 136)])
 def test_gemm_f16_operands(impl, M, N, K):
     ops.set_impl(1 if impl == "simple" else 0)
     ops.set_gemm_variant(*VARIANT.get(impl, (0, 0)))
