@@ -10,6 +10,7 @@ struct GemmArgs {
                   // forward GEMM and the bf16 operand of the backward's weight-gradient GEMM from one accumulator tile
   int M, N, K, lda, ldb, ldc, ldc2, ldr, ldc3;
   int c_dtype, r_dtype, c3_dtype, epi, accumulate, vec_ok;
+  int vec8_ok;    // 16-bit C (and C2 / C3): 16-byte aligned bases and leading dimensions that are multiples of 8 -> 16-byte stores
   int kchunk, splitk;
   float* ws;
   unsigned bytesA, bytesB;
@@ -123,6 +124,36 @@ __device__ __forceinline__ void epilogue4v(const GemmArgs& p, int m, int n, f32x
   }
   st4_any(p.C, co, p.c_dtype, o);
   if (p.C3) st4_any(p.C3, (size_t)m * p.ldc3 + n, p.c3_dtype, o);
+}
+
+// 8 consecutive columns of one row of a 16-bit output: ONE 16-byte store per output tensor instead of two 8-byte ones (the
+// epilogue of a 16-bit tile is bound by the number of store instructions it issues, not by their bytes).  Epilogues without
+// a residual operand only: bias, bias + GELU (+ derivative), plain.
+__device__ __forceinline__ void st8_16(void* base, size_t i, int dtype, const float (&o)[8]) {
+  if (dtype == MV_BF16) {
+    bf16x8 r;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) r[e] = (bf16_t)o[e];
+    *(bf16x8*)((bf16_t*)base + i) = r;
+  } else {
+    f16x8 r;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) r[e] = (f16_t)o[e];
+    *(f16x8*)((f16_t*)base + i) = r;
+  }
+}
+template <int E>
+__device__ __forceinline__ void epilogue8_16(const GemmArgs& p, int m, int n, f32x4 v0, f32x4 v1, f32x4 b0, f32x4 b1) {
+  if (m >= p.M) return;
+  float o[8] = {v0[0] + b0[0], v0[1] + b0[1], v0[2] + b0[2], v0[3] + b0[3], v1[0] + b1[0], v1[1] + b1[1], v1[2] + b1[2], v1[3] + b1[3]};
+  if (E == MV_EPI_BIAS_GELU_D) {
+    float dd[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { float g_, d_; gelu_erf_and_grad(o[e], g_, d_); o[e] = g_; dd[e] = d_; }
+    st8_16(p.C2, (size_t)m * p.ldc2 + n, p.c_dtype, dd);
+  }
+  st8_16(p.C, (size_t)m * p.ldc + n, p.c_dtype, o);
+  if (p.C3) st8_16(p.C3, (size_t)m * p.ldc3 + n, p.c3_dtype, o);
 }
 
 // run BODY(E) with the run-time epilogue selector turned into a compile-time constant
@@ -249,6 +280,23 @@ __device__ __forceinline__ bf16x8 g2_frag(const char* tile, int base, int l15, i
   {                                                                                                            \
     constexpr int EE = (E_) < 0 ? 0 : (E_);                                                                    \
     constexpr bool HAS_R = (E_) == MV_EPI_BIAS_RES || (E_) == MV_EPI_RES || (E_) == MV_EPI_MUL || (E_) == MV_EPI_DGELU || (E_) == MV_EPI_BIAS_RES_RELU; \
+    constexpr bool WIDE_E = (E_) == MV_EPI_NONE || (E_) == MV_EPI_BIAS || (E_) == MV_EPI_BIAS_GELU_D;          \
+    if (WIDE_E && NJ == 4 && p.vec8_ok && p.c_dtype != MV_F32 && !p.accumulate && n0 + wn + 64 <= p.N) {       \
+      /* 16-bit outputs, 64 whole columns: a lane owns 8 consecutive columns of a row (8 lanes per row, 8 rows per pass) */ \
+      const int r8 = lane >> 3, c8 = lane & 7;                                                                 \
+      const int ncol8 = n0 + wn + c8 * 8;                                                                      \
+      f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;                                                                \
+      if ((E_) != MV_EPI_NONE) { b0 = *(const f32x4*)(p.bias + ncol8); b1 = *(const f32x4*)(p.bias + ncol8 + 4); } \
+      _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                          \
+        _Pragma("unroll") for (int j = 0; j < NJ; ++j) *(f32x4*)(scr + l15 * 272 + j * 64 + lq * 16) = acc[i][j]; \
+        _Pragma("unroll") for (int rr = 0; rr < 2; ++rr) {                                                     \
+          const int row = rr * 8 + r8;                                                                         \
+          const f32x4 v0 = *(const f32x4*)(scr + row * 272 + c8 * 32);                                         \
+          const f32x4 v1 = *(const f32x4*)(scr + row * 272 + c8 * 32 + 16);                                    \
+          epilogue8_16<EE>(p, m0 + wm + i * 16 + row, ncol8, v0, v1, b0, b1);                                  \
+        }                                                                                                      \
+      }                                                                                                        \
+    } else {                                                                                                   \
     const int ncol = n0 + wn + c4 * 4;                                                                         \
     const bool lane_fast = ((E_) >= 0) && col_on && p.vec_ok && (p.N - ncol >= 4);                             \
     f32x4 b4 = {0.f, 0.f, 0.f, 0.f};                                                                           \
@@ -292,6 +340,7 @@ __device__ __forceinline__ bf16x8 g2_frag(const char* tile, int base, int l15, i
           rcur = rnext;                                                                                        \
         }                                                                                                      \
       }                                                                                                        \
+    }                                                                                                          \
     }                                                                                                          \
   }
 
