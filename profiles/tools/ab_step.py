@@ -1,0 +1,44 @@
+"""A/B of training-step variants in ONE process on ONE device (box-to-box spread of the same build is +-2 %): interleaved rounds,
+median ms/step per variant.  usage: python profiles/tools/ab_step.py pack"""
+import os
+import statistics
+import sys
+import time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+import medvill_amd as mv
+
+dev = torch.device("cuda", 0)
+cfg = mv.ModelConfig()
+torch.manual_seed(1234)
+model = mv.CXRBERT(cfg, None, dtype=torch.bfloat16, device=dev)
+model.train()
+step = mv.TrainStep(model, lr=1e-5)
+B, N, S = 64, 36, 473
+batches = [mv.data.synthetic_batch(cfg.vocab_size, B, N, S, "full", seed=1234 + 1000 * i, device=dev) for i in range(4)]
+
+
+def timed(n=8):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(n):
+        step(batches[i % 4])
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n * 1e3
+
+
+VARIANTS = {
+    "pack": [("padded", lambda: setattr(step, "pack_rows", False)), ("packed", lambda: setattr(step, "pack_rows", True))],
+}
+which = sys.argv[1] if len(sys.argv) > 1 else "pack"
+arms = VARIANTS[which]
+for _ in range(3):
+    step(batches[0])
+res = {n: [] for n, _ in arms}
+for r in range(5):
+    for n, f in arms:
+        f()
+        step(batches[0])
+        res[n].append(timed())
+for n, v in res.items():
+    print(f"{n:24s} median {statistics.median(v):.2f} ms  (min {min(v):.2f}, max {max(v):.2f})")
