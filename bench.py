@@ -259,6 +259,9 @@ def main():
         vls = torch.cat([b_["attn_desc"].host_desc()[:, 2] for b_ in batches]).double() if packed else torch.full((1,), float(L)).double()
         rows_mean = float(vls.mean())
         f_enc = cfg.layers * (rows_mean * (8.0 * Hh * Hh + 4.0 * Hh * Ii) + 4.0 * float((vls * vls).mean()) * Hh)
+        if step.tail_rows:
+            # the last layer's output projection and FFN run on the consumed rows only (labelled rows + one [CLS] row per sample)
+            f_enc -= (rows_mean - (n_lab + 1.0)) * (2.0 * Hh * Hh + 4.0 * Hh * Ii)
         f_exec = 3.0 * (2.0 * N * cfg.img_hidden * Hh + f_enc + 2.0 * Hh * Hh + n_lab * (2.0 * Hh * Hh + 2.0 * Hh * Vv) + 4.0 * Hh)
         executed = value / world * f_exec / 1e12
         kern = time_dominant_kernel(model.engine, B, L)
@@ -278,6 +281,8 @@ def main():
                        else "16-bit MFMA operands, all bf16-encoded",
                        "rows": (f"padding removed: encoder on the valid rows only (mean {rows_mean:.1f} of {L} positions per sample; "
                                 "results equal the padded run)") if packed else "padded",
+                       "last_layer": "output projection / FFN / LayerNorms of the last layer on the consumed rows only (labelled rows + "
+                                     "[CLS] rows; the other rows' outputs are unused and their gradients exactly zero)" if step.tail_rows else "all rows",
                        "padded_ms_per_step": extras.get("padded_ms_per_step"), "padded_pairs_per_s": pps(extras.get("padded_ms_per_step")),
                        "full_length_ms_per_step": extras.get("full_length_ms_per_step"),
                        "full_length_pairs_per_s": pps(extras.get("full_length_ms_per_step")),

@@ -256,6 +256,8 @@ class Engine:
             rows, rows_cap = getattr(self, "_rows_now", 0), getattr(self, "_rows_cap", 0)
             if rows_cap > rows > 0 and len(shape) > 0 and shape[0] == rows:
                 cap = n // rows * rows_cap
+            elif t is not None and t.dtype == dtype:
+                cap = n + n // 4          # a buffer that had to grow (labelled-row counts vary): leave headroom
             t = torch.empty(cap, dtype=dtype, device=self.device)
             self._ws[key] = t
         return t[:n].view(shape)
@@ -279,11 +281,18 @@ class Engine:
         ops.gemm(dy, x, gW, ta=True, tb=True, M=No, N=Ko, K=Mtok, lda=lda, ldb=ldb, ldc=ldc, splitk=0 if auto else 1, ws=ws)
 
     # ------------------------------------------------------------------ encoder forward
-    def encoder_forward(self, cls_tok, input_txt, attn_mask, segment, img_feats, img_pos, sep_tok, pack=False):
+    def encoder_forward(self, cls_tok, input_txt, attn_mask, segment, img_feats, img_pos, sep_tok, pack=False, tail_rows=None):
         """pack=True (fused training path, bf16, mask descriptors of the full / seq2seq / 1-D families): the encoder runs
         on the valid rows only -- positions after a sample's text [SEP] are invisible to every valid query in those
         families and carry no label, so they contribute nothing to the loss or to any gradient (include/medvill.h,
-        'packed rows').  Hidden states are then [sum(vl), H] and the first return value is that packed matrix."""
+        'packed rows').  Hidden states are then [sum(vl), H] and the first return value is that packed matrix.
+
+        tail_rows (fused training path; int32 [R], flat logical positions b*L+i of the labelled tokens): only those rows
+        and each sample's first row ([CLS] -> pooler -> ITM) of the LAST layer's output are ever consumed -- by the MLM
+        head on the labelled rows and by the pooler -- so everything of the last layer that follows its attention (output
+        projection, LayerNorm, FFN, LayerNorm: per-row work) runs on those R + B rows only, and so does its backward.
+        Exact: the other rows' outputs are unused and their gradients are zero.  The final hidden state is then the compact
+        [R + B, H] matrix (labelled rows first, in the order given, then the B first rows)."""
         cfg, dt, adt, dev = self.cfg, self.dt, self.adt, self.device
         fadt, dual = self.fadt, self.dual
         wf = self.wf
@@ -302,7 +311,7 @@ class Engine:
         if self.shadow_dirty:
             self.sync_shadow()
         f32 = torch.float32
-        S = self.S = dict(B=B, T=T, N=N, L=Lq, M=M, cu=None, rowmap=None, inv=None)
+        S = self.S = dict(B=B, T=T, N=N, L=Lq, M=M, cu=None, rowmap=None, inv=None, sel=None, n_lab=0)
         if pack:
             if not isinstance(attn_mask, MaskDesc) or dt != MV_BF16:
                 raise ValueError("pack=True needs mask descriptors (data.MaskDesc) and the bf16 path")
@@ -314,6 +323,13 @@ class Engine:
             S["M"] = M
         self._rows_now, self._rows_cap = M, B * Lq
         cu, rowmap = S["cu"], S["rowmap"]
+        if tail_rows is not None and cfg.layers >= 1:
+            lab = tail_rows.to(dev)
+            if S["inv"] is not None and lab.numel() > 0:     # logical flat positions -> packed rows
+                lab = S["inv"].index_select(0, lab.to(torch.int64))
+            first = cu[:B] if cu is not None else torch.arange(B, device=dev, dtype=torch.int32) * Lq
+            S["sel"] = torch.cat([lab.to(torch.int32), first.to(torch.int32)]).contiguous()
+            S["n_lab"] = int(tail_rows.numel())
         pd = S["p_drop"] = float(cfg.dropout) if self.training else 0.0
         self.drop_counter += 1
         dk = S["drop_keys"] = self._drop_keys(cfg.layers)
@@ -380,6 +396,21 @@ class Engine:
             lse = a_["lse"] = self._buf(f"lse{l}", (B, A, Lq), f32)
             ops.attn_fwd(qkv, bits, tinfo, ctx, lse, B, Lq, A, dh, p_drop=pd, drop_key=dk[(self.SITE_ATTN, l)], cu=cu,
                          total_rows=M, ctx_bf16=xb2(ctx, ctx_b))
+            Mr = M                  # rows the rest of this layer runs on
+            if l == cfg.layers - 1 and S["sel"] is not None:
+                # last layer: only the labelled rows and the first row of every sample are consumed downstream
+                sel = S["sel"]
+                Mr = int(sel.numel())
+                ctx_s, ctx_sb = self._pair("tail_ctx", (Mr, H))
+                x_s = self._buf("tail_x", (Mr, H), fadt)
+                ops.gather_rows(ctx, H, sel, Mr, H, ctx_s, H)
+                ops.gather_rows(x, H, sel, Mr, H, x_s, H)
+                if dual:
+                    ops.gather_rows(ctx_b, H, sel, Mr, H, ctx_sb, H)
+                ctx, x = ctx_s, x_s
+                a_["ctx_tail"] = ctx_sb
+            a_["rows"] = Mr
+            M_all, M = M, Mr        # (restored after the layer; nothing follows the last layer)
             pre1 = a_["pre1"] = self._buf(f"pre1_{l}", (M, H), f32)
             ops.gemm(ctx, wf[p + "attention.output.dense.weight"], pre1, M=M, N=H, K=H,
                      bias=self.p[p + "attention.output.dense.bias"], epi=EPI_BIAS_RES, r=x, p_drop=pd,
@@ -403,11 +434,15 @@ class Engine:
             a_["mean2"], a_["rstd2"] = self._buf(f"mean2_{l}", (M,), f32), self._buf(f"rstd2_{l}", (M,), f32)
             ops.layernorm_fwd(pre2, self.p[p + "output.LayerNorm.weight"], self.p[p + "output.LayerNorm.bias"], x, a_["mean2"],
                               a_["rstd2"], M, H, cfg.ln_eps, y_bf16=xb2(x, x_b))
+            M = M_all
             S["layers"].append(a_)
         S["hidden_f"], S["hidden"] = x, x_b
         pooled, pooled_b = self._pair("pooled", (B, H))
         S["pooled_f"], S["pooled"] = pooled, pooled_b
-        if cu is None:
+        if S["sel"] is not None:
+            R_ = S["n_lab"]                               # compact final hidden state: the B first rows follow the labelled ones
+            h0_f, S["h0"], S["h0_ld"] = x[R_:], x_b[R_:], H
+        elif cu is None:
             h0_f, S["h0"], S["h0_ld"] = x, x_b, Lq * H    # first row of every sample, addressed in place
         else:
             h0_f, S["h0"] = self._pair("h0", (B, H))
@@ -417,7 +452,7 @@ class Engine:
                 ops.gather_rows(x_b, H, cu, B, H, S["h0"], H)
         ops.gemm(h0_f, wf["enc.pooler.dense.weight"], pooled, M=B, N=H, K=H, lda=S["h0_ld"],
                  bias=self.p["enc.pooler.dense.bias"], epi=EPI_BIAS_TANH, c3=xb2(pooled, pooled_b))
-        return (x.view(B, Lq, H) if cu is None else x), pooled
+        return (x.view(B, Lq, H) if (cu is None and S["sel"] is None) else x), pooled
 
     # ------------------------------------------------------------------ heads (shared pieces)
     def _itm_forward(self):
@@ -492,6 +527,9 @@ class Engine:
         self._dW(dpre, S["h0"], g["enc.pooler.dense.weight"], H, H, B, lda=H, ldb=S["h0_ld"])
         dh0 = self._buf("dh0", (B, H), self.adt)
         ops.gemm(dpre, self.w["enc.pooler.dense.weight"], dh0, tb=True, M=B, N=H, K=H)
+        if S["sel"] is not None:                         # compact final hidden state: rows n_lab .. n_lab+B-1 are the first rows
+            S["dhidden"][S["n_lab"]:].copy_(dh0)
+            return
         if S["cu"] is None:
             rows0 = self._buf("rows0", (B,), torch.int32)
             rows0.copy_(torch.arange(B, device=self.device, dtype=torch.int32) * Lq)
@@ -535,18 +573,27 @@ class Engine:
         S, H, V = self.S, self.cfg.hidden, self.cfg.vocab_size
         M, B = S["M"], S["B"]
         R = int(label_rows.numel())
-        if S["inv"] is not None and R > 0:               # logical flat positions -> packed rows
+        compact = S["sel"] is not None                   # final hidden state = [labelled rows | first rows] (encoder_forward)
+        if compact and R != S["n_lab"]:
+            raise ValueError("heads_train: label_rows differ from the tail_rows the encoder ran with")
+        if not compact and S["inv"] is not None and R > 0:               # logical flat positions -> packed rows
             label_rows = S["inv"].index_select(0, label_rows.to(torch.int64))
         stats = torch.zeros(6, dtype=torch.float32, device=self.device)
         if compute_grad:
             self.ensure_grad()
-            dhid = S["dhidden"] = self._buf("dhidden", (M, H), self.adt)
-            dhid.zero_()
+            if compact:
+                dhid = S["dhidden"] = self._buf("dhidden_tail", (R + B, H), self.adt)
+            else:
+                dhid = S["dhidden"] = self._buf("dhidden", (M, H), self.adt)
+                dhid.zero_()
         if R > 0:
-            xr, xr_b = self._pair("ht_xr", (R, H))
-            ops.gather_rows(S["hidden_f"], H, label_rows, R, H, xr, H)
-            if self.dual:
-                ops.gather_rows(S["hidden"], H, label_rows, R, H, xr_b, H)
+            if compact:
+                xr, xr_b = S["hidden_f"][:R], S["hidden"][:R]
+            else:
+                xr, xr_b = self._pair("ht_xr", (R, H))
+                ops.gather_rows(S["hidden_f"], H, label_rows, R, H, xr, H)
+                if self.dual:
+                    ops.gather_rows(S["hidden"], H, label_rows, R, H, xr_b, H)
             logits = self._mlm_forward(xr, xr_b, R, "ht_")
             Vp = logits.shape[1]
             dl = torch.empty((R, Vp), dtype=self.adt, device=self.device) if compute_grad else None
@@ -554,7 +601,10 @@ class Engine:
                            grad_scale=(mlm_scale if mlm_scale is not None else 1.0 / R))
             if compute_grad:
                 dxr = self._mlm_backward(dl, "ht_")
-                ops.scatter_rows(dxr, H, label_rows, R, H, dhid, H, accumulate=False)
+                if compact:
+                    dhid[:R].copy_(dxr)
+                else:
+                    ops.scatter_rows(dxr, H, label_rows, R, H, dhid, H, accumulate=False)
         itm = self._itm_forward()
         d8 = self._buf("ditm8", (B, 8), self.adt) if compute_grad else None
         ops.ce_fwd_bwd(itm, 2, is_aligned, B, 2, stats[3:6], d8, 8, grad_scale_dev=itm_scale_dev,
@@ -604,17 +654,21 @@ class Engine:
         delta = self._buf("bw_delta", (B, A, Lq), torch.float32)
         da = self._buf("bw_da", (M, H), adt)
         dxb = [self._buf("bw_dx0", (M, H), adt), self._buf("bw_dx1", (M, H), adt)]
+        M_all = M
         for l in reversed(range(cfg.layers)):
             p = f"enc.encoder.layer.{l}."
             a_ = S["layers"][l]
             Wqkv, _, gWqkv, gbqkv = self.qkv_views(l)
+            # the last layer's per-row part ran on the consumed rows only (encoder_forward, tail_rows): so does its backward
+            tail = a_["rows"] != M_all
+            M = a_["rows"]
             # with dropout the projection branch sees dpre * mask / (1-p) while the residual branch sees dpre itself
             dpre2 = self._buf(f"bw_dpre2_{l}", (M, H), adt)
             dprd2 = self._buf(f"bw_dprd2_{l}", (M, H), adt) if pd > 0 else None
             dpre1 = self._buf(f"bw_dpre1_{l}", (M, H), adt)
             dprd1 = self._buf(f"bw_dprd1_{l}", (M, H), adt) if pd > 0 else None
             dz = self._buf(f"bw_dz_{l}", (M, I), adt)
-            dqkv = self._buf(f"bw_dqkv_{l}", (M, 3 * H), adt)
+            dqkv = self._buf(f"bw_dqkv_{l}", (M_all, 3 * H), adt)
             # LN2 backward (+ bias grad of output.dense)
             ops.layernorm_bwd(dy, a_["pre2"], a_["mean2"], a_["rstd2"], self.p[p + "output.LayerNorm.weight"], dpre2,
                               g[p + "output.LayerNorm.weight"], g[p + "output.LayerNorm.bias"], g[p + "output.dense.bias"], M, H,
@@ -637,8 +691,16 @@ class Engine:
             dproj1 = dprd1 if dprd1 is not None else dpre1
             fork()
             with torch.cuda.stream(side):
-                self._dW(dproj1, a_["ctx"], g[p + "attention.output.dense.weight"], H, H, M, lda=H, ldb=H)
-            ops.gemm(dproj1, self.w[p + "attention.output.dense.weight"], dctx, tb=True, M=M, N=H, K=H)
+                self._dW(dproj1, a_["ctx_tail"] if tail else a_["ctx"], g[p + "attention.output.dense.weight"], H, H, M, lda=H, ldb=H)
+            if tail:
+                # d(ctx) exists on the consumed rows only: everywhere else it is exactly zero
+                dctx_s = self._buf("bw_dctx_tail", (M, H), adt)
+                ops.gemm(dproj1, self.w[p + "attention.output.dense.weight"], dctx_s, tb=True, M=M, N=H, K=H)
+                dctx.zero_()
+                ops.scatter_rows(dctx_s, H, S["sel"], M, H, dctx, H, accumulate=False)
+            else:
+                ops.gemm(dproj1, self.w[p + "attention.output.dense.weight"], dctx, tb=True, M=M, N=H, K=H)
+            M = M_all
             ops.attn_bwd(a_["qkv"], a_["ctx"], dctx, a_["lse"], S["bits"], S["tinfo"], dqkv, delta, B, Lq, A, dh, cu=S["cu"],
                          total_rows=M, p_drop=pd,
                          drop_key=dk[(self.SITE_ATTN, l)])
@@ -648,7 +710,12 @@ class Engine:
                 self._dW(dqkv, a_["x"], gWqkv, 3 * H, H, M, lda=3 * H, ldb=H)
                 ev_layer = side_done()
             dx = dxb[l & 1]          # never the buffer dy currently lives in
-            ops.gemm(dqkv, Wqkv, dx, tb=True, M=M, N=H, K=3 * H, epi=EPI_RES, r=dpre1)
+            if tail:
+                # the residual branch's gradient (dpre1) also lives on the consumed rows only
+                ops.gemm(dqkv, Wqkv, dx, tb=True, M=M, N=H, K=3 * H)
+                ops.scatter_rows(dpre1, H, S["sel"], a_["rows"], H, dx, H, accumulate=True)
+            else:
+                ops.gemm(dqkv, Wqkv, dx, tb=True, M=M, N=H, K=3 * H, epi=EPI_RES, r=dpre1)
             dy = dx
             if bucket_hook:
                 # LayerNorm / bias gradients of the layer were written on the main stream, the weights on the side stream

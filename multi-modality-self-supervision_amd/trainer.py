@@ -32,6 +32,7 @@ class TrainStep:
         # padding removal: when a batch carries mask descriptors of the full / seq2seq / 1-D families (bf16 path), the
         # encoder runs on the valid rows only; results are those of the padded run (see Engine.encoder_forward)
         self.pack_rows = pack_rows
+        self.tail_rows = True        # last layer after its attention: consumed rows only (exact; Engine.encoder_forward)
         self.eng.ensure_opt()
         self.dp = None
         self.time_exchange = False
@@ -79,8 +80,10 @@ class TrainStep:
         desc = batch.get("attn_desc") if use_desc else None
         pack = bool(self.pack_rows and desc is not None and eng.adt == torch.bfloat16 and desc.packable())
         mask = desc if desc is not None else batch["attn_mask"]      # descriptors when there are any: no [B,L,L] traffic
+        # the last layer's per-row work runs only on the rows the heads consume (labelled rows + each sample's first row)
         eng.encoder_forward(batch["cls_tok"], batch["input_txt"], mask, batch["segment"],
-                            batch["img_feats"], batch["img_pos"], batch["sep_tok"], pack=pack)
+                            batch["img_feats"], batch["img_pos"], batch["sep_tok"], pack=pack,
+                            tail_rows=rows if self.tail_rows else None)
         R, B = int(rows.numel()), int(aligned.numel())
         # loss normalisation = the reference's means over the GLOBAL mini-batch (train_origin.py:120-126)
         mlm_dev = itm_dev = None

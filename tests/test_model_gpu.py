@@ -249,7 +249,14 @@ def test_dropout_training_step_against_oracle_with_the_same_masks(golden_dir):
         else:
             keep, sc = ops.dropout_mask(0.1, key, B * Lq * H, DEV)
             name = {eng.SITE_EMB: "emb", eng.SITE_OUT1: ("out1", l), eng.SITE_OUT2: ("out2", l)}[site]
-            masks[name] = (keep.view(B, Lq, H).float() * sc).cpu()
+            full = keep.view(B * Lq, H).float() * sc
+            if site != eng.SITE_EMB and l == cfg.layers - 1 and eng.S["sel"] is not None:
+                # the last layer's per-row part ran on the consumed rows only: its masks are keyed by the COMPACT row index;
+                # the other rows' outputs are never used, so any mask serves there
+                sel = eng.S["sel"].long()
+                full = torch.ones_like(full)
+                full[sel] = (keep.view(-1, H)[:sel.numel()].float() * sc)
+            masks[name] = full.view(B, Lq, H).cpu()
         fracs.append(float(keep.float().mean()))
         assert sc == pytest.approx(1.0 / (1.0 - 26.0 / 256.0))
     assert all(abs(f - (1 - 26 / 256)) < 0.01 for f in fracs), fracs
@@ -373,7 +380,7 @@ def test_packed_rows_reproduce_the_padded_step(family, B, N, S):
         assert (eng.S["cu"] is not None) == pack
         if pack:
             vl = batch["attn_desc"].host_desc()[:, 2]
-            assert eng.S["M"] == int(vl.sum()) < B * (N + S + 3) and eng.S["hidden"].shape[0] == eng.S["M"]
+            assert eng.S["M"] == int(vl.sum()) < B * (N + S + 3) and eng.S["layers"][0]["x"].shape[0] == eng.S["M"]
         out.append((stats.clone(), eng.flat_g.clone()))
     (s0, g0), (s1, g1) = out
     assert torch.equal(s0[[1, 2, 4, 5]], s1[[1, 2, 4, 5]])                       # counts: labels, correct predictions
@@ -404,6 +411,33 @@ def test_packed_rows_reproduce_the_padded_step_at_bert_base_scale(family, N, S):
     rel = float((g0 - g1).norm() / g0.norm())
     print(f"BERT-base {family} L={N + S + 3}: packed vs padded gradient rel L2 {rel:.2e}")
     assert rel < 1e-3
+
+
+@pytest.mark.parametrize("dtype,family,layers", [(torch.float32, "bar", 2), (torch.bfloat16, "mixed", 2), (torch.bfloat16, "full", 1)])
+def test_last_layer_on_consumed_rows_only_changes_nothing(dtype, family, layers):
+    """TrainStep runs the last layer's per-row part (output projection, LayerNorms, FFN) only on the rows that are consumed
+    downstream -- the labelled rows (MLM head) and each sample's first row (pooler -> ITM) -- and back-propagates through
+    it on those rows only.  The other rows' outputs are unused and their gradients are exactly zero, so losses, counters
+    and every parameter gradient must equal the all-rows run (different summation sets of the same non-zero terms)."""
+    cfg = mv.ModelConfig(hidden=128, heads=2, intermediate=512, layers=layers, vocab_size=1024, max_pos=512, dropout=0.0)
+    batch = mv.data.synthetic_batch(cfg.vocab_size, 5, 6, 90, family, seed=41, device=DEV)
+    out = []
+    for tail in (False, True):
+        model = mv.CXRBERT(cfg, None, dtype=dtype, device=DEV)
+        model.reset_parameters(seed=6)
+        model.train()
+        ts = mv.TrainStep(model, lr=0.0)
+        ts.tail_rows = tail
+        stats = ts(batch, train=True)
+        R = int(batch["label_rows"].numel())
+        assert (model.engine.S["sel"] is not None) == tail
+        assert model.engine.S["hidden"].shape[0] == (R + 5 if tail else model.engine.S["M"])
+        out.append((stats.clone(), model.engine.flat_g.clone()))
+    (s0, g0), (s1, g1) = out
+    assert torch.equal(s0[[1, 2, 4, 5]], s1[[1, 2, 4, 5]]) and float((s0 - s1).abs().max() / s0.abs().max()) < 1e-5
+    rel = float((g0 - g1).norm() / g0.norm())
+    print(f"consumed-rows tail vs all rows ({dtype}, {family}): gradient rel L2 {rel:.2e}")
+    assert rel < (1e-5 if dtype == torch.float32 else 2e-3)
 
 
 def test_packing_is_refused_where_padding_is_visible():
