@@ -67,7 +67,7 @@ def test_two_rank_step_equals_single_process_step(dtype):
     assert torch.equal(p0, p1)                                     # replicas stay identical without any broadcast
     # 2 AdamW steps of size 1e-3 on the same gradient (16-bit path: sign flips of near-zero gradient entries move 2e-3)
     assert float((p0 - ref).abs().max()) < (2e-5 if dtype == torch.float32 else 4.1e-3)
-    assert float((p0 - ref).abs().mean()) < (1e-6 if dtype == torch.float32 else 2e-5)
+    assert float((p0 - ref).abs().mean()) < (1e-6 if dtype == torch.float32 else 5e-5)
     tot = s0 + s1
     assert float(tot[1]) == float(stats[1]) and abs(float(tot[0]) - float(stats[0])) < 1e-2 * float(stats[0])
     assert out[0][3] == (dtype == torch.bfloat16)                  # packed rows ran under data parallelism
