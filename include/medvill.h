@@ -100,9 +100,7 @@ void mv_set_gemm_variant(int force, int nj);
  * (>= splitk*M*N floats) and are summed by a second kernel; only with MV_EPI_NONE and an f32 C.
  * accumulate != 0: C += result (f32 C, MV_EPI_NONE only).
  * p_drop > 0 (MV_EPI_BIAS_RES only, N % 4 == 0): C = dropout(A.B + bias) + R -- the hidden-state dropout
- * of HF BertSelfOutput / BertOutput; mask = mv_dropout_mask(p_drop, drop_key) over index m*N + n.
- * colsum (nullable, f32 [N]): colsum[n] += sum_m C[m,n] (atomics) from the tile epilogue -- the bias gradient of the Linear
- * layer whose input gradient this GEMM produces (C = dZ); 16-bit operands, N % 4 == 0, no split-K.  */
+ * of HF BertSelfOutput / BertOutput; mask = mv_dropout_mask(p_drop, drop_key) over index m*N + n.  */
 int mv_gemm(int dtype, int ta, int tb, int M, int N, int K,
             const void* A, int lda, const void* B, int ldb,
             void* C, int ldc, int c_dtype,
@@ -111,7 +109,7 @@ int mv_gemm(int dtype, int ta, int tb, int M, int N, int K,
             void* C2, int ldc2,
             void* C3, int ldc3, int c3_dtype,
             int splitk, float* ws, size_t ws_bytes, int accumulate,
-            float p_drop, unsigned long long drop_key, float* colsum, void* stream);
+            float p_drop, unsigned long long drop_key, void* stream);
 
 /* ---- attention masks ----------------------------------------------------------------------
  * Replaces CXRBertEncoder.get_extended_attn_mask (cxrbert_origin.py:75-85): instead of an
@@ -186,13 +184,11 @@ int mv_attn_fwd(int dtype, const void* qkv, const uint32_t* bits, const uint8_t*
                 void* ctx, void* ctx_bf16, float* lse, int B, int L, int A, int dh,
                 float p_drop, unsigned long long drop_key, const int32_t* cu, int total_rows, void* stream);
 
-/* dqkv [B*L,3H] from dctx [B*L,H]; `delta` is a [B,A,L] f32 scratch (rowsum(dctx*ctx)).
- * colsum (nullable, f32 [3H]): colsum[c] += sum over rows of dqkv[:, c] -- the bias gradient of the fused q/k/v projection,
- * accumulated from the kernels' own registers (no second pass over dqkv). */
+/* dqkv [B*L,3H] from dctx [B*L,H]; `delta` is a [B,A,L] f32 scratch (rowsum(dctx*ctx)). */
 int mv_attn_bwd(int dtype, const void* qkv, const void* ctx, const void* dctx, const float* lse,
                 const uint32_t* bits, const uint8_t* tileinfo,
                 void* dqkv, float* delta, int B, int L, int A, int dh,
-                float p_drop, unsigned long long drop_key, const int32_t* cu, int total_rows, float* colsum, void* stream);
+                float p_drop, unsigned long long drop_key, const int32_t* cu, int total_rows, void* stream);
 
 /* ---- LayerNorm ------------------------------------------------------------------------------
  * y = (x-mean)/sqrt(var+eps)*gamma+beta over the last dim (HF LayerNorm eps=1e-12 in the

@@ -29,14 +29,14 @@ PROTOTYPES = {
     "mv_build_info": [],
     "mv_set_gemm_variant": [i32, i32],
     "mv_gemm": [i32, i32, i32, i32, i32, i32, vp, i32, vp, i32, vp, i32, i32, vp, i32, vp, i32, i32, vp, i32, vp, i32, i32,
-                i32, vp, sz, i32, f32, u64, vp, vp],
+                i32, vp, sz, i32, f32, u64, vp],
     "mv_mask_pack": [vp, i32, i32, i32, vp, vp, vp],
     "mv_mask_build": [vp, i32, i32, vp, vp, vp],
     "mv_mlm_draws": [u64, i32, i32, i32, vp, vp, vp],
     "mv_mlm_corrupt": [vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "mv_pack_plan": [vp, i32, i32, vp, vp, vp, vp],
     "mv_attn_fwd": [i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, u64, vp, i32, vp],
-    "mv_attn_bwd": [i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, u64, vp, i32, vp, vp],
+    "mv_attn_bwd": [i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, u64, vp, i32, vp],
     "mv_layernorm_fwd": [i32, vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, f32, vp],
     "mv_layernorm_bwd": [i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, f32, u64, vp],
     "mv_embed_fwd": [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, f32,

@@ -144,7 +144,6 @@ struct AttnArgs {
   float scale;
   unsigned bytes_qkv, bytes_ctx;
   unsigned bytes_stat, bytes_bits;     // sizes of lse / delta ([B,A,L] f32) and of the mask words, for the LDS-DMA descriptors
-  float* colsum;                       // backward (nullable): f32 [3H], colsum[c] += sum over rows of dqkv[:, c] (the q/k/v bias gradient)
   DropCfg drop;   // attention-probability dropout; mask index = ((b*A + h)*L + q)*Lp + k, Lp = L rounded up to 4
   int Lp;
   // packed rows (nullable): sample b owns rows cu[b] .. cu[b+1]-1 of qkv / ctx / dctx / out / dqkv, i.e. only its first
@@ -213,12 +212,6 @@ __device__ __forceinline__ void tile_dma(__amdgpu_buffer_rsrc_t rs, unsigned byt
     const unsigned off = (unsigned)(((rowbase + row0 + r) * (size_t)ld + col0 + ch * 8) * 2);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (MV_LDS void*)(tile + pc * 1024), 16, ok ? off : bytes, 0, 0, 0);
   }
-}
-// column sums of a gradient block for the fused bias gradient: an accumulator register holds one d-column of 32 rows (the
-// lanes of a half-wave); butterfly over the 5 low lane bits, one atomic per column from the first lane of each half
-__device__ __forceinline__ void att_colsum32(float v, float* dst, int l31) {
-  v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64);
-  if (l31 == 0) atomicAdd(dst, v);
 }
 template <int N> __device__ __forceinline__ void att_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 // wait until at most `younger` stages (of PPW LDS-DMA instructions per wave each) are still in flight
@@ -602,12 +595,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_mfma_kernel(AttnArgs a) {
     cur = next_tile(tmk.need, cur, nkt);
     ++done;
   }
-  if (a.colsum && wave_on) {           // q-bias gradient: rows past Lv carry exact zeros (zero q / dO fragments, lse = +inf)
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) att_colsum32(dq[dt][i], a.colsum + head * 64 + 32 * dt + 8 * (i >> 2) + 4 * h + (i & 3), l31);
-  }
   if (!q_ok) return;
   bf16_t* orow = a.dqkv + (rowbase + q) * (size_t)ld + head * 64;
 #pragma unroll
@@ -770,16 +757,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_mfma_kernel(AttnArgs a) {
     }
     cur = next_tile(tmk.need, cur, nqt);
     ++done;
-  }
-  if (a.colsum && wave_on) {           // k / v bias gradients; key lanes past Lv hold values that are never stored: masked out
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int dcol = head * 64 + 32 * dt + 8 * (i >> 2) + 4 * h + (i & 3);
-        att_colsum32(k_ok ? dk[dt][i] : 0.f, a.colsum + H + dcol, l31);
-        att_colsum32(k_ok ? dv[dt][i] : 0.f, a.colsum + 2 * H + dcol, l31);
-      }
   }
   if (!k_ok) return;
   bf16_t* krow = a.dqkv + (rowbase + key) * (size_t)ld + H + head * 64;
@@ -1066,7 +1043,7 @@ static int launch_simple_bwd(const void* qkv, const void* ctx, const void* dctx,
 
 extern "C" int mv_attn_bwd(int dtype, const void* qkv, const void* ctx, const void* dctx, const float* lse, const uint32_t* bits,
                            const uint8_t* tileinfo, void* dqkv, float* delta, int B, int L, int A, int dh, float p_drop,
-                           unsigned long long drop_key, const int32_t* cu, int total_rows, float* colsum, void* stream_) {
+                           unsigned long long drop_key, const int32_t* cu, int total_rows, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   const DropCfg drop = mv_make_drop(p_drop, drop_key);
   if (!qkv || !ctx || !dctx || !lse || !bits || !tileinfo || !dqkv || !delta || B <= 0 || L <= 0 || A <= 0 || dh <= 0)
@@ -1082,7 +1059,7 @@ extern "C" int mv_attn_bwd(int dtype, const void* qkv, const void* ctx, const vo
     AttnArgs a{};
     a.cu = cu;
     a.qkv = (const bf16_t*)qkv; a.ctx = (const bf16_t*)ctx; a.dctx = (const bf16_t*)dctx; a.dqkv = (bf16_t*)dqkv;
-    a.bits = bits; a.info = tileinfo; a.lse_in = lse; a.delta = delta; a.delta_out = delta; a.colsum = colsum;
+    a.bits = bits; a.info = tileinfo; a.lse_in = lse; a.delta = delta; a.delta_out = delta;
     a.B = B; a.L = L; a.A = A; a.H = H; a.W = (L + 31) / 32; a.T = (L + 63) / 64;
     a.scale = 1.0f / sqrtf((float)dh);
     a.bytes_qkv = (unsigned)bq; a.bytes_ctx = (unsigned)bc;
@@ -1102,8 +1079,6 @@ extern "C" int mv_attn_bwd(int dtype, const void* qkv, const void* ctx, const vo
     return MV_OK;
   }
   if (dh > 128 || cu) return MV_E_SHAPE;
-  int rc = dtype == MV_F32 ? launch_simple_bwd<float>(qkv, ctx, dctx, lse, bits, dqkv, delta, B, L, A, dh, drop, stream)
-                           : launch_simple_bwd<bf16_t>(qkv, ctx, dctx, lse, bits, dqkv, delta, B, L, A, dh, drop, stream);
-  if (rc == MV_OK && colsum) rc = mv_colsum(dtype, dqkv, 3 * H, B * L, 3 * H, colsum, 1, stream_);   // exact / cross-check path
-  return rc;
+  return dtype == MV_F32 ? launch_simple_bwd<float>(qkv, ctx, dctx, lse, bits, dqkv, delta, B, L, A, dh, drop, stream)
+                         : launch_simple_bwd<bf16_t>(qkv, ctx, dctx, lse, bits, dqkv, delta, B, L, A, dh, drop, stream);
 }

@@ -205,9 +205,8 @@ __global__ __launch_bounds__(256, SB ? 3 : 2) void gemm_mfma_kernel(GemmArgs p) 
   // bias once per tile, residual rows one 16-row group ahead of the stores (see epilogue4v)
 #define EPI_BODY(E_)                                                                                          \
   {                                                                                                           \
-    f32x4 b4[4], rc[4], rn[4], cs[4];                                                                         \
+    f32x4 b4[4], rc[4], rn[4];                                                                                \
     bool fast[4];                                                                                             \
-    _Pragma("unroll") for (int j = 0; j < 4; ++j) cs[j] = (f32x4){0.f, 0.f, 0.f, 0.f};                        \
     _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                           \
       const int n = n0 + wn + j * 16 + 4 * lq;                                                                \
       fast[j] = p.vec_ok && (p.N - n >= 4);                                                                   \
@@ -226,21 +225,10 @@ __global__ __launch_bounds__(256, SB ? 3 : 2) void gemm_mfma_kernel(GemmArgs p) 
       }                                                                                                       \
       _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                         \
         const int n = n0 + wn + j * 16 + 4 * lq;                                                              \
-        if (fast[j]) cs[j] += epilogue4v<E_>(p, m, n, acc[i][j], b4[j], rc[j]);                               \
+        if (fast[j]) epilogue4v<E_>(p, m, n, acc[i][j], b4[j], rc[j]);                                        \
         else epilogue4_slow(p, m, n, acc[i][j]);                                                              \
       }                                                                                                       \
       _Pragma("unroll") for (int j = 0; j < 4; ++j) rc[j] = rn[j];                                            \
-    }                                                                                                         \
-    if (p.colsum) {                                                                                           \
-      /* column sums of the tile's 64 x 64 wave block: rows sit on lanes l15 (xor-shuffle over the low 4 lane bits), one \
-         atomic per column from lane l15 == 0; host side guarantees the vector path for every column */      \
-      _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                         \
-        _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                       \
-          float t_ = cs[j][e];                                                                                \
-          t_ += __shfl_xor(t_, 1, 64); t_ += __shfl_xor(t_, 2, 64); t_ += __shfl_xor(t_, 4, 64); t_ += __shfl_xor(t_, 8, 64); \
-          if (l15 == 0 && fast[j]) atomicAdd(p.colsum + n0 + wn + j * 16 + 4 * lq + e, t_);                   \
-        }                                                                                                     \
-      }                                                                                                       \
     }                                                                                                         \
   }
   MV_EPI_SWITCH(p.epi, EPI_BODY)
@@ -337,7 +325,7 @@ static inline bool aligned_to(const void* p, size_t a) { return p == nullptr || 
 extern "C" int mv_gemm(int dtype, int ta, int tb, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
                        void* C, int ldc, int c_dtype, const float* bias, int epi, const void* R, int ldr, int r_dtype,
                        void* C2, int ldc2, void* C3, int ldc3, int c3_dtype, int splitk, float* ws, size_t ws_bytes,
-                       int accumulate, float p_drop, unsigned long long drop_key, float* colsum, void* stream_) {
+                       int accumulate, float p_drop, unsigned long long drop_key, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) return MV_E_ARG;
   if (!mv_dtype_ok(dtype) || !mv_dtype_ok(c_dtype)) return MV_E_DTYPE;
@@ -359,7 +347,7 @@ extern "C" int mv_gemm(int dtype, int ta, int tb, int M, int N, int K, const voi
   }
   if (splitk == 0 && (!mv_is16(dtype) || g_mv_impl != 0)) splitk = 1;   // auto split-K only on the MFMA kernels
   GemmArgs p;
-  p.A = A; p.B = B; p.C = C; p.C2 = C2; p.bias = bias; p.R = R; p.C3 = C3; p.colsum = colsum;
+  p.A = A; p.B = B; p.C = C; p.C2 = C2; p.bias = bias; p.R = R; p.C3 = C3;
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldc2 = ldc2; p.ldr = ldr; p.ldc3 = ldc3;
   p.c_dtype = c_dtype; p.r_dtype = r_dtype; p.c3_dtype = c3_dtype; p.epi = epi; p.accumulate = accumulate;
   p.splitk = splitk; p.ws = ws; p.dbg = g_mv_gemm_dbg;
@@ -376,8 +364,6 @@ extern "C" int mv_gemm(int dtype, int ta, int tb, int M, int N, int K, const voi
               ((epi != MV_EPI_BIAS_GELU && epi != MV_EPI_BIAS_GELU_D) || (((ldc2 & 7) == 0) && aligned_to(C2, 16))) && ((N & 3) == 0);
   const bool mfma = mv_is16(dtype) && (g_mv_impl == 0);
   const bool f16 = dtype == MV_F16;
-  // fused column sums: 128x128 MFMA kernel, vector epilogue on every column, no split-K
-  if (colsum && (!mfma || !p.vec_ok || (N & 3) || splitk > 1 || accumulate)) return MV_E_SHAPE;
   if (mfma && f16 && (ta || tb)) return MV_E_DTYPE;   // f16 operands exist for the forward form y = x.W^T only
   if (mfma) {
     if ((lda & 7) || (ldb & 7) || !aligned_to(A, 16) || !aligned_to(B, 16)) return MV_E_SHAPE;
@@ -395,8 +381,8 @@ extern "C" int mv_gemm(int dtype, int ta, int tb, int M, int N, int K, const voi
     // (ring kernel with 64-deep stages for wide outputs and for dW; 128x128 register-staged for N <= 1024 and dX)
     // (768-column outputs: the 128x128 kernel at three blocks per CU wins in every layout, also for long contractions)
     const bool wide_nt = !ta && !tb && N >= 1024;
-    const bool big = !colsum && ((g_mv_gemm_force == 2) || (g_mv_gemm_force == 0 && M >= 256 && N >= 128 && ((K & 7) == 0 || (ta && tb)) && (wide_nt || ta) &&
-                                               (t128 >= 128 || (K >= 4096 && splitk != 1))));
+    const bool big = (g_mv_gemm_force == 2) || (g_mv_gemm_force == 0 && M >= 256 && N >= 128 && ((K & 7) == 0 || (ta && tb)) && (wide_nt || ta) &&
+                                               (t128 >= 128 || (K >= 4096 && splitk != 1)));
     if (big) {
       long long sk = splitk;
       if (splitk > 1 || splitk == 0) {      // 0 = auto
@@ -438,7 +424,7 @@ extern "C" int mv_gemm(int dtype, int ta, int tb, int M, int N, int K, const voi
       if (splitk == 0) {
         const int tiles = ((M + GT_BM - 1) / GT_BM) * ((N + GT_BN - 1) / GT_BN);
         splitk = 1;
-        if (!colsum && tiles < 512 && K >= 2048 && ws && epi == MV_EPI_NONE && c_dtype == MV_F32) {
+        if (tiles < 512 && K >= 2048 && ws && epi == MV_EPI_NONE && c_dtype == MV_F32) {
           splitk = 768 / tiles; if (splitk > K / 1024) splitk = K / 1024; if (splitk > 16) splitk = 16; if (splitk < 1) splitk = 1;
           if (ws_bytes < (size_t)splitk * M * N * sizeof(float)) splitk = 1;
         }

@@ -10,7 +10,6 @@ struct GemmArgs {
                   // forward GEMM and the bf16 operand of the backward's weight-gradient GEMM from one accumulator tile
   int M, N, K, lda, ldb, ldc, ldc2, ldr, ldc3;
   int c_dtype, r_dtype, c3_dtype, epi, accumulate, vec_ok;
-  float* colsum;  // optional f32 [N]: colsum[n] += sum_m C[m,n] (atomics; the bias gradient of the layer that produced A), 128x128 kernel
   int vec8_ok;    // 16-bit C (and C2 / C3): 16-byte aligned bases and leading dimensions that are multiples of 8 -> 16-byte stores
   int kchunk, splitk;
   float* ws;
@@ -88,8 +87,8 @@ __device__ __forceinline__ f32x4 epi_load_res4(const GemmArgs& p, int m, int n) 
   return r;
 }
 template <int E>
-__device__ __forceinline__ f32x4 epilogue4v(const GemmArgs& p, int m, int n, f32x4 v, f32x4 b4, f32x4 r) {
-  if (m >= p.M) return (f32x4){0.f, 0.f, 0.f, 0.f};
+__device__ __forceinline__ void epilogue4v(const GemmArgs& p, int m, int n, f32x4 v, f32x4 b4, f32x4 r) {
+  if (m >= p.M) return;
   const size_t co = (size_t)m * p.ldc + n;
   f32x4 o = v;
   if (E == MV_EPI_BIAS || E == MV_EPI_BIAS_GELU || E == MV_EPI_BIAS_RES || E == MV_EPI_BIAS_TANH || E == MV_EPI_BIAS_GELU_D || E == MV_EPI_BIAS_RELU || E == MV_EPI_BIAS_RES_RELU) o += b4;
@@ -125,7 +124,6 @@ __device__ __forceinline__ f32x4 epilogue4v(const GemmArgs& p, int m, int n, f32
   }
   st4_any(p.C, co, p.c_dtype, o);
   if (p.C3) st4_any(p.C3, (size_t)m * p.ldc3 + n, p.c3_dtype, o);
-  return o;         // what was stored (before rounding to the output encoding): the column-sum fusion adds it up
 }
 
 // 8 consecutive columns of one row of a 16-bit output: ONE 16-byte store per output tensor instead of two 8-byte ones (the

@@ -149,11 +149,6 @@ class Engine:
         self._ws = {}
         self._gemm_ws = None
         self._side = None             # side HIP stream for the weight-gradient GEMMs of the backward
-        # bias gradients of the q/k/v and FFN-up projections from the producing kernels' epilogues (mv_gemm / mv_attn_bwd
-        # `colsum`) instead of separate column-sum kernels on the side stream.  Measured SLOWER at the bench shape (28.07 ->
-        # 29.82 ms/step, profiles/r02_gemm_variants.txt): ~1.2 M float atomics per GEMM land on 3,072 addresses, the contended
-        # regime of the memory-side atomic units.  Kept as an option, off.
-        self.fuse_colsum = False
         self.training = False         # dropout is active only when True (CXRBERT.train() / TrainStep(train=True))
         # dropout stream: keyed by torch's seed (set_seed of utils/utils.py:9-16 -> torch.manual_seed), a per-rank offset
         # added by TrainStep under data parallelism, and a counter advanced once per forward (every step draws fresh masks)
@@ -682,14 +677,10 @@ class Engine:
             fork()
             with torch.cuda.stream(side):
                 self._dW(dproj2, a_["i"], g[p + "output.dense.weight"], H, I, M, lda=H, ldb=I)
-            # dz = (dproj2.W2) * gelu'(z); its column sums (the bias gradient of intermediate.dense) come from the same tile epilogue
-            fuse_cs = self.dt == MV_BF16 and self.fuse_colsum
-            ops.gemm(dproj2, self.w[p + "output.dense.weight"], dz, tb=True, M=M, N=I, K=H, epi=EPI_MUL, r=a_["dgelu"],
-                     colsum=g[p + "intermediate.dense.bias"] if fuse_cs else None)
+            ops.gemm(dproj2, self.w[p + "output.dense.weight"], dz, tb=True, M=M, N=I, K=H, epi=EPI_MUL, r=a_["dgelu"])
             fork()
             with torch.cuda.stream(side):
-                if not fuse_cs:
-                    ops.colsum(dz, I, M, I, g[p + "intermediate.dense.bias"], accumulate=True)
+                ops.colsum(dz, I, M, I, g[p + "intermediate.dense.bias"], accumulate=True)
                 self._dW(dz, a_["a"], g[p + "intermediate.dense.weight"], I, H, M, lda=I, ldb=H)
             ops.gemm(dz, self.w[p + "intermediate.dense.weight"], da, tb=True, M=M, N=H, K=I, epi=EPI_RES, r=dpre2)
             # LN1 backward (+ bias grad of attention.output.dense)
@@ -710,14 +701,12 @@ class Engine:
             else:
                 ops.gemm(dproj1, self.w[p + "attention.output.dense.weight"], dctx, tb=True, M=M, N=H, K=H)
             M = M_all
-            # the q/k/v bias gradient (column sums of dqkv) comes out of the attention backward kernels' registers
             ops.attn_bwd(a_["qkv"], a_["ctx"], dctx, a_["lse"], S["bits"], S["tinfo"], dqkv, delta, B, Lq, A, dh, cu=S["cu"],
                          total_rows=M, p_drop=pd,
-                         drop_key=dk[(self.SITE_ATTN, l)], colsum=gbqkv if self.fuse_colsum else None)
+                         drop_key=dk[(self.SITE_ATTN, l)])
             fork()
             with torch.cuda.stream(side):
-                if not self.fuse_colsum:
-                    ops.colsum(dqkv, 3 * H, M, 3 * H, gbqkv, accumulate=True)
+                ops.colsum(dqkv, 3 * H, M, 3 * H, gbqkv, accumulate=True)
                 self._dW(dqkv, a_["x"], gWqkv, 3 * H, H, M, lda=3 * H, ldb=H)
                 ev_layer = side_done()
             dx = dxb[l & 1]          # never the buffer dy currently lives in

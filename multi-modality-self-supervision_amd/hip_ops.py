@@ -15,12 +15,10 @@ def _lib():
 
 
 def gemm(a, b, c, *, ta=False, tb=False, M, N, K, lda=None, ldb=None, ldc=None, bias=None, epi=EPI_NONE, r=None, ldr=None,
-         c2=None, ldc2=None, c3=None, ldc3=None, splitk=1, ws=None, accumulate=False, p_drop=0.0, drop_key=0, colsum=None):
+         c2=None, ldc2=None, c3=None, ldc3=None, splitk=1, ws=None, accumulate=False, p_drop=0.0, drop_key=0):
     """c[M,N] = epi(op(a)[M,K] . op(b)[K,N]); c3 (optional): the same result in a second 16-bit encoding; see mv_gemm in
     include/medvill.h."""
-    L.require_cuda(a, b, c, bias, r, c2, c3, ws, colsum)
-    if colsum is not None and (colsum.dtype != torch.float32 or colsum.numel() < N):
-        raise TypeError("colsum must be f32 [N]")
+    L.require_cuda(a, b, c, bias, r, c2, c3, ws)
     lda = lda if lda is not None else (M if ta else K)
     ldb = ldb if ldb is not None else (N if tb else K)
     ldc = ldc if ldc is not None else N
@@ -33,8 +31,8 @@ def gemm(a, b, c, *, ta=False, tb=False, M, N, K, lda=None, ldb=None, ldc=None, 
         raise TypeError("bias must be f32")
     rc = _lib().mv_gemm(L.dt_of(a), int(ta), int(tb), M, N, K, L.ptr(a), lda, L.ptr(b), ldb, L.ptr(c), ldc, L.dt_of(c),
                         L.ptr(bias), epi, L.ptr(r), ldr, L.dt_of(r) if r is not None else 0, L.ptr(c2), ldc2,
-                        L.ptr(c3), ldc3, L.dt_of(c3) if c3 is not None else 0, splitk, L.ptr(ws), (ws.numel() * 4) if ws is not None else 0,
-                        int(accumulate), float(p_drop), int(drop_key), L.ptr(colsum), L.stream_ptr())
+                        L.ptr(c3), ldc3, L.dt_of(c3) if c3 is not None else 0, splitk, L.ptr(ws), (ws.numel() * 4) if ws is not None else 0, int(accumulate), float(p_drop), int(drop_key),
+                        L.stream_ptr())
     L.check(rc, f"mv_gemm(M={M},N={N},K={K},ta={ta},tb={tb},epi={epi})")
     return c
 
@@ -122,13 +120,10 @@ def attn_fwd(qkv, bits, tileinfo, ctx, lse, B, Lq, A, dh, p_drop=0.0, drop_key=0
     L.check(rc, "mv_attn_fwd")
 
 
-def attn_bwd(qkv, ctx, dctx, lse, bits, tileinfo, dqkv, delta, B, Lq, A, dh, p_drop=0.0, drop_key=0, cu=None, total_rows=0,
-             colsum=None):
-    if colsum is not None and (colsum.dtype != torch.float32 or colsum.numel() < 3 * A * dh or not colsum.is_cuda):
-        raise TypeError("attn_bwd: colsum must be a device f32 [3H] tensor")
+def attn_bwd(qkv, ctx, dctx, lse, bits, tileinfo, dqkv, delta, B, Lq, A, dh, p_drop=0.0, drop_key=0, cu=None, total_rows=0):
     rc = _lib().mv_attn_bwd(L.dt_of(qkv), L.ptr(qkv), L.ptr(ctx), L.ptr(dctx), L.ptr(lse), L.ptr(bits), L.ptr(tileinfo),
                             L.ptr(dqkv), L.ptr(delta), B, Lq, A, dh, float(p_drop), int(drop_key), L.ptr(cu), int(total_rows),
-                            L.ptr(colsum), L.stream_ptr())
+                            L.stream_ptr())
     L.check(rc, "mv_attn_bwd")
 
 

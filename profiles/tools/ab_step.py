@@ -29,8 +29,6 @@ def timed(n=8):
 
 VARIANTS = {
     "pack": [("padded", lambda: setattr(step, "pack_rows", False)), ("packed", lambda: setattr(step, "pack_rows", True))],
-    "colsum": [("separate colsum kernels", lambda: setattr(model.engine, "fuse_colsum", False)),
-               ("fused column sums", lambda: setattr(model.engine, "fuse_colsum", True))],
     "tail": [("last layer on all rows", lambda: setattr(step, "tail_rows", False)), ("last layer on consumed rows", lambda: setattr(step, "tail_rows", True))],
 }
 which = sys.argv[1] if len(sys.argv) > 1 else "pack"
