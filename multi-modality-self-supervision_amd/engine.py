@@ -152,6 +152,7 @@ class Engine:
         self.training = False         # dropout is active only when True (CXRBERT.train() / TrainStep(train=True))
         # dropout stream: keyed by torch's seed (set_seed of utils/utils.py:9-16 -> torch.manual_seed), a per-rank offset
         # added by TrainStep under data parallelism, and a counter advanced once per forward (every step draws fresh masks)
+        self.dw_splitk = 0      # weight gradients: 0 = the library fills the chip with split-K slabs; n > 1 caps the slab count
         self.drop_seed = (torch.initial_seed() ^ 0x5DEECE66D) & 0xFFFFFFFFFFFFFFFF
         self.drop_counter = 0
         self._bind()
@@ -278,7 +279,7 @@ class Engine:
         # split-K is chosen by the library (splitk=0) from the tile grid; it needs room for up to 16 partial slabs
         auto = self.dt == MV_BF16 and Mtok >= 2048 and No * Ko <= 4 * 1024 * 1024
         ws = self._gemm_workspace(16 * No * Ko) if auto else None
-        ops.gemm(dy, x, gW, ta=True, tb=True, M=No, N=Ko, K=Mtok, lda=lda, ldb=ldb, ldc=ldc, splitk=0 if auto else 1, ws=ws)
+        ops.gemm(dy, x, gW, ta=True, tb=True, M=No, N=Ko, K=Mtok, lda=lda, ldb=ldb, ldc=ldc, splitk=self.dw_splitk if auto else 1, ws=ws)
 
     # ------------------------------------------------------------------ encoder forward
     def encoder_forward(self, cls_tok, input_txt, attn_mask, segment, img_feats, img_pos, sep_tok, pack=False, tail_rows=None):

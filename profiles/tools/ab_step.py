@@ -29,6 +29,10 @@ def timed(n=8):
 
 VARIANTS = {
     "pack": [("padded", lambda: setattr(step, "pack_rows", False)), ("packed", lambda: setattr(step, "pack_rows", True))],
+    "dwsplit": [("dW split-K auto (fills 256 CUs)", lambda: setattr(model.engine, "dw_splitk", 0)),
+                ("dW split-K <= 4", lambda: setattr(model.engine, "dw_splitk", 4)),
+                ("dW split-K <= 3", lambda: setattr(model.engine, "dw_splitk", 3)),
+                ("dW split-K <= 2", lambda: setattr(model.engine, "dw_splitk", 2))],
     "tail": [("last layer on all rows", lambda: setattr(step, "tail_rows", False)), ("last layer on consumed rows", lambda: setattr(step, "tail_rows", True))],
 }
 which = sys.argv[1] if len(sys.argv) > 1 else "pack"
@@ -42,4 +46,4 @@ for r in range(5):
         step(batches[0])
         res[n].append(timed())
 for n, v in res.items():
-    print(f"{n:24s} median {statistics.median(v):.2f} ms  (min {min(v):.2f}, max {max(v):.2f})")
+    print(f"{n:36s} median {statistics.median(v):.2f} ms  (min {min(v):.2f}, max {max(v):.2f})")
