@@ -19,7 +19,7 @@
  *   - every call takes the hipStream_t to enqueue on (as void*) and never synchronises.
  *   - return 0 = ok; negative = invalid argument / unsupported shape (MV_E_*);
  *     positive = hipError_t of a failed launch.  Nothing throws.
- *   - re-entrant, no global mutable state except mv_set_impl() (test hook).
+ *   - re-entrant, no global mutable state except the two test hooks mv_set_impl() / mv_set_gemm_variant().
  *   - dtype: MV_F32 = exact fp32 path (plain VALU kernels; parity at 1e-3 and below),
  *            MV_BF16 / MV_F16 = 16-bit storage, fp32 accumulate, MFMA kernels (the fast path).
  *   - matrices are row-major; "ld*" are leading dimensions in ELEMENTS.

@@ -11,7 +11,7 @@ import os
 import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libmedvill_hip.so")
+LIB_PATH = os.environ.get("MV_LIB_PATH") or os.path.join(HERE, "libmedvill_hip.so")   # MV_LIB_PATH: kernel-variant experiments
 
 MV_F32, MV_BF16, MV_F16 = 0, 1, 2
 EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RES, EPI_DGELU, EPI_RES, EPI_BIAS_TANH, EPI_BIAS_GELU_D, EPI_MUL, EPI_BIAS_RELU, EPI_BIAS_RES_RELU = range(11)

@@ -1,4 +1,5 @@
-// Library-level entry points (version / implementation selector).
+// Library-level entry points (version / implementation selector).  The two selectors (g_mv_impl here, the GEMM tile override in
+// mv_gemm.hip) are process-global TEST HOOKS -- the only mutable state of the library; nothing on the product path sets them.
 #include "mv_common.h"
 
 int g_mv_impl = 0;

@@ -201,8 +201,23 @@ __device__ __forceinline__ void tile_store(const u32x4 (&reg)[2], char* tile, in
 // applied to the per-lane SOURCE address; rows past `nrows` are zero-filled (out-of-range buffer offset).  No registers hold
 // the tile, so a ring of several stages can be in flight: the kernels below keep NS - 1 tiles ahead of the one they compute on
 // and retire them with counted `s_waitcnt vmcnt(N)` + one raw s_barrier per tile.
+// The LDS-DMA itself is issued from inline assembly.  Through the builtin the compiler tracks the transfer as a pending LDS
+// write and, having no alias information for `ds_read_b64_tr_b16`, puts `s_waitcnt vmcnt(0)` in front of the first transposed
+// fragment read of every tile -- the whole ring drained once per tile, so only the transfer issued last was ever ahead.  The
+// kernels below order the ring themselves (counted vmcnt + s_barrier before a stage is read, see att_wait_stage).
+typedef int dma_rsrc_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ dma_rsrc_t dma_rsrc(const void* p, unsigned bytes) {      // raw buffer, stride 0, `bytes` records
+  const unsigned long long v = (unsigned long long)(uintptr_t)p;
+  return (dma_rsrc_t){(int)(unsigned)v, (int)((unsigned)(v >> 32) & 0xffffu), (int)bytes, 0x00020000};
+}
+__device__ __forceinline__ void lds_dma16(dma_rsrc_t rs, MV_LDS void* dst, unsigned voff) {   // dst: wave-uniform, lane i lands at +16 i
+  asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"((unsigned)(uintptr_t)dst), "v"(voff), "s"(rs) : "memory");
+}
+__device__ __forceinline__ void lds_dma4(dma_rsrc_t rs, MV_LDS void* dst, unsigned voff) {
+  asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dword %1, %2, 0 offen lds" ::"s"((unsigned)(uintptr_t)dst), "v"(voff), "s"(rs) : "memory");
+}
 template <int NW>
-__device__ __forceinline__ void tile_dma(__amdgpu_buffer_rsrc_t rs, unsigned bytes, size_t rowbase, int row0, int nrows, int ld,
+__device__ __forceinline__ void tile_dma(dma_rsrc_t rs, unsigned bytes, size_t rowbase, int row0, int nrows, int ld,
                                          int col0, char* tile, int wid, int lane) {
 #pragma unroll
   for (int i = 0; i < 8 / NW; ++i) {
@@ -210,7 +225,7 @@ __device__ __forceinline__ void tile_dma(__amdgpu_buffer_rsrc_t rs, unsigned byt
     const int r = pc * 8 + (lane >> 3), ch = (lane & 7) ^ att_f(r);
     const bool ok = (row0 + r) < nrows;
     const unsigned off = (unsigned)(((rowbase + row0 + r) * (size_t)ld + col0 + ch * 8) * 2);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (MV_LDS void*)(tile + pc * 1024), 16, ok ? off : bytes, 0, 0, 0);
+    lds_dma16(rs, (MV_LDS void*)(tile + pc * 1024), ok ? off : bytes);
   }
 }
 template <int N> __device__ __forceinline__ void att_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -319,6 +334,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_mfma_kernel(AttnArgs a) {
   const size_t rowbase = a.cu ? (size_t)a.cu[b] : (size_t)b * L;
   const size_t lrow = (size_t)b * L;                            // logical row base (mask words)
   __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.qkv, 0, a.bytes_qkv, 0x00020000);
+  const dma_rsrc_t rsq = dma_rsrc(a.qkv, a.bytes_qkv);
 
   bf16x8 qf[4];
 #pragma unroll
@@ -338,8 +354,8 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_mfma_kernel(AttnArgs a) {
   int iss = cur, issued = 0, done = 0;
   auto issue = [&]() {
     char* st_ = smem + (issued % FWD_NS) * 16384;
-    tile_dma<4>(rs, a.bytes_qkv, rowbase, iss * 64, Lv, ld, H + head * 64, st_, wid, lane);
-    tile_dma<4>(rs, a.bytes_qkv, rowbase, iss * 64, Lv, ld, 2 * H + head * 64, st_ + 8192, wid, lane);
+    tile_dma<4>(rsq, a.bytes_qkv, rowbase, iss * 64, Lv, ld, H + head * 64, st_, wid, lane);
+    tile_dma<4>(rsq, a.bytes_qkv, rowbase, iss * 64, Lv, ld, 2 * H + head * 64, st_ + 8192, wid, lane);
     ++issued;
     iss = next_tile(tmk.need, iss, nkt);
   };
@@ -525,6 +541,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_mfma_kernel(AttnArgs a) {
   const size_t rowbase = a.cu ? (size_t)a.cu[b] : (size_t)b * L;
   const size_t lrow = (size_t)b * L;
   __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.qkv, 0, a.bytes_qkv, 0x00020000);
+  const dma_rsrc_t rsq = dma_rsrc(a.qkv, a.bytes_qkv);
   __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc((void*)a.dctx, 0, a.bytes_ctx, 0x00020000);
 
   bf16x8 qf[4], dof[4];
@@ -561,8 +578,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_mfma_kernel(AttnArgs a) {
   int iss = cur, issued = 0, done = 0;
   auto issue = [&]() {
     char* st_ = smem + (issued % DQ_NS) * 16384;
-    tile_dma<4>(rs, a.bytes_qkv, rowbase, iss * 64, Lv, ld, H + head * 64, st_, wid, lane);
-    tile_dma<4>(rs, a.bytes_qkv, rowbase, iss * 64, Lv, ld, 2 * H + head * 64, st_ + 8192, wid, lane);
+    tile_dma<4>(rsq, a.bytes_qkv, rowbase, iss * 64, Lv, ld, H + head * 64, st_, wid, lane);
+    tile_dma<4>(rsq, a.bytes_qkv, rowbase, iss * 64, Lv, ld, 2 * H + head * 64, st_ + 8192, wid, lane);
     ++issued;
     iss = next_tile(tmk.need, iss, nkt);
   };
@@ -686,6 +703,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_mfma_kernel(AttnArgs a) {
   const size_t rowbase = a.cu ? (size_t)a.cu[b] : (size_t)b * L;
   const size_t lrow = (size_t)b * L;
   __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.qkv, 0, a.bytes_qkv, 0x00020000);
+  const dma_rsrc_t rsq = dma_rsrc(a.qkv, a.bytes_qkv);
   __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc((void*)a.dctx, 0, a.bytes_ctx, 0x00020000);
 
   bf16x8 kf[4], vf[4];
@@ -706,27 +724,26 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_mfma_kernel(AttnArgs a) {
 
   // Q / dO tiles, their softmax statistics and this key block's mask words all arrive by LDS-DMA into a ring of DKV_NS
   // stages (rows past Lv are zero-filled: a zero dO row and a zero delta make that row contribute nothing to dK or dV)
-  __amdgpu_buffer_rsrc_t rsl = __builtin_amdgcn_make_buffer_rsrc((void*)a.lse_in, 0, a.bytes_stat, 0x00020000);
-  __amdgpu_buffer_rsrc_t rsdl = __builtin_amdgcn_make_buffer_rsrc((void*)a.delta, 0, a.bytes_stat, 0x00020000);
-  __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)a.bits, 0, a.bytes_bits, 0x00020000);
+  const dma_rsrc_t rsdo = dma_rsrc(a.dctx, a.bytes_ctx);
+  const dma_rsrc_t rsl = dma_rsrc(a.lse_in, a.bytes_stat), rsdl = dma_rsrc(a.delta, a.bytes_stat), rsw = dma_rsrc(a.bits, a.bytes_bits);
   const TileMasks tmk = load_tile_masks_k(a.info, b, T, ka, min(k0w >> 6, T - 1), lane);
   int cur = next_tile(tmk.need, -1, nqt);
   int iss = cur, issued = 0, done = 0;
   auto issue = [&]() {
     char* st_ = smem + (issued % DKV_NS) * KV_STAGE;
-    tile_dma<4>(rs, a.bytes_qkv, rowbase, iss * 64, Lv, ld, head * 64, st_, wid, lane);
-    tile_dma<4>(rsd, a.bytes_ctx, rowbase, iss * 64, Lv, H, head * 64, st_ + 8192, wid, lane);
+    tile_dma<4>(rsq, a.bytes_qkv, rowbase, iss * 64, Lv, ld, head * 64, st_, wid, lane);
+    tile_dma<4>(rsdo, a.bytes_ctx, rowbase, iss * 64, Lv, H, head * 64, st_ + 8192, wid, lane);
     {   // 64 rows x 4 mask words: 256 dwords, 64 per wave
       const int idx = wid * 64 + lane, qq = iss * 64 + (idx >> 2), wi = kw0 + (idx & 3);
       const bool ok = qq < Lv && wi < a.W;
       const unsigned off = (unsigned)(((lrow + qq) * (size_t)a.W + wi) * 4);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (MV_LDS void*)(st_ + 16384 + 512 + wid * 256), 4, ok ? off : a.bytes_bits, 0, 0, 0);
+      lds_dma4(rsw, (MV_LDS void*)(st_ + 16384 + 512 + wid * 256), ok ? off : a.bytes_bits);
     }
     {   // lse (even waves) / delta (odd waves) of the 64 query rows; issued by every wave so that the counted waits are uniform
       const int qi = iss * 64 + lane;
       const unsigned off = (unsigned)((sbase + qi) * 4);
-      if (wid & 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsdl, (MV_LDS void*)(st_ + 16384 + 256), 4, qi < Lv ? off : a.bytes_stat, 0, 0, 0);
-      else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsl, (MV_LDS void*)(st_ + 16384), 4, qi < Lv ? off : a.bytes_stat, 0, 0, 0);
+      if (wid & 1) lds_dma4(rsdl, (MV_LDS void*)(st_ + 16384 + 256), qi < Lv ? off : a.bytes_stat);
+      else lds_dma4(rsl, (MV_LDS void*)(st_ + 16384), qi < Lv ? off : a.bytes_stat);
     }
     ++issued;
     iss = next_tile(tmk.need, iss, nqt);

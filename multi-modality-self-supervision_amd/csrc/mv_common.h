@@ -85,45 +85,50 @@ __host__ __device__ __forceinline__ bool mv_is16(int dtype) { return dtype == MV
 __host__ __device__ __forceinline__ bool mv_dtype_ok(int dtype) { return dtype == MV_F32 || dtype == MV_BF16 || dtype == MV_F16; }
 
 // erf by Abramowitz-Stegun 7.1.26 (|abs error| <= 1.5e-7, i.e. fp32 rounding level): 1 rcp + 1 exp + 6 fma instead
-// of libdevice erff's ~40-instruction branchy polynomial.  The GELU epilogues run it 16384 times per 128x128 tile.
-__device__ __forceinline__ float fast_erf(float x) {
-  const float ax = fabsf(x);
-  const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
-  float p = fmaf(1.061405429f, t, -1.453152027f);
-  p = fmaf(p, t, 1.421413741f);
-  p = fmaf(p, t, -0.284496736f);
-  p = fmaf(p, t, 0.254829592f);
-  const float e = __expf(-ax * ax);
-  const float r = 1.0f - p * t * e;
-  return copysignf(r, x);
+// of libdevice erff's ~40-instruction branchy polynomial.  The GELU epilogues run it 65536 times per 256x256 tile, where
+// the arithmetic is what the epilogue costs (profiles/r02_gemm_variants.txt), so: the reciprocal is the bare v_rcp_f32
+// (1 ulp; `__frcp_rn` / `1.0f / x` compile to the 12-instruction IEEE division sequence), 1/sqrt2 and the 0.5 of the cdf are
+// folded into the constants, and the sign is handled by one select on 0.5 * erfc(|z| / sqrt2).
+#define MV_AS_P 0.3275911f
+#define MV_AS_A1 0.254829592f
+#define MV_AS_A2 -0.284496736f
+#define MV_AS_A3 1.421413741f
+#define MV_AS_A4 -1.453152027f
+#define MV_AS_A5 1.061405429f
+// h = 0.5 * erfc(|z| / sqrt2) = upper tail of the standard normal; e = exp(-z^2 / 2)
+__device__ __forceinline__ float mv_norm_tail(float z, float& e) {
+  const float t = __builtin_amdgcn_rcpf(fmaf(MV_AS_P * 0.70710678118654752440f, fabsf(z), 1.0f));
+  float p = fmaf(0.5f * MV_AS_A5, t, 0.5f * MV_AS_A4);
+  p = fmaf(p, t, 0.5f * MV_AS_A3);
+  p = fmaf(p, t, 0.5f * MV_AS_A2);
+  p = fmaf(p, t, 0.5f * MV_AS_A1);
+  e = __builtin_amdgcn_exp2f(z * z * -0.72134752044448170368f);      // exp(-z^2/2) = 2^(-z^2 * log2(e) / 2)
+  return p * t * e;
 }
-__device__ __forceinline__ float gelu_erf(float z) { return z * 0.5f * (1.0f + fast_erf(z * 0.70710678118654752440f)); }
-// d/dz [ z * Phi(z) ] = Phi(z) + z * phi(z).  The erf approximation's exp(-(z/sqrt2)^2) IS the Gaussian pdf's
-// exp(-z^2/2): one exponential and one reciprocal serve both terms.
+__device__ __forceinline__ float fast_erf(float x) {
+  float e;
+  const float h = mv_norm_tail(x * 1.41421356237309504880f, e);      // erf(x) = 1 - 2 * tail(x * sqrt2)
+  return copysignf(fmaf(-2.0f, h, 1.0f), x);
+}
+__device__ __forceinline__ float gelu_erf(float z) {
+  float e;
+  const float h = mv_norm_tail(z, e);
+  return z * (z >= 0.f ? 1.0f - h : h);
+}
+// d/dz [ z * Phi(z) ] = Phi(z) + z * phi(z).  The tail's exp(-z^2/2) IS the Gaussian pdf's: one exponential and one
+// reciprocal serve both terms.
 __device__ __forceinline__ float dgelu_erf(float z) {
-  const float u = z * 0.70710678118654752440f, au = fabsf(u);
-  const float t = __frcp_rn(fmaf(0.3275911f, au, 1.0f));
-  float p = fmaf(1.061405429f, t, -1.453152027f);
-  p = fmaf(p, t, 1.421413741f);
-  p = fmaf(p, t, -0.284496736f);
-  p = fmaf(p, t, 0.254829592f);
-  const float e = __expf(-au * au);
-  const float erf_abs = 1.0f - p * t * e;
-  const float cdf = 0.5f * (1.0f + copysignf(erf_abs, u));
+  float e;
+  const float h = mv_norm_tail(z, e);
+  const float cdf = z >= 0.f ? 1.0f - h : h;
   return fmaf(z * 0.39894228040143267794f, e, cdf);
 }
 
 // gelu(z) and gelu'(z) from one exponential and one reciprocal (forward epilogue MV_EPI_BIAS_GELU_D)
 __device__ __forceinline__ void gelu_erf_and_grad(float z, float& g, float& d) {
-  const float u = z * 0.70710678118654752440f, au = fabsf(u);
-  const float t = __frcp_rn(fmaf(0.3275911f, au, 1.0f));
-  float p = fmaf(1.061405429f, t, -1.453152027f);
-  p = fmaf(p, t, 1.421413741f);
-  p = fmaf(p, t, -0.284496736f);
-  p = fmaf(p, t, 0.254829592f);
-  const float e = __expf(-au * au);
-  const float erf_abs = 1.0f - p * t * e;
-  const float cdf = 0.5f * (1.0f + copysignf(erf_abs, u));
+  float e;
+  const float h = mv_norm_tail(z, e);
+  const float cdf = z >= 0.f ? 1.0f - h : h;
   g = z * cdf;
   d = fmaf(z * 0.39894228040143267794f, e, cdf);
 }

@@ -51,17 +51,21 @@ class _CXRBertFn(torch.autograd.Function):
         eng.training = model.training           # dropout (p = 0.1 at every site of the reference) only in train mode
         hidden, pooled = eng.encoder_forward(cls_tok, input_txt, attn_mask, segment, feats, pos, sep_tok)
         ctx.model, ctx.want_heads = model, want_heads
+        if want_heads == 2:                     # ITM head only (retrieval: `self.itm(cls)` on the pooled output)
+            return eng._itm_forward().clone()
         if want_heads:
             mlm, itm = eng.heads_full()
             return mlm, itm
         return hidden.clone(), pooled.clone()
 
     @staticmethod
-    def backward(ctx, g0, g1):
+    def backward(ctx, g0, g1=None):
         model = ctx.model
         eng = model.engine
         eng.zero_grad()
-        if ctx.want_heads:
+        if ctx.want_heads == 2:
+            eng.heads_full_backward(None, g0)
+        elif ctx.want_heads:
             eng.heads_full_backward(g0, g1)
         else:
             S, H = eng.S, eng.cfg.hidden
@@ -194,6 +198,10 @@ class CXRBERT(nn.Module):
 
     def forward(self, cls_tok, input_txt, attn_mask, segment, input_img, sep_tok):
         return self._run(True, cls_tok, input_txt, attn_mask, segment, input_img, sep_tok)
+
+    def _itm_only(self, cls_tok, input_txt, attn_mask, segment, input_img, sep_tok):
+        """ITM logits [B,2] of enc + itm without the MLM head (the retrieval model's forward), differentiable."""
+        return self._run(2, cls_tok, input_txt, attn_mask, segment, input_img, sep_tok)
 
     # ------------------------------------------------------------------ state dict (reference key names)
     def state_dict(self, *a, **k):

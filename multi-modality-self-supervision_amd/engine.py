@@ -550,7 +550,7 @@ class Engine:
         S, H, V = self.S, self.cfg.hidden, self.cfg.vocab_size
         M, B = S["M"], S["B"]
         Vp = (V + 7) // 8 * 8
-        self.S["hf_"]["Vp"] = Vp
+        self.S.setdefault("hf_", {})["Vp"] = Vp
         self.ensure_grad()
         dhid = S["dhidden"] = self._buf("dhidden", (M, H), self.adt)
         if dmlm is not None:

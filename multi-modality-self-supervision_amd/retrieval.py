@@ -25,9 +25,7 @@ class CXRBertForRetrieval(nn.Module):
 
     def forward(self, cls_tok, input_txt, attn_mask, segment, input_img, sep_tok):
         """-> ITM logits [B,2] (retrieval.py:26-31: `_, cls, _ = self.enc(...); return self.itm(cls)`)."""
-        _, pooled, _ = self.enc(cls_tok, input_txt, attn_mask, segment, input_img, sep_tok)
-        w, b = self.bert.get_parameter("itm.linear.weight"), self.bert.get_parameter("itm.linear.bias")
-        return torch.nn.functional.linear(pooled.float(), w, b)      # [B,H] x [H,2]: plumbing-sized
+        return self.bert._itm_only(cls_tok, input_txt, attn_mask, segment, input_img, sep_tok)
 
     @torch.no_grad()
     def score(self, cls_tok, input_txt, attn_mask, segment, input_img, sep_tok):
