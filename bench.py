@@ -275,9 +275,11 @@ def main():
             "config": {"workload": c["name"], "per_gpu_batch": B, "global_batch": B * world, "seq_len": L, "regions": N,
                        "mask": c["family"], "layers": cfg.layers, "hidden": cfg.hidden, "vocab": cfg.vocab_size,
                        "parallelism": f"dp{world}", "optimizer": "HF AdamW fused", "dropout": cfg.dropout,
-                       "precision": ("16-bit MFMA operands, fp32 accumulate / residual sums / statistics / optimizer; forward operands "
-                                     "f16-encoded, gradient-product operands bf16-encoded (BERT-base logits 3.5e-3 max-abs from the "
-                                     "reference; bf16-encoded forward operands give 2.6e-2: profiles/r02_bf16_error.txt)") if eng.dual
+                       "precision": ("16-bit MFMA operands, fp32 accumulate / statistics / master weights / optimizer; forward operands "
+                                     "f16-encoded, gradient-product operands bf16-encoded; encoder LayerNorm inputs (residual sums) stored "
+                                     + ("f16" if eng.ln_in_16 else "fp32") + " (BERT-base logits " + ("3.8-4.6e-3" if eng.ln_in_16 else "3.2-3.4e-3")
+                                     + " max-abs from the reference, tolerance 1e-2; bf16-encoded forward operands give 2.6e-2: "
+                                     "profiles/r02_bf16_error.txt)") if eng.dual
                        else "16-bit MFMA operands, all bf16-encoded",
                        "rows": (f"padding removed: encoder on the valid rows only (mean {rows_mean:.1f} of {L} positions per sample; "
                                 "results equal the padded run)") if packed else "padded",

@@ -228,6 +228,13 @@ __device__ __forceinline__ void tile_dma(dma_rsrc_t rs, unsigned bytes, size_t r
     lds_dma16(rs, (MV_LDS void*)(tile + pc * 1024), ok ? off : bytes);
   }
 }
+// Where a ring iteration requests the next tile: right after the barrier (0) or after its own tile body (1).  Inside a tile body
+// the compiler may wait for one of ITS memory operations -- a scratch reload of a spilled register (dK/dV kernel), the mask words
+// of a mixed-class tile (fwd, dQ) -- with vmcnt(0); vmcnt retires in order, so that wait also waits for every LDS-DMA issued
+// before it.  Issued late, the youngest transfer in flight at that point is a whole tile old instead of a few instructions.
+#ifndef ATT_ISSUE_LATE
+#define ATT_ISSUE_LATE 1
+#endif
 template <int N> __device__ __forceinline__ void att_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 // wait until at most `younger` stages (of PPW LDS-DMA instructions per wave each) are still in flight
 template <int PPW>
@@ -367,7 +374,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_mfma_kernel(AttnArgs a) {
     att_wait_stage<4>(issued - done - 1);           // this wave's pieces of tile `cur` have landed ...
     __builtin_amdgcn_s_barrier();                   // ... and everybody's; everybody is done reading the slot refilled next
     __builtin_amdgcn_sched_barrier(0);
-    if (iss < nkt) issue();
+    if (!ATT_ISSUE_LATE && iss < nkt) issue();
     const char* tK = smem + (done % FWD_NS) * 16384;
     const char* tV = tK + 8192;
     const int cls = !wave_on ? 0 : (((tmk.w_is1 >> cur) & 1) ? 1 : (((tmk.w_nz >> cur) & 1) ? 2 : 0));
@@ -450,6 +457,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_mfma_kernel(AttnArgs a) {
             o[dt] = mma32<F16>(frag_tr(tV, 32 * dt, 32 * kk + 16 * s2, lane), pf, o[dt]);
         }
     }
+    if (ATT_ISSUE_LATE && iss < nkt) issue();
     cur = next_tile(tmk.need, cur, nkt);
     ++done;
   }
@@ -591,7 +599,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_mfma_kernel(AttnArgs a) {
     att_wait_stage<4>(issued - done - 1);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    if (iss < nkt) issue();
+    if (!ATT_ISSUE_LATE && iss < nkt) issue();
     const char* tK = smem + (done % DQ_NS) * 16384;
     const char* tV = tK + 8192;
     const int cls = !wave_on ? 0 : (((tmk.w_is1 >> cur) & 1) ? 1 : (((tmk.w_nz >> cur) & 1) ? 2 : 0));
@@ -609,6 +617,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_mfma_kernel(AttnArgs a) {
         default: dq_tile<true, true, true>(a, tK, tV, qf, dof, dq, myw, q_ok, q, b, head, k0, Lv, lse2, dlt, c2, lane); break;
       }
     }
+    if (ATT_ISSUE_LATE && iss < nkt) issue();
     cur = next_tile(tmk.need, cur, nkt);
     ++done;
   }
@@ -755,7 +764,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_mfma_kernel(AttnArgs a) {
     att_wait_stage<6>(issued - done - 1);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    if (iss < nqt) issue();
+    if (!ATT_ISSUE_LATE && iss < nqt) issue();
     const char* st = smem + (done % DKV_NS) * KV_STAGE;
     const char* tQ = st;
     const char* tD = st + 8192;
@@ -772,6 +781,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_mfma_kernel(AttnArgs a) {
         default: dkv_tile<true, true>(a, tQ, tD, s_lse, s_dl, s_w, kf, vf, dk, dv, b, head, cur, key, wid, c2, lane); break;
       }
     }
+    if (ATT_ISSUE_LATE && iss < nqt) issue();
     cur = next_tile(tmk.need, cur, nqt);
     ++done;
   }

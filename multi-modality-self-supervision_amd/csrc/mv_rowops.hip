@@ -149,6 +149,7 @@ extern "C" int mv_layernorm_fwd(int dtype, const void* x, int x_dtype, const flo
   else if (dtype == MV_BF16 && x_dtype == MV_F32) { typedef float TX_; typedef bf16_t TY_; NC_DISPATCH(H, LNF); }
   else if (dtype == MV_BF16 && x_dtype == MV_BF16) { typedef bf16_t TX_; typedef bf16_t TY_; NC_DISPATCH(H, LNF); }
   else if (dtype == MV_F16 && x_dtype == MV_F32) { typedef float TX_; typedef f16_t TY_; NC_DISPATCH(H, LNF); }
+  else if (dtype == MV_F16 && x_dtype == MV_F16) { typedef f16_t TX_; typedef f16_t TY_; NC_DISPATCH(H, LNF); }
   else return MV_E_DTYPE;
 #undef LNF
   MV_CHECK_LAUNCH();
@@ -170,6 +171,7 @@ extern "C" int mv_layernorm_bwd(int dtype, const void* dy, const void* x, int x_
   if (dtype == MV_F32 && x_dtype == MV_F32) { typedef float TX_; typedef float TD_; NC_DISPATCH(H, LNB); }
   else if (dtype == MV_BF16 && x_dtype == MV_F32) { typedef float TX_; typedef bf16_t TD_; NC_DISPATCH(H, LNB); }
   else if (dtype == MV_BF16 && x_dtype == MV_BF16) { typedef bf16_t TX_; typedef bf16_t TD_; NC_DISPATCH(H, LNB); }
+  else if (dtype == MV_BF16 && x_dtype == MV_F16) { typedef f16_t TX_; typedef bf16_t TD_; NC_DISPATCH(H, LNB); }
   else return MV_E_DTYPE;
 #undef LNB
   MV_CHECK_LAUNCH();

@@ -22,6 +22,8 @@ from . import cxrbert_oracle as O
 from . import synth
 
 SITES = ("w", "tables", "feats", "imgproj", "x_op", "x_res", "qkv", "p", "ctx", "a_op", "a_res", "act", "head_x", "t", "decoder_w")
+# not a product rounding site (the LayerNorm inputs stay fp32); switchable to price storing them in 16 bits
+EXTRA_SITES = ("pre",)
 
 
 def bf(t):
@@ -82,11 +84,11 @@ def forward(P, cfg, b, R: Rounder):
         pr = torch.softmax(s, dim=-1)
         # the kernel rounds exp(s - m) to bf16 for the PV MFMA and divides by the UNROUNDED row sum afterwards
         c = R("ctx", torch.matmul(R("p", pr), v).permute(0, 2, 1, 3).reshape(B, L, H))
-        a = O.layer_norm(F.linear(c, W("attention.output.dense"), Bi("attention.output.dense")) + xr,
+        a = O.layer_norm(R("pre", F.linear(c, W("attention.output.dense"), Bi("attention.output.dense")) + xr),
                          P[p + "attention.output.LayerNorm.weight"], P[p + "attention.output.LayerNorm.bias"], cfg.ln_eps)
         ao, ar = R("a_op", a), R("a_res", a)
         i = R("act", O.gelu_erf(F.linear(ao, W("intermediate.dense"), Bi("intermediate.dense"))))
-        x = O.layer_norm(F.linear(i, W("output.dense"), Bi("output.dense")) + ar,
+        x = O.layer_norm(R("pre", F.linear(i, W("output.dense"), Bi("output.dense")) + ar),
                          P[p + "output.LayerNorm.weight"], P[p + "output.LayerNorm.bias"], cfg.ln_eps)
     pooled = torch.tanh(F.linear(R("x_op", x[:, 0]), R("w", P["enc.pooler.dense.weight"]), P["enc.pooler.dense.bias"]))
     t = O.gelu_erf(F.linear(R("head_x", x), R("w", P["mlm.predictions.transform.dense.weight"]),
@@ -138,6 +140,9 @@ def main(argv):
         run("encoder: weights split, activations bf16", allsites - {"x_res", "a_res"}, {"w", "decoder_w", "tables"})
         run("f16 forward operands, f16 residual operand (round-2 default)", (), (), allsites)
         run("f16 forward operands, fp32 residual operand", (), (), allsites - {"x_res", "a_res"})
+        if "pre" in argv:
+            run("f16 forward operands + f16 LayerNorm inputs (not adopted)", (), (), allsites | {"pre"})
+            run("only 'pre' in f16", (), (), {"pre"})
     print(f"logit std {float(ref.std()):.3f} abs-max {float(ref.abs().max()):.2f}")
 
 

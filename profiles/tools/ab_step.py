@@ -33,6 +33,8 @@ VARIANTS = {
                 ("dW split-K <= 4", lambda: setattr(model.engine, "dw_splitk", 4)),
                 ("dW split-K <= 3", lambda: setattr(model.engine, "dw_splitk", 3)),
                 ("dW split-K <= 2", lambda: setattr(model.engine, "dw_splitk", 2))],
+    "lnin": [("LayerNorm inputs fp32", lambda: setattr(model.engine, "ln_in_16", False)),
+             ("LayerNorm inputs f16", lambda: setattr(model.engine, "ln_in_16", True))],
     "tail": [("last layer on all rows", lambda: setattr(step, "tail_rows", False)), ("last layer on consumed rows", lambda: setattr(step, "tail_rows", True))],
 }
 which = sys.argv[1] if len(sys.argv) > 1 else "pack"
