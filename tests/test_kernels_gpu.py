@@ -283,6 +283,46 @@ def test_attention_fwd_bwd(impl, fam, B, A, N, S):
         ops.set_impl(0)
 
 
+@pytest.mark.parametrize("impl", ["mfma", "simple_bf16", "f32"])
+@pytest.mark.parametrize("fam,B,A,N,S", [("full", 2, 2, 16, 45), ("s2s", 2, 3, 36, 150), ("bar", 2, 2, 36, 221), ("full", 1, 12, 100, 409)])
+def test_attention_dropout_follows_the_mask_function(impl, fam, B, A, N, S):
+    """Attention-probability dropout (HF BertSelfAttention.dropout): forward and both backward kernels regenerate the mask that
+    mv_dropout_mask defines for this site -- checked by applying that mask in an fp64 restatement and differentiating it."""
+    dt = torch.float32 if impl == "f32" else torch.bfloat16
+    ops.set_impl(1 if impl == "simple_bf16" else 0)
+    try:
+        dh, Lq, key, p = 64, N + S + 3, 0x1234567, 0.1
+        H = A * dh
+        mask = _masks(fam, B, N, S).to(DEV)
+        qkv = rnd((B, Lq, 3 * H), dt, 41, 1.0)
+        dctx = rnd((B, Lq, H), dt, 42, 1.0)
+        bits = torch.zeros((B, Lq, (Lq + 31) // 32), dtype=torch.int32, device=DEV)
+        tinfo = torch.zeros((B, (Lq + 63) // 64, (Lq + 63) // 64), dtype=torch.uint8, device=DEV)
+        ops.mask_pack(mask, bits, tinfo)
+        Lp = (Lq + 3) // 4 * 4                     # mask index ((b*A + h)*L + q)*Lp + k (include/medvill.h, mv_attn_fwd)
+        keep, sc = ops.dropout_mask(p, key, B * A * Lq * Lp, DEV)
+        keep = keep.view(B, A, Lq, Lp)[..., :Lq].double()
+        frac = float(keep.mean())
+        assert abs(frac - (1 - 26 / 256)) < 4 * math.sqrt(0.1 * 0.9 / keep.numel()) + 1e-3 and sc == pytest.approx(256 / 230)
+        ctx = torch.zeros((B, Lq, H), dtype=dt, device=DEV)
+        lse = torch.zeros((B, A, Lq), dtype=torch.float32, device=DEV)
+        ops.attn_fwd(qkv.view(B * Lq, 3 * H), bits, tinfo, ctx, lse, B, Lq, A, dh, p_drop=p, drop_key=key)
+        qd = qkv.double().requires_grad_(True)
+        q, k, v = [t.view(B, Lq, A, dh).permute(0, 2, 1, 3) for t in qd.split(H, dim=-1)]
+        add = (1.0 - (mask if mask.dim() == 3 else mask[:, None, :].expand(B, Lq, Lq)).double()) * -10000.0
+        pr = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(dh) + add[:, None], -1) * keep * sc
+        rctx = (pr @ v).permute(0, 2, 1, 3).reshape(B, Lq, H)
+        tol = 1e-5 if impl == "f32" else 2e-2
+        assert relerr(ctx, rctx) < tol
+        dqkv = torch.zeros((B, Lq, 3 * H), dtype=dt, device=DEV)
+        delta = torch.zeros((B, A, Lq), dtype=torch.float32, device=DEV)
+        ops.attn_bwd(qkv.view(B * Lq, 3 * H), ctx, dctx, lse, bits, tinfo, dqkv, delta, B, Lq, A, dh, p_drop=p, drop_key=key)
+        (rctx * dctx.double()).sum().backward()
+        assert relerr(dqkv, qd.grad) < (1e-5 if impl == "f32" else 2.5e-2)
+    finally:
+        ops.set_impl(0)
+
+
 def test_mask_pack_bits_and_tile_classes():
     B, N, S = 3, 36, 120
     Lq = N + S + 3
