@@ -105,3 +105,37 @@ def test_replicas_with_different_parameters_are_refused():
     out = mgr.dict()
     mp.spawn(_bad_seed_worker, args=(world, _free_port(), out), nprocs=world, join=True)
     assert all("different parameters" in out[r] for r in range(world)), dict(out)
+
+
+def _rccl_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    import medvill_amd as mv
+    cfg = mv.ModelConfig(vocab_size=2048, hidden=128, layers=3, heads=2, intermediate=512, max_pos=128)
+    m = mv.CXRBERT(cfg, None, dtype=torch.bfloat16, device=f"cuda:{rank}")
+    m.reset_parameters(seed=11)
+    m.train()
+    full = mv.data.synthetic_batch(cfg.vocab_size, 8, 6, 40, "mixed", seed=5, device=f"cuda:{rank}")
+    sl = slice(rank * 4, rank * 4 + 4)
+    half = {k: v[sl] for k, v in full.items() if k not in ("label_rows", "label_ids")}
+    ts = mv.TrainStep(m, lr=1e-3, distributed=True)
+    for _ in range(3):
+        stats = ts(half, train=True)
+    torch.cuda.synchronize()
+    out[rank] = (m.engine.flat_p.cpu(), stats.cpu(), float(ts.exchange_exposed_ms()))
+    dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one device per rank: runs on nodes with >= 2 GPUs")
+def test_two_rank_step_over_rccl():
+    """The same two-rank step over the nccl backend (= RCCL over xGMI), one device per rank, bf16 path, dropout on, packed rows,
+    bucketed gradient all-reduce on the side stream: replicas must stay bit-identical and finite."""
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_rccl_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    assert torch.equal(out[0][0], out[1][0]) and bool(torch.isfinite(out[0][0]).all())
+    assert float(out[0][1][1]) > 0
