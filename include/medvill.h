@@ -274,7 +274,7 @@ int mv_cast2d(const void* src, int src_dtype, long long lds, void* dst, int dst_
               int rows, int cols, void* stream);
 
 /* dst[c, r] = src[r, c] for r < rows, c < cols (leading dimensions lds >= cols, ldd >= rows; same dtype both sides).
- * Utility (the training engine needs no transposed copies: every GEMM form reads the weights as stored). */
+ * Utility (the training engine keeps one transposed copy per layer: the FFN-down weights, for dz as an NT-form GEMM). */
 int mv_transpose(int dtype, const void* src, long long lds, void* dst, long long ldd, int rows, int cols, void* stream);
 
 /* dst(dst_dtype) = src(src_dtype), n elements */

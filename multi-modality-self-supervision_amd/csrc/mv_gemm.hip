@@ -359,6 +359,7 @@ extern "C" int mv_gemm(int dtype, int ta, int tb, int M, int N, int K, const voi
              (!need_bias || aligned_to(bias, 16)) &&
              (!need_r || (((ldr & 3) == 0) && aligned_to(R, rsz))) &&
              ((epi != MV_EPI_BIAS_GELU && epi != MV_EPI_BIAS_GELU_D) || (((ldc2 & 3) == 0) && aligned_to(C2, csz)));
+  p.r8_ok = need_r && mv_is16(r_dtype) && ((ldr & 7) == 0) && aligned_to(R, 16);
   p.vec8_ok = mv_is16(c_dtype) && ((ldc & 7) == 0) && aligned_to(C, 16) && (!need_bias || aligned_to(bias, 16)) &&
               (!C3 || (((ldc3 & 7) == 0) && aligned_to(C3, 16))) &&
               ((epi != MV_EPI_BIAS_GELU && epi != MV_EPI_BIAS_GELU_D) || (((ldc2 & 7) == 0) && aligned_to(C2, 16))) && ((N & 3) == 0);

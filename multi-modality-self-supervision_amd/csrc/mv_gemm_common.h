@@ -11,6 +11,7 @@ struct GemmArgs {
   int M, N, K, lda, ldb, ldc, ldc2, ldr, ldc3;
   int c_dtype, r_dtype, c3_dtype, epi, accumulate, vec_ok;
   int vec8_ok;    // 16-bit C (and C2 / C3): 16-byte aligned bases and leading dimensions that are multiples of 8 -> 16-byte stores
+  int r8_ok;      // the elementwise operand R likewise: 16-bit, 16-byte aligned, ldr a multiple of 8 -> 16-byte loads
   int kchunk, splitk;
   float* ws;
   unsigned bytesA, bytesB;
@@ -142,10 +143,33 @@ __device__ __forceinline__ void st8_16(void* base, size_t i, int dtype, const fl
     *(f16x8*)((f16_t*)base + i) = r;
   }
 }
+// 8 consecutive 16-bit elements of the elementwise operand, as raw bits (zeros past the last row); decoded at the point of use
+__device__ __forceinline__ u32x4 ld8_raw(const GemmArgs& p, int m, int n) {
+  if (m >= p.M) return (u32x4){0u, 0u, 0u, 0u};
+  return *(const u32x4*)((const char*)p.R + ((size_t)m * p.ldr + n) * 2);
+}
+__device__ __forceinline__ void dec8_16(u32x4 raw, int dtype, float (&r)[8]) {
+  if (dtype == MV_BF16) {
+    const bf16x8 v = __builtin_bit_cast(bf16x8, raw);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) r[e] = (float)v[e];
+  } else {
+    const f16x8 v = __builtin_bit_cast(f16x8, raw);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) r[e] = (float)v[e];
+  }
+}
 template <int E>
-__device__ __forceinline__ void epilogue8_16(const GemmArgs& p, int m, int n, f32x4 v0, f32x4 v1, f32x4 b0, f32x4 b1) {
+__device__ __forceinline__ void epilogue8_16(const GemmArgs& p, int m, int n, f32x4 v0, f32x4 v1, f32x4 b0, f32x4 b1,
+                                             u32x4 rraw = (u32x4){0u, 0u, 0u, 0u}) {
   if (m >= p.M) return;
   float o[8] = {v0[0] + b0[0], v0[1] + b0[1], v0[2] + b0[2], v0[3] + b0[3], v1[0] + b1[0], v1[1] + b1[1], v1[2] + b1[2], v1[3] + b1[3]};
+  if (E == MV_EPI_MUL || E == MV_EPI_RES) {
+    float r[8];
+    dec8_16(rraw, p.r_dtype, r);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (E == MV_EPI_MUL) ? o[e] * r[e] : o[e] + r[e];
+  }
   if (E == MV_EPI_BIAS_GELU_D) {
     float dd[8];
 #pragma unroll
@@ -281,19 +305,32 @@ __device__ __forceinline__ bf16x8 g2_frag(const char* tile, int base, int l15, i
     constexpr int EE = (E_) < 0 ? 0 : (E_);                                                                    \
     constexpr bool HAS_R = (E_) == MV_EPI_BIAS_RES || (E_) == MV_EPI_RES || (E_) == MV_EPI_MUL || (E_) == MV_EPI_DGELU || (E_) == MV_EPI_BIAS_RES_RELU; \
     constexpr bool WIDE_E = (E_) == MV_EPI_NONE || (E_) == MV_EPI_BIAS || (E_) == MV_EPI_BIAS_GELU_D;          \
-    if (WIDE_E && NJ == 4 && p.vec8_ok && p.c_dtype != MV_F32 && !p.accumulate && n0 + wn + 64 <= p.N) {       \
+    constexpr bool WIDE_R = (E_) == MV_EPI_MUL || (E_) == MV_EPI_RES;      /* 16-bit elementwise operand, 16-byte loads */ \
+    if ((WIDE_E || (WIDE_R && p.r8_ok)) && NJ == 4 && p.vec8_ok && p.c_dtype != MV_F32 && !p.accumulate && n0 + wn + 64 <= p.N) { \
       /* 16-bit outputs, 64 whole columns: a lane owns 8 consecutive columns of a row (8 lanes per row, 8 rows per pass) */ \
       const int r8 = lane >> 3, c8 = lane & 7;                                                                 \
       const int ncol8 = n0 + wn + c8 * 8;                                                                      \
       f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;                                                                \
-      if ((E_) != MV_EPI_NONE) { b0 = *(const f32x4*)(p.bias + ncol8); b1 = *(const f32x4*)(p.bias + ncol8 + 4); } \
+      if (WIDE_E && (E_) != MV_EPI_NONE) { b0 = *(const f32x4*)(p.bias + ncol8); b1 = *(const f32x4*)(p.bias + ncol8 + 4); } \
+      /* the elementwise operand's rows are requested two 16-row groups ahead of their use (4 x 16 bytes per lane in flight) */ \
+      u32x4 rq[2][2];                                                                                          \
+      if (WIDE_R) {                                                                                            \
+        _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                          \
+          _Pragma("unroll") for (int rr = 0; rr < 2; ++rr) rq[t][rr] = ld8_raw(p, m0 + wm + t * 16 + rr * 8 + r8, ncol8); \
+      }                                                                                                        \
       _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                          \
         _Pragma("unroll") for (int j = 0; j < NJ; ++j) *(f32x4*)(scr + l15 * 272 + j * 64 + lq * 16) = acc[i][j]; \
         _Pragma("unroll") for (int rr = 0; rr < 2; ++rr) {                                                     \
           const int row = rr * 8 + r8;                                                                         \
           const f32x4 v0 = *(const f32x4*)(scr + row * 272 + c8 * 32);                                         \
           const f32x4 v1 = *(const f32x4*)(scr + row * 272 + c8 * 32 + 16);                                    \
-          epilogue8_16<EE>(p, m0 + wm + i * 16 + row, ncol8, v0, v1, b0, b1);                                  \
+          if (WIDE_R) {                                                                                        \
+            const u32x4 rcur = rq[i & 1][rr];                                                                  \
+            if (i + 2 < 8) rq[i & 1][rr] = ld8_raw(p, m0 + wm + (i + 2) * 16 + row, ncol8);                    \
+            epilogue8_16<EE>(p, m0 + wm + i * 16 + row, ncol8, v0, v1, b0, b1, rcur);                          \
+          } else {                                                                                             \
+            epilogue8_16<EE>(p, m0 + wm + i * 16 + row, ncol8, v0, v1, b0, b1);                                \
+          }                                                                                                    \
         }                                                                                                      \
       }                                                                                                        \
     } else {                                                                                                   \

@@ -156,6 +156,12 @@ class Engine:
         # and read by LayerNorm forward and backward) are stored in f16 instead of fp32: -0.47 ms/step; BERT-base logits
         # 3.2-3.4e-3 -> 3.8-4.6e-3 max-abs from the reference (tolerance 1e-2; profiles/r02_bf16_error.txt).  MV_LN_IN_16=0: fp32.
         self.ln_in_16 = os.environ.get("MV_LN_IN_16", "1") != "0"
+        # dz = dproj2 . W2 (the widest input-gradient GEMM) as y = x . (W2^T)^T over a transposed bf16 copy of the FFN-down weights:
+        # the 256-row LDS-DMA kernel in its row-major form is the fastest GEMM of the library and the contraction-major form on
+        # 128x128 tiles is fill-bound (profiles/r02_gemm_variants.txt).  The copies (12 x 4.7 MB) are refreshed behind the
+        # optimizer step on the side stream.
+        self.dz_nt = os.environ.get("MV_DZ_NT", "1") != "0"
+        self._w2t, self._w2t_ev, self._w2t_stale = None, None, True
         self.dw_splitk = 0      # weight gradients: 0 = the library fills the chip with split-K slabs; n > 1 caps the slab count
         self.drop_seed = (torch.initial_seed() ^ 0x5DEECE66D) & 0xFFFFFFFFFFFFFFFF
         self.drop_counter = 0
@@ -211,6 +217,28 @@ class Engine:
         if self.dual:
             ops.cast(self.flat_p, self.shadow_f, self.n_flat)
         self.shadow_dirty = False
+        self._w2t_stale = True
+
+    def refresh_w2t(self, on_side=True):
+        """Transposed bf16 copies of the FFN-down weights ([I, H] each) for the NT form of dz; enqueued on the side stream (idle
+        outside the backward) so that the main stream only waits for an event at its first dz."""
+        if not (self.dz_nt and self.dt == MV_BF16):
+            return
+        cfg = self.cfg
+        H, I = cfg.hidden, cfg.intermediate
+        if self._w2t is None:
+            self._w2t = [torch.empty((I, H), dtype=self.adt, device=self.device) for _ in range(cfg.layers)]
+        main = torch.cuda.current_stream()
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        side = self._side if (on_side and os.environ.get("MV_SINGLE_STREAM") != "1") else main
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            for l in range(cfg.layers):
+                ops.transpose(self.w[f"enc.encoder.layer.{l}.output.dense.weight"], self._w2t[l], H, I)
+            self._w2t_ev = torch.cuda.Event()
+            self._w2t_ev.record(side)
+        self._w2t_stale = False
 
     def zero_grad(self):
         self.ensure_grad()
@@ -655,6 +683,11 @@ class Engine:
 
         if bucket_hook:
             bucket_hook("heads", None)
+        use_w2t = self.dz_nt and self.dt == MV_BF16
+        if use_w2t:
+            if self._w2t_stale or self._w2t is None:
+                self.refresh_w2t(on_side=False)
+            main.wait_event(self._w2t_ev)
         pd, dk = S["p_drop"], S["drop_keys"]
         dctx = self._buf("bw_dctx", (M, H), adt)
         delta = self._buf("bw_delta", (B, A, Lq), torch.float32)
@@ -683,7 +716,10 @@ class Engine:
             fork()
             with torch.cuda.stream(side):
                 self._dW(dproj2, a_["i"], g[p + "output.dense.weight"], H, I, M, lda=H, ldb=I)
-            ops.gemm(dproj2, self.w[p + "output.dense.weight"], dz, tb=True, M=M, N=I, K=H, epi=EPI_MUL, r=a_["dgelu"])
+            if use_w2t:
+                ops.gemm(dproj2, self._w2t[l], dz, M=M, N=I, K=H, epi=EPI_MUL, r=a_["dgelu"])
+            else:
+                ops.gemm(dproj2, self.w[p + "output.dense.weight"], dz, tb=True, M=M, N=I, K=H, epi=EPI_MUL, r=a_["dgelu"])
             fork()
             with torch.cuda.stream(side):
                 ops.colsum(dz, I, M, I, g[p + "intermediate.dense.bias"], accumulate=True)
@@ -747,3 +783,4 @@ class Engine:
         ops.adamw_step(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.shadow, self.n_flat, lr, betas[0], betas[1], eps,
                        weight_decay, step, correct_bias, grad_scale, shadow_f16=self.shadow_f)
         self.shadow_dirty = False
+        self.refresh_w2t()

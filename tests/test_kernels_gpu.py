@@ -74,6 +74,29 @@ def test_gemm_layouts(impl, ta, tb, M, N, K):
         ops.set_gemm_variant(0, 0)
 
 
+@pytest.mark.parametrize("impl", ["mfma", "mfma256k64", "pring256"])
+@pytest.mark.parametrize("epi", [EPI_MUL, EPI_RES])
+@pytest.mark.parametrize("rdt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("tb", [False, True])
+@pytest.mark.parametrize("M,N,K", [(300, 512, 192), (513, 3072, 768)])
+def test_gemm_elementwise_operand_16_byte_path(impl, epi, rdt, tb, M, N, K):
+    """C = (A.B) * R and C = A.B + R with a 16-bit R and a 16-bit C: the 256-row kernels read R in 16-byte pieces (8 columns per
+    lane, requested two 16-row groups ahead); ragged last row tile, R in either encoding, both weight layouts (dz = dy.W2 is
+    the NN form, its NT form runs over a transposed weight copy)."""
+    a = rnd((M, K), torch.bfloat16, 3, 0.5)
+    b = rnd((K, N) if tb else (N, K), torch.bfloat16, 4, 0.5)
+    r = rnd((M, N), rdt, 6)
+    c = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+    ops.set_gemm_variant(*VARIANT.get(impl, (0, 0)))
+    try:
+        ops.gemm(a, b, c, tb=tb, M=M, N=N, K=K, epi=epi, r=r)
+    finally:
+        ops.set_gemm_variant(0, 0)
+    y = a.double() @ (b.double() if tb else b.double().t())
+    ref = y * r.double() if epi == EPI_MUL else y + r.double()
+    assert torch.isfinite(c.float()).all() and relerr(c, ref) < 1e-2
+
+
 @pytest.mark.parametrize("impl", ["mfma", "mfma2s", "mfma256k64", "pring256", "f32"])
 @pytest.mark.parametrize("epi", [EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RES, EPI_DGELU, EPI_RES, EPI_BIAS_TANH, EPI_BIAS_GELU_D, EPI_MUL])
 @pytest.mark.parametrize("M,N,K,cdt", [(256, 384, 128, "bf16"), (200, 130, 72, "f32"), (128, 768, 768, "f32")])
