@@ -5,7 +5,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from medvill_amd import hip_ops as ops
-from medvill_amd._lib import EPI_MUL, EPI_NONE, EPI_RES
+from medvill_amd._lib import EPI_BIAS_RES, EPI_MUL, EPI_NONE, EPI_RES
 dev = "cuda"
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 25483
 H, I = 768, 3072
@@ -33,12 +33,24 @@ dz = torch.empty(M, I, device=dev, dtype=b16)
 dzi = (torch.randn(M, I, device=dev) * 0.5).to(b16)
 W1 = (torch.randn(I, H, device=dev) * 0.05).to(b16)          # da = dz . W1 : [M,3072] x [3072,768]
 da = torch.empty(M, H, device=dev, dtype=b16)
+dq3 = (torch.randn(M, 3 * H, device=dev) * 0.5).to(b16)
+Wq = (torch.randn(3 * H, H, device=dev) * 0.05).to(b16)
+xi16 = (torch.randn(M, I, device=dev) * 0.5).to(f16)
+W2f = (torch.randn(H, I, device=dev) * 0.05).to(f16)
+a16 = (torch.randn(M, H, device=dev) * 0.5).to(f16)
+pre16 = torch.empty(M, H, device=dev, dtype=f16)
+bh = torch.randn(H, device=dev)
 cases = [
     ("dz NN  (W2 as stored)  no epilogue", lambda: ops.gemm(dy, W2, dz, tb=True, M=M, N=I, K=H), 2.0 * M * I * H),
     ("dz NN  (W2 as stored)  x gelu'", lambda: ops.gemm(dy, W2, dz, tb=True, M=M, N=I, K=H, epi=EPI_MUL, r=gd), 2.0 * M * I * H),
     ("dz NT  (W2^T copy)     no epilogue", lambda: ops.gemm(dy, W2t, dz, M=M, N=I, K=H), 2.0 * M * I * H),
     ("dz NT  (W2^T copy)     x gelu'", lambda: ops.gemm(dy, W2t, dz, M=M, N=I, K=H, epi=EPI_MUL, r=gd), 2.0 * M * I * H),
     ("da NN  (W1 as stored)  + residual", lambda: ops.gemm(dzi, W1, da, tb=True, M=M, N=H, K=I, epi=EPI_RES, r=dy), 2.0 * M * I * H),
+    ("da NN  (W1 as stored)  no epilogue", lambda: ops.gemm(dzi, W1, da, tb=True, M=M, N=H, K=I), 2.0 * M * I * H),
+    ("dx NN  (Wqkv)          + residual", lambda: ops.gemm(dq3, Wq, da, tb=True, M=M, N=H, K=3 * H, epi=EPI_RES, r=dy), 2.0 * M * 3 * H * H),
+    ("dx NN  (Wqkv)          no epilogue", lambda: ops.gemm(dq3, Wq, da, tb=True, M=M, N=H, K=3 * H), 2.0 * M * 3 * H * H),
+    ("ffn2 NT f16 bias+res+drop -> f16", lambda: ops.gemm(xi16, W2f, pre16, M=M, N=H, K=I, bias=bh, epi=EPI_BIAS_RES, r=a16, p_drop=0.1, drop_key=7), 2.0 * M * I * H),
+    ("ffn2 NT f16 no epilogue   -> f16", lambda: ops.gemm(xi16, W2f, pre16, M=M, N=H, K=I), 2.0 * M * I * H),
 ]
 for name, fn, fl in cases:
     out = []
