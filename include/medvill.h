@@ -95,7 +95,7 @@ void mv_set_gemm_variant(int force, int nj);
  * 16-bit operands need 16-byte aligned bases and lda, ldb multiples of 8; a contraction length
  * K that is not a multiple of 8 is allowed only when the k-contiguous operand's rows are
  * zero-padded up to the next multiple of 8.
- * splitk = 0: let the library pick (needs ws for up to 16 slices, else 1 is used).
+ * splitk = 0: let the library pick (up to 32 slices, as many as ws holds; without ws 1 is used).
  * splitk > 1: the K range is cut in `splitk` slices whose partial tiles go to `ws`
  * (>= splitk*M*N floats) and are summed by a second kernel; only with MV_EPI_NONE and an f32 C.
  * accumulate != 0: C += result (f32 C, MV_EPI_NONE only).

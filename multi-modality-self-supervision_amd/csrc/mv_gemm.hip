@@ -389,9 +389,11 @@ extern "C" int mv_gemm(int dtype, int ta, int tb, int M, int N, int K, const voi
       if (splitk > 1 || splitk == 0) {      // 0 = auto
         const long long tiles = t256;
         sk = 1;
-        if (tiles < 256 && K >= 2048) { sk = 256 / tiles; if (sk > K / 1024) sk = K / 1024; if (sk > 16) sk = 16; if (sk < 1) sk = 1; }
+        // enough slabs to give every CU a unit, each at least 1024 deep; at most 32 and as many as the workspace holds
+        if (tiles < 256 && K >= 2048) { sk = 256 / tiles; if (sk > K / 1024) sk = K / 1024; if (sk > 32) sk = 32; if (sk < 1) sk = 1; }
         if (splitk > 1 && sk > splitk) sk = splitk;
-        if (sk > 1 && (!ws || ws_bytes < (size_t)sk * M * N * sizeof(float) || epi != MV_EPI_NONE || c_dtype != MV_F32)) sk = 1;
+        if (sk > 1 && ws) { const long long fit = (long long)(ws_bytes / ((size_t)M * N * sizeof(float))); if (sk > fit) sk = fit < 1 ? 1 : fit; }
+        if (sk > 1 && (!ws || epi != MV_EPI_NONE || c_dtype != MV_F32)) sk = 1;
       }
       // cost ~ rounds x tile width (1 block / CU for the 8-wave tiles, 2 blocks / CU for 256x128)
       const long long r256 = (t256 * sk + 255) / 256 * 256, r192 = (t192 * sk + 255) / 256 * 192,

@@ -308,9 +308,10 @@ class Engine:
 
     # dW[No,Ko] = dy[Mtok,No]^T . x[Mtok,Ko]  (contraction over tokens; split-K when the tile grid is small)
     def _dW(self, dy, x, gW, No, Ko, Mtok, lda, ldb, ldc=None):
-        # split-K is chosen by the library (splitk=0) from the tile grid; it needs room for up to 16 partial slabs
+        # split-K is chosen by the library (splitk=0) from the tile grid and the workspace: up to 32 partial slabs for the small
+        # [H, H] gradients (9 tiles of 256x256 need ~24 slabs to occupy the chip), 16 for the large ones
         auto = self.dt == MV_BF16 and Mtok >= 2048 and No * Ko <= 4 * 1024 * 1024
-        ws = self._gemm_workspace(16 * No * Ko) if auto else None
+        ws = self._gemm_workspace((32 if No * Ko <= 1024 * 1024 else 16) * No * Ko) if auto else None
         ops.gemm(dy, x, gW, ta=True, tb=True, M=No, N=Ko, K=Mtok, lda=lda, ldb=ldb, ldc=ldc, splitk=self.dw_splitk if auto else 1, ws=ws)
 
     # ------------------------------------------------------------------ encoder forward

@@ -37,6 +37,8 @@ VARIANTS = {
              ("LayerNorm inputs f16", lambda: setattr(model.engine, "ln_in_16", True))],
     "dznt": [("dz on the 128x128 kernel over W2 as stored", lambda: setattr(model.engine, "dz_nt", False)),
              ("dz on the 256-row kernel over a W2^T copy", lambda: setattr(model.engine, "dz_nt", True))],
+    "dwo": [("small dW: at most 16 split-K slabs", lambda: setattr(model.engine, "dw_splitk", 16)),
+            ("small dW: up to 32 slabs (auto)", lambda: setattr(model.engine, "dw_splitk", 0))],
     "tail": [("last layer on all rows", lambda: setattr(step, "tail_rows", False)), ("last layer on consumed rows", lambda: setattr(step, "tail_rows", True))],
 }
 which = sys.argv[1] if len(sys.argv) > 1 else "pack"
