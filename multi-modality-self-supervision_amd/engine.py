@@ -162,6 +162,7 @@ class Engine:
         # optimizer step on the side stream.
         self.dz_nt = os.environ.get("MV_DZ_NT", "1") != "0"
         self._w2t, self._w2t_ev, self._w2t_stale = None, None, True
+        self.head_splitk = True  # split-K for the decoder's input gradient (see _mlm_backward)
         self.dw_splitk = 0      # weight gradients: 0 = the library fills the chip with split-K slabs; n > 1 caps the slab count
         self.drop_seed = (torch.initial_seed() ^ 0x5DEECE66D) & 0xFFFFFFFFFFFFFFFF
         self.drop_counter = 0
@@ -529,7 +530,16 @@ class Engine:
         # tied decoder: dE = dlogits^T . t  (the embedding scatter-add comes later, in embed_bwd)
         self._dW(dlogits, hs["t"], g["enc.txt_embeddings.word_embeddings.weight"], V, H, R, lda=Vp, ldb=H)
         dt_ = self._buf(tag + "dt", (R, H), self.adt)
-        ops.gemm(dlogits, self.w["enc.txt_embeddings.word_embeddings.weight"], dt_, tb=True, M=R, N=H, K=V, lda=Vp, ldb=H)
+        if self.dt == MV_BF16 and self.head_splitk and R * H <= 4 * 1024 * 1024:
+            # dt = dlogits . E contracts over the vocabulary (K = 30,522) into a [R, 768] result: 156 tiles of 128x128 for the
+            # ~3,300 labelled rows -- a fifth of the chip's tile slots, 477 K-steps each.  Split-K (partial sums in f32, one
+            # reduction, one cast) spreads it over the whole chip.
+            dt32 = self._buf(tag + "dt32", (R, H), torch.float32)
+            ops.gemm(dlogits, self.w["enc.txt_embeddings.word_embeddings.weight"], dt32, tb=True, M=R, N=H, K=V, lda=Vp, ldb=H,
+                     splitk=0, ws=self._gemm_workspace(8 * R * H))
+            ops.cast(dt32, dt_, R * H)
+        else:
+            ops.gemm(dlogits, self.w["enc.txt_embeddings.word_embeddings.weight"], dt_, tb=True, M=R, N=H, K=V, lda=Vp, ldb=H)
         dtact = self._buf(tag + "dtact", (R, H), self.adt)
         ops.layernorm_bwd(dt_, hs["tact"], hs["mean"], hs["rstd"], self.p["mlm.predictions.transform.LayerNorm.weight"], dtact,
                           g["mlm.predictions.transform.LayerNorm.weight"], g["mlm.predictions.transform.LayerNorm.bias"], None, R, H)

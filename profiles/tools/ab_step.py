@@ -39,6 +39,8 @@ VARIANTS = {
              ("dz on the 256-row kernel over a W2^T copy", lambda: setattr(model.engine, "dz_nt", True))],
     "dwo": [("small dW: at most 16 split-K slabs", lambda: setattr(model.engine, "dw_splitk", 16)),
             ("small dW: up to 32 slabs (auto)", lambda: setattr(model.engine, "dw_splitk", 0))],
+    "headk": [("decoder input gradient: one pass over K = 30,522", lambda: setattr(model.engine, "head_splitk", False)),
+              ("decoder input gradient: split-K", lambda: setattr(model.engine, "head_splitk", True))],
     "tail": [("last layer on all rows", lambda: setattr(step, "tail_rows", False)), ("last layer on consumed rows", lambda: setattr(step, "tail_rows", True))],
 }
 which = sys.argv[1] if len(sys.argv) > 1 else "pack"
