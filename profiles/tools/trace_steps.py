@@ -27,7 +27,7 @@ def main():
                          int(r["Grid_Size_X"]) // max(1, int(r["Workgroup_Size_X"]))))
     rows.sort()
     opt = [i for i, r in enumerate(rows) if "adamw_kernel" in r[3]]
-    k = int(sys.argv[2]) if len(sys.argv) > 2 else len(opt) // 2 - 1
+    k = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2].isdigit() else len(opt) // 2 - 1
     lo, hi = (opt[k - 1] + 1 if k > 0 else 0), opt[k] + 1
     step = rows[lo:hi]
     t0, t1 = step[0][0], step[-1][1]
@@ -54,6 +54,11 @@ def main():
         perk[key][0] += 1
         perk[key][1] += (e - s) / 1e3
     print("busy ms per queue:", {q: round(v, 2) for q, v in perq.items()})
+    if "--small" in sys.argv:
+        print("launches with fewer than 512 workgroups that run longer than 25 us (under-occupied kernels):")
+        for s_, e_, q, n, g_ in sorted(step, key=lambda r: r[0] - r[1]):
+            if g_ < 512 and (e_ - s_) > 25000:
+                print(f"   queue {q} {short(n):60s} workgroups {g_:5d}  {(e_ - s_) / 1e3:8.1f} us")
     print(f"{'queue':>5} {'kernel':60s} {'calls':>5} {'total_us':>10} {'avg_us':>8}")
     for (q, n), (c, t) in sorted(perk.items(), key=lambda x: -x[1][1]):
         print(f"{q:>5} {n:60s} {c:5d} {t:10.1f} {t / c:8.1f}")
