@@ -162,6 +162,8 @@ class Engine:
         # optimizer step on the side stream.
         self.dz_nt = os.environ.get("MV_DZ_NT", "1") != "0"
         self._w2t, self._w2t_ev, self._w2t_stale = None, None, True
+        self.head_on_side = True  # the tied decoder's weight gradient on the side stream (see _mlm_backward)
+        self._dE_ev = None
         self.head_splitk = True  # split-K for the decoder's input gradient (see _mlm_backward)
         self.dw_splitk = 0      # weight gradients: 0 = the library fills the chip with split-K slabs; n > 1 caps the slab count
         self.drop_seed = (torch.initial_seed() ^ 0x5DEECE66D) & 0xFFFFFFFFFFFFFFFF
@@ -527,8 +529,19 @@ class Engine:
         R, Vp = hs["R"], hs["Vp"]
         g = self.g
         ops.colsum(dlogits, Vp, R, V, g["mlm.predictions.bias"], accumulate=True)
-        # tied decoder: dE = dlogits^T . t  (the embedding scatter-add comes later, in embed_bwd)
-        self._dW(dlogits, hs["t"], g["enc.txt_embeddings.word_embeddings.weight"], V, H, R, lda=Vp, ldb=H)
+        # tied decoder: dE = dlogits^T . t  (the embedding scatter-add comes later, in embed_bwd).  360 tiles, no split-K, no
+        # workspace: it runs on the side stream, which is idle until the encoder's backward starts; embed_bwd waits for it.
+        main = torch.cuda.current_stream()
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        side = self._side if (self.head_on_side and os.environ.get("MV_SINGLE_STREAM") != "1") else main
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            self._dW(dlogits, hs["t"], g["enc.txt_embeddings.word_embeddings.weight"], V, H, R, lda=Vp, ldb=H)
+            self._dE_ev = torch.cuda.Event()
+            self._dE_ev.record(side)
+        if side is not main:
+            dlogits.record_stream(side)     # a per-step allocation of the caller: not to be reused before the side stream has read it
         dt_ = self._buf(tag + "dt", (R, H), self.adt)
         if self.dt == MV_BF16 and self.head_splitk and R * H <= 4 * 1024 * 1024:
             # dt = dlogits . E contracts over the vocabulary (K = 30,522) into a [R, 768] result: 156 tiles of 128x128 for the
@@ -775,6 +788,9 @@ class Engine:
                 bucket_hook(f"layer{l}", ev_layer)
         e = "enc.txt_embeddings."
         dimg = self._buf("bw_dimg", (B * N, H), adt)
+        if getattr(self, "_dE_ev", None) is not None:
+            main.wait_event(self._dE_ev)      # the decoder's word-embedding gradient (written, not accumulated) is in place
+            self._dE_ev = None
         ops.embed_bwd(self.dt, dy, self._ws["pre0"][:M * H].view(M, H), self._ws["mean0"][:M], self._ws["rstd0"][:M],
                       self.p[e + "LayerNorm.weight"], S["cls_tok"], S["txt"], S["segment"], S["img_pos"], S["sep_tok"],
                       g[e + "word_embeddings.weight"], g[e + "position_embeddings.weight"], g[e + "token_type_embeddings.weight"],

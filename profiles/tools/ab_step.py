@@ -41,6 +41,8 @@ VARIANTS = {
             ("small dW: up to 32 slabs (auto)", lambda: setattr(model.engine, "dw_splitk", 0))],
     "headk": [("decoder input gradient: one pass over K = 30,522", lambda: setattr(model.engine, "head_splitk", False)),
               ("decoder input gradient: split-K", lambda: setattr(model.engine, "head_splitk", True))],
+    "dEside": [("decoder weight gradient on the main stream", lambda: setattr(model.engine, "head_on_side", False)),
+               ("decoder weight gradient on the side stream", lambda: setattr(model.engine, "head_on_side", True))],
     "tail": [("last layer on all rows", lambda: setattr(step, "tail_rows", False)), ("last layer on consumed rows", lambda: setattr(step, "tail_rows", True))],
 }
 which = sys.argv[1] if len(sys.argv) > 1 else "pack"
