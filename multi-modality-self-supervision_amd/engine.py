@@ -243,6 +243,15 @@ class Engine:
             self._w2t_ev.record(side)
         self._w2t_stale = False
 
+    def side_stream(self):
+        """The engine's second HIP stream (weight gradients during the backward; idle otherwise), or the current stream under
+        MV_SINGLE_STREAM=1."""
+        if os.environ.get("MV_SINGLE_STREAM") == "1":
+            return torch.cuda.current_stream()
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        return self._side
+
     def zero_grad(self):
         self.ensure_grad()
         self.flat_g.zero_()

@@ -75,8 +75,19 @@ class TrainStep:
             self.dp.timing = self.time_exchange
         rows, ids, aligned = self._prep(batch)
         eng.training = bool(train and self.model.training)      # dropout like the reference's model.train()
+        zero_ev = None
         if train:
-            eng.flat_g.zero_()
+            # the flat gradient is cleared on the engine's side stream, which is idle during the forward; the heads wait for it
+            main = torch.cuda.current_stream() if eng.device.type == "cuda" else None
+            side = eng.side_stream() if main is not None else None
+            if side is not None and side is not main:
+                side.wait_stream(main)                 # behind the previous step's optimizer (it read the gradients)
+                with torch.cuda.stream(side):
+                    eng.flat_g.zero_()
+                    zero_ev = torch.cuda.Event()
+                    zero_ev.record(side)
+            else:
+                eng.flat_g.zero_()
         desc = batch.get("attn_desc") if use_desc else None
         pack = bool(self.pack_rows and desc is not None and eng.adt == torch.bfloat16 and desc.packable())
         mask = desc if desc is not None else batch["attn_mask"]      # descriptors when there are any: no [B,L,L] traffic
@@ -96,6 +107,8 @@ class TrainStep:
             mlm_dev, mlm_scale = None, 0.0
         if not self.itm_task:
             itm_dev, itm_scale = None, 0.0
+        if zero_ev is not None:
+            torch.cuda.current_stream().wait_event(zero_ev)
         stats = eng.heads_train(rows, ids, aligned, mlm_scale_dev=mlm_dev, mlm_scale=mlm_scale, itm_scale=itm_scale,
                                 itm_scale_dev=itm_dev, compute_grad=train)
         if train:
