@@ -192,7 +192,7 @@ def main():
     torch.manual_seed(1234)                                 # identical init on every rank (checked by TrainStep's checksum)
     model = mv.CXRBERT(cfg, None, dtype=torch.bfloat16, device=dev, fwd_operand=args.fwd_operand)
     model.train()                                           # dropout 0.1 at every site, like the reference's train()
-    step = mv.TrainStep(model, lr=1e-5, distributed=(world > 1))
+    step = mv.TrainStep(model, lr=1e-5, distributed=(world > 1), overlap_optimizer=True)      # as CXRBERT_Trainer builds it
     B, N, S = args.batch, c["N"], c["S"]
     L = N + S + 3
 

@@ -205,6 +205,7 @@ class CXRBERT(nn.Module):
 
     # ------------------------------------------------------------------ state dict (reference key names)
     def state_dict(self, *a, **k):
+        self.engine.wait_optimizer()
         sd = OrderedDict((n, self.engine.p[n].detach().clone()) for n in self._param_names)
         for alias, canon in ALIASES.items():
             sd[alias] = sd[canon]
@@ -214,6 +215,7 @@ class CXRBERT(nn.Module):
         return sd
 
     def load_state_dict(self, sd, strict=True):
+        self.engine.wait_optimizer()
         missing = []
         with torch.no_grad():
             for n in self._param_names:

@@ -164,6 +164,7 @@ class Engine:
         self._w2t, self._w2t_ev, self._w2t_stale = None, None, True
         self.head_on_side = True  # the tied decoder's weight gradient on the side stream (see _mlm_backward)
         self._dE_ev = None
+        self._opt_ev = None       # overlapped AdamW: parameter range -> event (see adamw_step)
         self.head_splitk = True  # split-K for the decoder's input gradient (see _mlm_backward)
         self.dw_splitk = 0      # weight gradients: 0 = the library fills the chip with split-K slabs; n > 1 caps the slab count
         self.drop_seed = (torch.initial_seed() ^ 0x5DEECE66D) & 0xFFFFFFFFFFFFFFFF
@@ -215,6 +216,7 @@ class Engine:
 
     def sync_shadow(self):
         """16-bit path: refresh the copies the MFMA kernels read from the fp32 master weights."""
+        self.wait_optimizer()
         if self.dt == MV_BF16:
             ops.cast(self.flat_p, self.shadow, self.n_flat)
         if self.dual:
@@ -356,6 +358,7 @@ class Engine:
             raise ValueError(f"attn_mask shape {tuple(attn_mask.shape)} does not match L = N+T+2 = {Lq}")
         if self.shadow_dirty:
             self.sync_shadow()
+        self._wait_opt("embeddings")
         f32 = torch.float32
         S = self.S = dict(B=B, T=T, N=N, L=Lq, M=M, cu=None, rowmap=None, inv=None, sel=None, n_lab=0)
         if pack:
@@ -430,6 +433,7 @@ class Engine:
                       drop_key=dk[(self.SITE_EMB, 0)], rowmap=rowmap, n_rows=M, x0_bf16=xb2(x, x_b))
         S["layers"] = []
         for l in range(cfg.layers):
+            self._wait_opt(f"layer{l}")
             p = f"enc.encoder.layer.{l}."
             Wqkv, bqkv, _, _ = self.qkv_views(l, fwd=True)
             a_ = {}
@@ -497,6 +501,7 @@ class Engine:
             ops.gather_rows(x, H, cu, B, H, h0_f, H)
             if dual:
                 ops.gather_rows(x_b, H, cu, B, H, S["h0"], H)
+        self._wait_opt("heads")
         ops.gemm(h0_f, wf["enc.pooler.dense.weight"], pooled, M=B, N=H, K=H, lda=S["h0_ld"],
                  bias=self.p["enc.pooler.dense.bias"], epi=EPI_BIAS_TANH, c3=xb2(pooled, pooled_b))
         return (x.view(B, Lq, H) if (cu is None and S["sel"] is None) else x), pooled
@@ -813,10 +818,60 @@ class Engine:
             bucket_hook("embeddings", None)
 
     # ------------------------------------------------------------------ optimizer
-    def adamw_step(self, step, lr=1e-5, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.0, correct_bias=True, grad_scale=1.0):
-        """HF AdamW over the whole flat buffer in one kernel; also refreshes the bf16 shadow."""
+    def adamw_step(self, step, lr=1e-5, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.0, correct_bias=True, grad_scale=1.0,
+                   overlap=False):
+        """HF AdamW over the flat buffer; also refreshes the 16-bit shadows.
+
+        overlap=False: one kernel on the current stream.  overlap=True: one kernel per contiguous parameter range in FORWARD
+        order (embeddings, layer 0 .. L-1, heads) on the side stream, an event after each; the next `encoder_forward` makes the
+        current stream wait for a range's event right before it reads that range, so the optimizer (HBM-bound, MFMA idle) runs
+        under the next step's first layers (MFMA-bound).  Anything else that reads parameters on the current stream must call
+        `wait_optimizer()` first (CXRBERT.state_dict / save / load do)."""
         self.ensure_opt()
-        ops.adamw_step(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.shadow, self.n_flat, lr, betas[0], betas[1], eps,
-                       weight_decay, step, correct_bias, grad_scale, shadow_f16=self.shadow_f)
+        if not (overlap and self.device.type == "cuda" and os.environ.get("MV_SINGLE_STREAM") != "1"):
+            self.wait_optimizer()
+            ops.adamw_step(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.shadow, self.n_flat, lr, betas[0], betas[1], eps,
+                           weight_decay, step, correct_bias, grad_scale, shadow_f16=self.shadow_f)
+            self.shadow_dirty = False
+            self.refresh_w2t()
+            return
+        from .dist import bucket_ranges
+        cfg = self.cfg
+        ranges = bucket_ranges(self.layout, self.n_flat, cfg.layers)
+        main, side = torch.cuda.current_stream(), self.side_stream()
+        side.wait_stream(main)                  # gradients (and their all-reduce, which the caller finished) are final
+        evs = {}
+        use_w2t = self.dz_nt and self.dt == MV_BF16
+        if use_w2t and self._w2t is None:
+            self._w2t = [torch.empty((cfg.intermediate, cfg.hidden), dtype=self.adt, device=self.device) for _ in range(cfg.layers)]
+        with torch.cuda.stream(side):
+            for name in ["embeddings"] + [f"layer{l}" for l in range(cfg.layers)] + ["heads"]:
+                s_, e_ = ranges[name]
+                sl = slice(s_, e_)
+                ops.adamw_step(self.flat_p[sl], self.flat_g[sl], self.flat_m[sl], self.flat_v[sl],
+                               None if self.shadow is None else self.shadow[sl], e_ - s_, lr, betas[0], betas[1], eps,
+                               weight_decay, step, correct_bias, grad_scale,
+                               shadow_f16=None if self.shadow_f is None else self.shadow_f[sl])
+                if use_w2t and name.startswith("layer"):
+                    l = int(name[5:])
+                    ops.transpose(self.w[f"enc.encoder.layer.{l}.output.dense.weight"], self._w2t[l], cfg.hidden, cfg.intermediate)
+                ev = torch.cuda.Event()
+                ev.record(side)
+                evs[name] = ev
+        self._opt_ev = evs
+        self._w2t_ev, self._w2t_stale = evs["heads"], False
         self.shadow_dirty = False
-        self.refresh_w2t()
+
+    def _wait_opt(self, name):
+        """Current stream waits for the optimizer's kernel over parameter range `name` (overlapped AdamW), once."""
+        if self._opt_ev:
+            ev = self._opt_ev.pop(name, None)
+            if ev is not None:
+                torch.cuda.current_stream().wait_event(ev)
+
+    def wait_optimizer(self):
+        """Current stream waits for every outstanding optimizer kernel (before parameters are read outside the engine)."""
+        if self._opt_ev:
+            for ev in self._opt_ev.values():
+                torch.cuda.current_stream().wait_event(ev)
+            self._opt_ev = None

@@ -23,7 +23,7 @@ class TrainStep:
     """Fused pretraining step over a CXRBERT model (single GPU or one rank of a DP job)."""
 
     def __init__(self, model: CXRBERT, lr=1e-5, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.0, distributed=False, group=None,
-                 mlm_task=True, itm_task=True, pack_rows=True):
+                 mlm_task=True, itm_task=True, pack_rows=True, overlap_optimizer=False):
         # HF AdamW defaults, as effectively used by the reference: train_origin.py:60 passes only lr
         self.model, self.eng = model, model.engine
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
@@ -33,6 +33,9 @@ class TrainStep:
         # encoder runs on the valid rows only; results are those of the padded run (see Engine.encoder_forward)
         self.pack_rows = pack_rows
         self.tail_rows = True        # last layer after its attention: consumed rows only (exact; Engine.encoder_forward)
+        # AdamW range by range on the side stream, under the next step's first layers (Engine.adamw_step).  Opt-in: whoever reads
+        # parameters on the current stream between steps without going through the model must call sync() first
+        self.overlap_optimizer = overlap_optimizer
         self.eng.ensure_opt()
         self.dp = None
         self.time_exchange = False
@@ -66,8 +69,13 @@ class TrainStep:
             stats = self._run(batch, train, use_desc=False)
         if train:
             self.step_cnt += 1
-            self.eng.adamw_step(self.step_cnt, lr=self.lr, betas=self.betas, eps=self.eps, weight_decay=self.wd)
+            self.eng.adamw_step(self.step_cnt, lr=self.lr, betas=self.betas, eps=self.eps, weight_decay=self.wd,
+                                overlap=self.overlap_optimizer)
         return stats
+
+    def sync(self):
+        """Order the current stream behind an overlapped optimizer step (no-op otherwise)."""
+        self.eng.wait_optimizer()
 
     def _run(self, batch, train, use_desc):
         eng = self.eng
@@ -158,6 +166,7 @@ class CXRBERT_Trainer:
         self.mlm_task = _str2bool(getattr(args, "mlm_task", True))
         self.itm_task = _str2bool(getattr(args, "itm_task", True))
         self.step = TrainStep(self.model, lr=getattr(args, "lr", 1e-5), distributed=self.distributed, mlm_task=self.mlm_task,
+                              overlap_optimizer=True,
                               itm_task=self.itm_task)
         self.recognise_masks = True     # derive {family, n2, vl} descriptors from the Dataset's materialised masks (verified)
         self.n_recognised = 0

@@ -43,6 +43,8 @@ VARIANTS = {
               ("decoder input gradient: split-K", lambda: setattr(model.engine, "head_splitk", True))],
     "dEside": [("decoder weight gradient on the main stream", lambda: setattr(model.engine, "head_on_side", False)),
                ("decoder weight gradient on the side stream", lambda: setattr(model.engine, "head_on_side", True))],
+    "optov": [("AdamW on the main stream after the backward", lambda: setattr(step, "overlap_optimizer", False)),
+              ("AdamW on the side stream under the next forward", lambda: setattr(step, "overlap_optimizer", True))],
     "tail": [("last layer on all rows", lambda: setattr(step, "tail_rows", False)), ("last layer on consumed rows", lambda: setattr(step, "tail_rows", True))],
 }
 which = sys.argv[1] if len(sys.argv) > 1 else "pack"

@@ -332,6 +332,35 @@ def test_retrieval_head_with_1d_masks(golden_dir):
         assert float((sc.cpu() - ref).abs().max()) < tol
 
 
+def test_overlapped_optimizer_equals_the_plain_step():
+    """TrainStep(overlap_optimizer=True): AdamW runs range by range on the side stream and the next forward waits per range.
+    Elementwise the same arithmetic on the same gradients; the gradients themselves carry float-atomic sums, so two runs of the
+    SAME mode already differ in last bits (and AdamW turns a sign flip of a near-zero gradient into 2 lr): the comparison uses the
+    bounds of the data-parallel test.  state_dict() taken right after a step sees the finished update."""
+    cfg = mv.ModelConfig(vocab_size=2048, hidden=128, layers=3, heads=2, intermediate=512, max_pos=128)
+    out = []
+    for overlap in (False, True):
+        torch.manual_seed(5)
+        m = mv.CXRBERT(cfg, None, dtype=torch.bfloat16, device=DEV)
+        m.reset_parameters(seed=3)
+        m.train()
+        ts = mv.TrainStep(m, lr=1e-3, overlap_optimizer=overlap)
+        for i in range(3):
+            batch = mv.data.synthetic_batch(cfg.vocab_size, 8, 6, 40, "mixed", seed=20 + i, device=DEV)
+            stats = ts(batch, train=True)
+        sd = m.state_dict()                                    # waits for the side stream's kernels by itself
+        ev = ts(mv.data.synthetic_batch(cfg.vocab_size, 8, 6, 40, "full", seed=99, device=DEV), train=False)
+        torch.cuda.synchronize()
+        out.append((m.engine.flat_p.clone(), sd, stats.cpu(), ev.cpu(), m.engine.shadow.clone()))
+    (p0, sd0, s0, e0, sh0), (p1, sd1, s1, e1, sh1) = out
+    d = (p0 - p1).abs()
+    assert float(d.max()) < 3 * 2e-3 + 1e-4 and float(d.mean()) < 5e-5, (float(d.max()), float(d.mean()))
+    assert torch.equal(sh1.float(), p1.to(torch.bfloat16).float())                     # shadows refreshed from the updated weights
+    assert float((s0 - s1).abs().max()) < 1e-2 * float(s0.abs().max()) and float((e0 - e1).abs().max()) < 1e-2 * float(e0.abs().max())
+    off = m.engine.layout["enc.pooler.dense.weight"][0]
+    assert torch.equal(sd1["enc.pooler.dense.weight"].flatten(), p1[off:off + 128 * 128])    # state_dict saw the finished step
+
+
 def test_retrieval_forward_is_differentiable_through_the_itm_head(golden_dir):
     """CXRBertForRetrieval.forward (enc + itm, Retrieval/retrieval.py:26-31) runs its ITM linear on the C ABI too and stays a
     differentiable node: its parameter gradients equal those of the ITM output of the full CXRBERT.forward."""
