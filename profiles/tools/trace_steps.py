@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-step, per-queue summary of a rocprofv3 --kernel-trace CSV of bench.py: finds the optimizer launches (one per step), cuts
+"""Per-step, per-queue summary of a rocprofv3 --kernel-trace CSV of bench.py: finds the embedding-forward launches (one per step), cuts
 the trace into steps and prints, for the chosen step, wall time, per-queue busy time, time with >= 2 kernels in flight, and the
 per-kernel totals split by queue.   usage: trace_steps.py <kernel_trace.csv> [step_index]"""
 import csv
@@ -26,7 +26,8 @@ def main():
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Queue_Id"], r["Kernel_Name"],
                          int(r["Grid_Size_X"]) // max(1, int(r["Workgroup_Size_X"]))))
     rows.sort()
-    opt = [i for i, r in enumerate(rows) if "adamw_kernel" in r[3]]
+    # one embedding-forward launch per step (the optimizer may run as one kernel or range by range on the side stream)
+    opt = [i - 1 for i, r in enumerate(rows) if "embed_fwd_kernel" in r[3] and i > 0]
     k = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2].isdigit() else len(opt) // 2 - 1
     lo, hi = (opt[k - 1] + 1 if k > 0 else 0), opt[k] + 1
     step = rows[lo:hi]
@@ -54,6 +55,18 @@ def main():
         perk[key][0] += 1
         perk[key][1] += (e - s) / 1e3
     print("busy ms per queue:", {q: round(v, 2) for q, v in perq.items()})
+    if "--gaps" in sys.argv:
+        print("largest intervals with NO kernel running (us), with the kernel that ended before and the one that started after:")
+        iv = sorted(step, key=lambda r: r[0])
+        gaps, end, last = [], iv[0][1], iv[0]
+        for r in iv[1:]:
+            if r[0] > end:
+                gaps.append((r[0] - end, short(last[3]), short(r[3]), (end - t0) / 1e6))
+            if r[1] > end:
+                end, last = r[1], r
+        for g_, a_, b_, at in sorted(gaps, reverse=True)[:14]:
+            print(f"   {g_ / 1e3:7.1f} us at {at:6.2f} ms  after {a_[:44]:44s} before {b_[:44]}")
+        print(f"   ({len(gaps)} gaps, {sum(g[0] for g in gaps) / 1e6:.2f} ms in total)")
     if "--small" in sys.argv:
         print("launches with fewer than 512 workgroups that run longer than 25 us (under-occupied kernels):")
         for s_, e_, q, n, g_ in sorted(step, key=lambda r: r[0] - r[1]):
