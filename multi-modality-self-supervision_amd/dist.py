@@ -15,6 +15,8 @@ diverge silently).
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -39,6 +41,9 @@ class GradAllReducer:
         self.flat_g = flat_g
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # rehearsal on a one-GPU box: MV_DP_FORCE=1 issues every collective even in a one-rank group, so that the RCCL calls,
+        # the communication stream and the Work handles are exercised for real (tests/test_dp_gpu.py)
+        self.force = os.environ.get("MV_DP_FORCE") == "1" and dist.is_initialized()
         self.ranges = bucket_ranges(layout, n_flat, layers)
         self.merge = max(1, merge_layers)      # layers per bucket: ~2 x 28 MB fp32 at BERT-base
         self.layers = layers
@@ -53,7 +58,7 @@ class GradAllReducer:
 
     def check_replicas(self, flat_p: torch.Tensor):
         """Raise unless every rank holds the same parameters (sum and sum of squares, all-reduced MIN and MAX)."""
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return
         d = flat_p.double()
         c = torch.stack([d.sum(), (d * d).sum()])
@@ -67,12 +72,12 @@ class GradAllReducer:
     def global_counts(self, n_labelled: int, batch: int, device):
         """-> f32[2] device tensor (n_labelled_global, B_global); one small all-reduce."""
         t = torch.tensor([float(n_labelled), float(batch)], dtype=torch.float32, device=device)
-        if self.world > 1:
+        if self.world > 1 or self.force:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t
 
     def _launch(self, s, e, events=()):
-        if self.world == 1 or e <= s:
+        if (self.world == 1 and not self.force) or e <= s:
             return
         view = self.flat_g[s:e]
         if self.cuda:

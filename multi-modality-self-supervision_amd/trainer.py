@@ -107,7 +107,7 @@ class TrainStep:
         # loss normalisation = the reference's means over the GLOBAL mini-batch (train_origin.py:120-126)
         mlm_dev = itm_dev = None
         mlm_scale, itm_scale = 1.0 / max(R, 1), 1.0 / B
-        if train and self.dp is not None and self.dp.world > 1:      # eval: local sums only, no collective (ranks may
+        if train and self.dp is not None and (self.dp.world > 1 or self.dp.force):      # eval: local sums only, no collective (ranks may
             # hold different numbers of eval batches)
             inv = torch.reciprocal(torch.clamp(self.dp.global_counts(R, B, eng.device), min=1.0))
             mlm_dev, itm_dev = inv[0:1], inv[1:2]

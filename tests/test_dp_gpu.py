@@ -139,3 +139,45 @@ def test_two_rank_step_over_rccl():
     mp.spawn(_rccl_worker, args=(world, _free_port(), out), nprocs=world, join=True)
     assert torch.equal(out[0][0], out[1][0]) and bool(torch.isfinite(out[0][0]).all())
     assert float(out[0][1][1]) > 0
+
+
+def _rccl_one_rank_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ["MV_DP_FORCE"] = "1"               # issue every collective although the group has one rank
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    import medvill_amd as mv
+    cfg = mv.ModelConfig(vocab_size=2048, hidden=128, layers=3, heads=2, intermediate=512, max_pos=128)
+    res = []
+    for distributed in (True, False):
+        torch.manual_seed(3)
+        m = mv.CXRBERT(cfg, None, dtype=torch.bfloat16, device="cuda:0")
+        m.reset_parameters(seed=11)
+        m.eval()                      # dropout off: a distributed step draws rank-specific masks, the comparison needs the same function
+        ts = mv.TrainStep(m, lr=1e-3, distributed=distributed, overlap_optimizer=True)
+        ts.time_exchange = True
+        for i in range(3):
+            batch = mv.data.synthetic_batch(cfg.vocab_size, 8, 6, 40, "mixed", seed=5 + i, device="cuda:0")
+            stats = ts(batch, train=True)
+        ts.sync()
+        torch.cuda.synchronize()
+        res.append((m.engine.flat_p.cpu(), stats.cpu(), float(ts.exchange_exposed_ms()), None if ts.dp is None else len(ts.dp.ranges)))
+    out[0] = res
+    dist.destroy_process_group()
+
+
+def test_one_rank_rccl_group_runs_every_collective():
+    """The nccl (= RCCL) code path on a one-GPU box: a one-rank process group with MV_DP_FORCE=1, so that the parameter checksum,
+    the per-step count all-reduce and the bucketed gradient all-reduces on the communication stream all go through RCCL.  Summing
+    over one rank changes nothing: the parameters must follow the undistributed step (up to the float-atomic noise of the
+    gradients, see test_overlapped_optimizer_equals_the_plain_step)."""
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_rccl_one_rank_worker, args=(1, _free_port(), out), nprocs=1, join=True)
+    (p_d, s_d, exposed, nb), (p_s, s_s, _, _) = out[0]
+    assert bool(torch.isfinite(p_d).all()) and nb is not None and nb >= 3
+    d = (p_d - p_s).abs()
+    assert float(d.max()) < 3 * 2e-3 + 1e-4 and float(d.mean()) < 5e-5
+    assert float(s_d[1]) == float(s_s[1]) and exposed >= 0.0
