@@ -165,6 +165,9 @@ def main():
     if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
+    # before the HIP runtime starts: see medvill_amd/__init__.py.  Several ranks time-slicing ONE GPU (the gloo rehearsal) keep the
+    # default pool: two processes with 8 hardware queues each oversubscribe the device's queue slots (7.7 s per step measured)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "4" if os.environ.get("MV_SINGLE_DEVICE") == "1" else "8")
     import torch
     # rehearsal hooks for a 1-GPU box: MV_DIST_BACKEND=gloo MV_SINGLE_DEVICE=1 run every rank on cuda:0 over gloo
     if os.environ.get("MV_SINGLE_DEVICE") == "1":
@@ -173,7 +176,10 @@ def main():
     dev = torch.device("cuda", local_rank)
     backend = None
     rccl_ranks = 1
-    if world > 1:
+    # MV_DP_FORCE=1 under a one-rank launcher (torch.distributed.run --nproc-per-node 1): rehearse the RCCL branch on a one-GPU
+    # box -- the process group is built and every collective of the step is issued over it (see dist.GradAllReducer)
+    dist_on = world > 1 or (os.environ.get("MV_DP_FORCE") == "1" and "RANK" in os.environ)
+    if dist_on:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("MV_DIST_BACKEND", "nccl")          # "nccl" is RCCL on ROCm
@@ -192,7 +198,7 @@ def main():
     torch.manual_seed(1234)                                 # identical init on every rank (checked by TrainStep's checksum)
     model = mv.CXRBERT(cfg, None, dtype=torch.bfloat16, device=dev, fwd_operand=args.fwd_operand)
     model.train()                                           # dropout 0.1 at every site, like the reference's train()
-    step = mv.TrainStep(model, lr=1e-5, distributed=(world > 1), overlap_optimizer=True)      # as CXRBERT_Trainer builds it
+    step = mv.TrainStep(model, lr=1e-5, distributed=dist_on, overlap_optimizer=True)      # as CXRBERT_Trainer builds it
     B, N, S = args.batch, c["N"], c["S"]
     L = N + S + 3
 
@@ -203,7 +209,7 @@ def main():
     batches = make_batches(c["family"])
 
     def sync():
-        if world > 1:
+        if dist_on:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -224,12 +230,12 @@ def main():
             dt = float(t[0])
         return dt / n * 1e3, out
 
-    step.time_exchange = world > 1
+    step.time_exchange = dist_on
     ms_per_step, stats = timed(step, batches, args.warmup, args.steps)
     print(f"[bench] rank {rank}: {ms_per_step:.2f} ms/step", file=sys.stderr, flush=True)
     value = world * B / (ms_per_step / 1e3)
     st = stats.cpu()
-    exposed_ms = step.exchange_exposed_ms() if world > 1 else 0.0
+    exposed_ms = step.exchange_exposed_ms() if dist_on else 0.0
     packed = model.engine.S.get("cu") is not None
 
     extras = {}
@@ -307,7 +313,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.config)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist_on:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 
