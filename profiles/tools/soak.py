@@ -10,11 +10,15 @@ import medvill_amd as mv
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 400
 dev = torch.device("cuda", 0)
+dist_on = os.environ.get("MV_DP_FORCE") == "1" and "RANK" in os.environ       # one-rank RCCL group, every collective issued
+if dist_on:
+    torch.cuda.set_device(0)
+    torch.distributed.init_process_group("nccl", device_id=dev)
 cfg = mv.ModelConfig()
 torch.manual_seed(7)
 model = mv.CXRBERT(cfg, None, dtype=torch.bfloat16, device=dev)
 model.train()
-step = mv.TrainStep(model, lr=5e-5)
+step = mv.TrainStep(model, lr=5e-5, distributed=dist_on, overlap_optimizer=True)
 B, N, S = 64, 36, 473
 batches = [mv.data.synthetic_batch(cfg.vocab_size, B, N, S, "full" if i % 2 == 0 else "mixed", seed=100 + i, device=dev) for i in range(8)]
 hist = []
@@ -27,7 +31,10 @@ for i in range(steps):
         hist.append(mlm)
         print(f"step {i + 1:5d}: mlm {mlm:.4f} (acc {float(s[2] / s[1]):.3f})  itm {itm:.4f}  [{(time.perf_counter() - t0):.1f} s]", flush=True)
         assert all(map(lambda v: v == v and abs(v) < 1e4, (mlm, itm))), "non-finite loss"
+step.sync()
 p = model.engine.flat_p
 assert bool(torch.isfinite(p).all()), "non-finite parameter"
 assert hist[-1] < hist[0] - 1.0, f"loss did not fall: {hist}"
-print("ok: parameters finite, mlm loss", hist[0], "->", hist[-1])
+print("ok: parameters finite, mlm loss", hist[0], "->", hist[-1], "(RCCL path)" if dist_on else "")
+if dist_on:
+    torch.distributed.destroy_process_group()
