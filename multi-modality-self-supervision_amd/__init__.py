@@ -13,6 +13,28 @@ import os as _os
 # 26.9).  The variable is read when the HIP runtime initialises, i.e. at the first device call -- importing torch is not one.
 _os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
+
+def _warn_if_hip_started():
+    # main_origin.py imports torch / wandb and may touch the device before it imports the trainer: the variable above is then
+    # too late, the engine's side stream can share the main stream's hardware queue and the step serialises (26.6 -> 29.5 ms)
+    import sys as _sys
+    _torch = _sys.modules.get("torch")
+    try:
+        started = _torch is not None and _torch.cuda.is_initialized()
+    except Exception:
+        started = False
+    if started and _os.environ.get("GPU_MAX_HW_QUEUES") == "8" and not _os.environ.get("_MV_HWQ_SET_EARLY"):
+        import warnings as _w
+        _w.warn("medvill_amd was imported after the HIP runtime had started: GPU_MAX_HW_QUEUES=8 could not take effect in this "
+                "process.  With fewer hardware queues the backward's side stream may serialise behind the main stream (about 10 % "
+                "slower steps).  Export GPU_MAX_HW_QUEUES=8 before starting Python, or import medvill_amd before the first CUDA call.",
+                RuntimeWarning, stacklevel=3)
+
+
+if _os.environ.get("GPU_MAX_HW_QUEUES") == "8" and "torch" not in __import__("sys").modules:
+    _os.environ["_MV_HWQ_SET_EARLY"] = "1"
+_warn_if_hip_started()
+
 from .engine import Engine, ModelConfig, param_layout  # noqa: F401
 from .cxrbert import CXRBERT  # noqa: F401
 from .trainer import CXRBERT_Trainer, TrainStep  # noqa: F401

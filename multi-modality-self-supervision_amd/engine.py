@@ -147,7 +147,7 @@ class Engine:
         self.shadow_f = torch.zeros(self.n_flat, dtype=torch.float16, device=self.device) if self.dual else None
         self.shadow_dirty = True
         self._ws = {}
-        self._gemm_ws = None
+        self._gemm_ws = {}             # split-K workspaces, one per stream that runs split-K GEMMs (never shared across streams)
         self._side = None             # side HIP stream for the weight-gradient GEMMs of the backward
         self.training = False         # dropout is active only when True (CXRBERT.train() / TrainStep(train=True))
         # dropout stream: keyed by torch's seed (set_seed of utils/utils.py:9-16 -> torch.manual_seed), a per-rank offset
@@ -202,6 +202,9 @@ class Engine:
         device = torch.device(device)
         if device == self.device:
             return self
+        if self.device.type == "cuda":
+            self.wait_optimizer()          # an overlapped AdamW may still be writing the buffers that are copied below
+            torch.cuda.current_stream().synchronize()
         # host storage is allowed (state-dict I/O); every kernel call requires device tensors and raises otherwise
         for k in ("flat_p", "flat_g", "flat_m", "flat_v", "shadow", "shadow_f"):
             t = getattr(self, k)
@@ -210,7 +213,7 @@ class Engine:
         self.device = device
         self._ws.clear()
         self.shadow_dirty = True
-        self._gemm_ws = None
+        self._gemm_ws = {}
         self._bind()
         return self
 
@@ -316,9 +319,17 @@ class Engine:
         return (f, self._buf(key + "_b", shape, self.adt)) if self.dual else (f, f)
 
     def _gemm_workspace(self, nfloat):
-        if self._gemm_ws is None or self._gemm_ws.numel() < nfloat:
-            self._gemm_ws = torch.empty(nfloat, dtype=torch.float32, device=self.device)
-        return self._gemm_ws
+        """Split-K workspace of the CURRENT stream.  The main stream and the side stream each own one: a buffer shared between
+        them would be written by two split-K GEMMs at once whenever both streams take the split-K route (small-vocabulary
+        models: the tied decoder's weight gradient on the side stream next to the head's input gradient on the main one)."""
+        st = torch.cuda.current_stream() if self.device.type == "cuda" else None
+        key = st.cuda_stream if st is not None else 0
+        ws = self._gemm_ws.get(key)
+        if ws is None or ws.numel() < nfloat:
+            if ws is not None and st is not None:
+                ws.record_stream(st)          # kernels already enqueued on this stream may still use the old buffer
+            ws = self._gemm_ws[key] = torch.empty(nfloat, dtype=torch.float32, device=self.device)
+        return ws
 
     # dW[No,Ko] = dy[Mtok,No]^T . x[Mtok,Ko]  (contraction over tokens; split-K when the tile grid is small)
     def _dW(self, dy, x, gW, No, Ko, Mtok, lda, ldb, ldc=None):

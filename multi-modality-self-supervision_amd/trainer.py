@@ -55,7 +55,7 @@ class TrainStep:
             rows, ids = D.label_index(batch["txt_labels"])
         return rows.to(dev), ids.to(dev), batch["is_aligned"].to(dev, torch.int32)
 
-    def __call__(self, batch, train=True, verify=None):
+    def __call__(self, batch, train=True, verify=None, agree=False):
         """batch: dict with the reference's batch fields (cls_tok, input_txt, attn_mask, segment,
         img_feats, img_pos, sep_tok, txt_labels, is_aligned) [+ label_rows/label_ids].
         Returns the device tensor stats f32[6] = [mlm_nll_sum, n_lab, mlm_correct, itm_nll_sum, B, itm_correct]
@@ -63,10 +63,18 @@ class TrainStep:
         verify (optional callable -> bool): called after the forward and backward have been enqueued and before the
         optimizer; when it returns False the step is redone with batch["attn_mask"] instead of batch["attn_desc"]
         (CXRBERT_Trainer uses it to check, off the critical path, that descriptors it derived from a materialised
-        mask describe that mask bit for bit)."""
+        mask describe that mask bit for bit).  agree: under data parallelism, all-reduce the outcome so that every rank takes
+        the same branch; the caller must pass the same `agree` on every rank."""
         stats = self._run(batch, train, use_desc=True)
-        if verify is not None and not verify():
-            stats = self._run(batch, train, use_desc=False)
+        if verify is not None or agree:
+            ok = True if verify is None else bool(verify())
+            if agree and self.dp is not None:
+                # the first _run has already issued this step's collectives: a rank that redid the step on its own would issue a
+                # second set while its peers moved on.  `agree` is set by the caller on EVERY rank for this step (whether or not
+                # the rank has something to verify): all ranks agree (MIN) and redo the step together.
+                ok = self.dp.all_agree(ok)
+            if not ok:
+                stats = self._run(batch, train, use_desc=False)
         if train:
             self.step_cnt += 1
             self.eng.adamw_step(self.step_cnt, lr=self.lr, betas=self.betas, eps=self.eps, weight_decay=self.wd,
@@ -170,57 +178,98 @@ class CXRBERT_Trainer:
                               itm_task=self.itm_task)
         self.recognise_masks = True     # derive {family, n2, vl} descriptors from the Dataset's materialised masks (verified)
         self.n_recognised = 0
+        # how the derived descriptors are checked against the shipped matrices (see _recognise_masks): "full" = every entry of
+        # every batch on the device (134 MB over PCIe per step at B=64, L=512), "sampled" = every entry of the first
+        # `verify_first` batches and of every `verify_every`-th one, probe rows on the host otherwise, "off" = probes only
+        self.verify_masks = getattr(args, "verify_masks", "sampled")
+        self.verify_first, self.verify_every, self.verify_probes = 2, 64, 4
+        self._mask_batches, self._full_check = 0, True
         self._vstream = None
         self.log_freq = getattr(args, "log_freq", 10)
         self.logger = logger            # optional callable(dict, step=epoch): stands in for wandb.log
         print("Total Parameters:", sum(p.nelement() for p in self.model.parameters()))
 
-    def _recognise_masks(self, attn_masks, input_ids, N):
+    def _check_policy(self):
+        """Counts the batch and decides whether it gets the every-entry device check; a function of the batch count alone, so
+        that the ranks of a data-parallel job decide alike (they then agree on the outcome with one collective)."""
+        self._mask_batches += 1
+        self._full_check = self.verify_masks == "full" or (self.verify_masks == "sampled" and (
+            self._mask_batches <= self.verify_first or self._mask_batches % self.verify_every == 0))
+        return self._full_check
+
+    def _recognise_masks(self, attn_masks, input_ids, N, txt_labels=None):
         """The reference Dataset ships a materialised int64 mask per sample (dataset_origin.py:138-176: 134 MB per batch at
         B=64, L=512).  Its five families are closed forms of {family, n2, vl}: derive the descriptors from a few probe
-        entries on the host (two rows and a column per sample), let the step run on them (packed rows, mask bits built on
-        the device) and check them against EVERY entry of the shipped matrix on the device, on a side stream, off the
-        critical path (`verify`).  A mask outside the families -- or any mismatch -- falls back to the matrix itself.
-        Returns (MaskDesc, verify callable) or (None, None)."""
+        entries on the host (two rows and a column per sample, all samples at once), let the step run on them (packed rows,
+        mask bits built on the device).  `verify` then checks the descriptors against the shipped matrix: EVERY entry, on the
+        device, on a side stream (`self.verify_masks == "full"`, or the first `verify_first` batches and every
+        `verify_every`-th one under the default "sampled" policy); the other batches are checked on the host on the three
+        probe lines plus `verify_probes` random rows per sample -- no 134 MB host-to-device copy on those steps.  A mask
+        outside the families -- or any mismatch -- falls back to the matrix itself.
+        Returns (MaskDesc, verify callable or None) or (None, None)."""
         m = attn_masks
-        if not torch.is_tensor(m) or m.dtype != torch.int64 or m.dim() not in (2, 3):
+        if not torch.is_tensor(m) or m.dtype != torch.int64 or m.dim() not in (2, 3) or m.is_cuda:
             return None, None
         B, L = m.shape[0], m.shape[-1]
         S = L - N - 3
         n2 = N + 2
         if S < 1 or input_ids.shape[1] != S + 1:
             return None, None
-        mh = m if not m.is_cuda else None
         ids = input_ids.cpu()
-        n_ids = (ids != 0).sum(1).to(torch.int64)          # [PAD] = 0 after the text [SEP]
+        # valid length from the LAST non-zero id (the text [SEP] is never 0): random_word (dataset_origin.py:183-209) may put
+        # id 0 at a labelled in-text position, and a tokenizer may use id 0 for a real token
+        nz = ids != 0
+        T = ids.shape[1]
+        last = torch.where(nz.any(1), T - 1 - nz.flip(1).to(torch.int64).argmax(1), torch.full((B,), -1, dtype=torch.int64))
+        n_ids = last + 1
         vl = n2 + n_ids
+        if txt_labels is not None and torch.is_tensor(txt_labels):
+            lab = txt_labels.cpu() != -100
+            if lab.shape == (B, L) and bool((lab & (torch.arange(L).view(1, L) >= vl.view(B, 1))).any()):
+                return None, None          # a label after the derived valid length: the packed rows would drop it
         j = torch.arange(L).view(1, L)
         full_row = (j < vl.view(B, 1)).to(torch.int64)
         if m.dim() == 2:
-            fams = ["1d"] * B if mh is not None and torch.equal(mh, full_row) else None
-        else:
-            if mh is None:
+            if not torch.equal(m, full_row):
                 return None, None
-            r0, rl, cl = mh[:, 0, :], mh[:, L - 1, :], mh[:, :, L - 1]
+            fam_id = torch.full((B,), D.FAMILY_ID["1d"], dtype=torch.int32)
+        else:
+            r0, rl, cl = m[:, 0, :], m[:, L - 1, :], m[:, :, L - 1]
             img_row = (j < n2).to(torch.int64).expand(B, L)
+            txt_row = (j >= n2).to(torch.int64).expand(B, L)
+            bar_col = ((j < n2) | (j == L - 1)).to(torch.int64).expand(B, L)
             ones = torch.ones((B, L), dtype=torch.int64)
-            i = torch.arange(L).view(1, L)
-            fams = []
-            for b in range(B):
-                if torch.equal(r0[b], full_row[b]) and torch.equal(rl[b], full_row[b]):
-                    fams.append("full")
-                elif torch.equal(r0[b], img_row[b]) and torch.equal(rl[b], ones[b]):
-                    fams.append("s2s")
-                elif torch.equal(r0[b], ones[b]) and torch.equal(rl[b], ones[b]) and torch.equal(cl[b], ((i[0] < n2) | (i[0] == L - 1)).to(torch.int64)):
-                    fams.append("bar")
-                elif torch.equal(r0[b], img_row[b]) and torch.equal(rl[b], (j[0] >= n2).to(torch.int64)):
-                    fams.append("noncross")
-                else:
-                    fams = None
-                    break
-        if fams is None:
-            return None, None
-        desc = D.MaskDesc.make(fams, N, S, n_ids, self.device)
+            eq = lambda a, b_: (a == b_).all(1)
+            is_full = eq(r0, full_row) & eq(rl, full_row)
+            is_s2s = eq(r0, img_row) & eq(rl, ones)
+            is_bar = eq(r0, ones) & eq(rl, ones) & eq(cl, bar_col)
+            is_non = eq(r0, img_row) & eq(rl, txt_row)
+            fam_id = torch.full((B,), -1, dtype=torch.int32)
+            # same precedence as a per-sample if / elif chain over (full, s2s, bar, noncross)
+            for cond, name in ((is_non, "noncross"), (is_bar, "bar"), (is_s2s, "s2s"), (is_full, "full")):
+                fam_id = torch.where(cond, torch.full_like(fam_id, D.FAMILY_ID[name]), fam_id)
+            if bool((fam_id < 0).any()):
+                return None, None
+        d = torch.empty((B, 3), dtype=torch.int32)
+        d[:, 0], d[:, 1], d[:, 2] = fam_id, n2, vl.to(torch.int32)
+        desc = D.MaskDesc(d.to(self.device), L, host=d)
+        if self.verify_masks == "off":
+            return desc, None
+        if not self._full_check:
+            # host-side spot check of `verify_probes` random rows per sample against the closed forms (SURVEY Appendix B)
+            if m.dim() == 3 and self.verify_probes > 0:
+                g = torch.Generator().manual_seed(self._mask_batches)
+                rows = torch.randint(0, L, (B, self.verify_probes), generator=g)
+                got = m[torch.arange(B).view(B, 1), rows]                       # [B, P, L]
+                i_ = rows.view(B, -1, 1)
+                jj = torch.arange(L).view(1, 1, L)
+                f = fam_id.view(B, 1, 1)
+                want = torch.where(f == 1, (jj < n2) | ((i_ >= n2) & (jj >= n2) & (jj <= i_)),
+                       torch.where(f == 2, (i_ < n2) | (jj < n2) | (jj <= i_),
+                       torch.where(f == 3, (i_ < n2) == (jj < n2), jj < vl.view(B, 1, 1))))
+                if not torch.equal(got, want.to(torch.int64)):
+                    return None, None
+            return desc, None
         state = {}
 
         def verify():
@@ -256,7 +305,9 @@ class CXRBERT_Trainer:
         if isinstance(attn_masks, D.MaskDesc):             # a loader that already ships descriptors
             batch["attn_desc"], batch["attn_mask"] = attn_masks, None
             return batch, None
-        desc, verify = self._recognise_masks(attn_masks, input_ids, feats.shape[1]) if self.recognise_masks else (None, None)
+        if self.recognise_masks:
+            self._check_policy()
+        desc, verify = self._recognise_masks(attn_masks, input_ids, feats.shape[1], txt_labels) if self.recognise_masks else (None, None)
         if desc is not None:
             batch["attn_desc"] = desc
             self.n_recognised += 1
@@ -267,13 +318,16 @@ class CXRBERT_Trainer:
         losses, mlm_l, itm_l = [], [], []
         for i, data in enumerate(loader):
             batch, verify = self._to_batch(data)
-            stats = self.step(batch, train=train, verify=verify).double().cpu()   # the one sync per step
+            agree = bool(train and self.distributed and self.recognise_masks and self.verify_masks != "off" and self._full_check)
+            stats = self.step(batch, train=train, verify=verify, agree=agree).double().cpu()   # the one sync per step
             tot += stats
             ml = float(stats[0] / max(stats[1], 1.0))
             il = float(stats[3] / max(stats[4], 1.0))
             mlm_l.append(ml)
             itm_l.append(il)
             losses.append((ml if self.mlm_task else 0.0) + (il if self.itm_task else 0.0))
+        if train:
+            self.step.sync()        # parameters may be read on the current stream right after train() (overlapped AdamW)
         n = max(len(losses), 1)
         pre = "" if train else "eval_"
         out = {pre + "avg_loss": sum(losses) / n, pre + "avg_mlm_loss" if train else "eval_mlm_loss": sum(mlm_l) / n,
@@ -313,4 +367,14 @@ BERT_CONFIGS = {   # offline stand-ins for BertConfig.from_pretrained(...) at tr
                               intermediate_size=3072, max_position_embeddings=512),
     "bert-small-scratch": dict(vocab_size=30522, hidden_size=512, num_hidden_layers=4, num_attention_heads=8,
                                intermediate_size=2048, max_position_embeddings=512),
+    # the other --bert_model choices of main_origin.py:111-120 (their published config.json values)
+    "google/bert_uncased_L-4_H-512_A-8": dict(vocab_size=30522, hidden_size=512, num_hidden_layers=4, num_attention_heads=8,
+                                              intermediate_size=2048, max_position_embeddings=512),
+    "google/bert_uncased_L-2_H-128_A-2": dict(vocab_size=30522, hidden_size=128, num_hidden_layers=2, num_attention_heads=2,
+                                              intermediate_size=512, max_position_embeddings=512),
+    "emilyalsentzer/Bio_ClinicalBERT": dict(vocab_size=28996, hidden_size=768, num_hidden_layers=12, num_attention_heads=12,
+                                            intermediate_size=3072, max_position_embeddings=512),
+    "bionlp/bluebert_pubmed_mimic_uncased_L-12_H-768_A-12": dict(vocab_size=30522, hidden_size=768, num_hidden_layers=12,
+                                                                 num_attention_heads=12, intermediate_size=3072,
+                                                                 max_position_embeddings=512),
 }

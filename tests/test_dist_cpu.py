@@ -3,6 +3,8 @@ hook order and the global loss normalisation, no GPU needed."""
 import os
 import socket
 
+import pytest
+
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -40,13 +42,22 @@ def _worker(rank, world, port, out):
     local_nll = torch.tensor([3.0 * (rank + 1)])
     contrib = local_nll / cnt[0]
     dist.all_reduce(contrib)
-    ok = ok and abs(float(contrib) - (3.0 * 3 / 21.0)) < 1e-6
+    tot_nll, tot_cnt = 3.0 * sum(r + 1 for r in range(world)), float(sum(10 + r for r in range(world)))
+    ok = ok and abs(float(contrib) - tot_nll / tot_cnt) < 1e-6
+    # verification outcome of the trainer's mask check: one dissenting rank makes EVERY rank redo the step (same branch
+    # everywhere, so the collectives of the redone step match)
+    ok = ok and red.all_agree(True) is True
+    ok = ok and red.all_agree(rank != world - 1) is False
     out[rank] = ok
     dist.destroy_process_group()
 
 
-def test_two_rank_gradient_allreduce_and_global_normalisation():
-    world = 2
+
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_gradient_allreduce_global_normalisation_and_agreement(world):
+    """world 4: uneven labelled-token counts per rank (10, 11, 12, 13) and the merged two-layer buckets of a 3-layer model."""
     mgr = mp.Manager()
     out = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
