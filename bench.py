@@ -125,7 +125,7 @@ def time_dominant_kernel(eng, B, L):
     ms = e0.elapsed_time(e1) / reps
     fl = 2.0 * M * H * I
     nout = 3 if eng.dual else 2
-    enc = "f16" if eng.dual else "bf16"
+    enc = "f16" if eng.fadt == torch.float16 else "bf16"
     traffic, note = pmc_traffic()
     return dict(kernel=f"gemm_ring_kernel<NT, 256x256x64, {enc} operands> {M}x{I}x{H} +bias+GELU (writes gelu(z) and gelu'(z)"
                        + (" in f16 and gelu(z) again in bf16 for the weight-gradient product)" if eng.dual else ")"),
@@ -155,6 +155,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary timings (padded / BAR / non-cross / full-length / bf16 operands)")
     ap.add_argument("--fwd-operand", default=None, choices=["f16", "bf16"], help="encoding of the forward MFMA operands (default f16)")
+    ap.add_argument("--grad-operand", default=None, choices=["f16", "bf16"], help="encoding of the gradient-product operands (default: f16 "
+                    "under a loss scale with f16 forward operands, else bf16)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -197,7 +199,7 @@ def main():
     c = CONFIGS[args.config]
     cfg = mv.ModelConfig(max_pos=c["max_pos"])
     torch.manual_seed(1234)                                 # identical init on every rank (checked by TrainStep's checksum)
-    model = mv.CXRBERT(cfg, None, dtype=torch.bfloat16, device=dev, fwd_operand=args.fwd_operand)
+    model = mv.CXRBERT(cfg, None, dtype=torch.bfloat16, device=dev, fwd_operand=args.fwd_operand, grad_operand=args.grad_operand)
     model.train()                                           # dropout 0.1 at every site, like the reference's train()
     step = mv.TrainStep(model, lr=1e-5, distributed=dist_on, overlap_optimizer=True)      # as CXRBERT_Trainer builds it
     B, N, S = args.batch, c["N"], c["S"]
@@ -278,16 +280,22 @@ def main():
             "metric": "image-text pairs/sec pretraining step, BERT-base seq512", "value": value, "unit": "pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16/f16" if eng.dual else "bf16", "data": "synthetic",
+            "dtype": "f16/bf16" if eng.dual else ("f16" if eng.fadt == torch.float16 else "bf16"), "data": "synthetic",
             "config": {"workload": c["name"], "per_gpu_batch": B, "global_batch": B * world, "seq_len": L, "regions": N,
                        "mask": c["family"], "layers": cfg.layers, "hidden": cfg.hidden, "vocab": cfg.vocab_size,
                        "parallelism": f"dp{world}", "optimizer": "HF AdamW fused", "dropout": cfg.dropout,
                        "precision": ("16-bit MFMA operands, fp32 accumulate / statistics / master weights / optimizer; forward operands "
-                                     "f16-encoded, gradient-product operands bf16-encoded; encoder LayerNorm inputs (residual sums) stored "
+                                     "f16-encoded, gradient-product operands " + ("bf16-encoded (every stored activation in both encodings)" if eng.dual
+                                                                                 else "f16-encoded under a dynamic loss scale (device-side overflow check, "
+                                                                                      "overflowed steps skipped)")
+                                     + "; encoder LayerNorm inputs (residual sums) stored "
                                      + ("f16" if eng.ln_in_16 else "fp32") + " (BERT-base logits " + ("3.8-4.6e-3" if eng.ln_in_16 else "3.2-3.4e-3")
                                      + " max-abs from the reference, tolerance 1e-2; bf16-encoded forward operands give 2.6e-2: "
-                                     "profiles/r02_bf16_error.txt)") if eng.dual
+                                     "profiles/r02_bf16_error.txt)") if eng.fadt == torch.float16
                        else "16-bit MFMA operands, all bf16-encoded",
+                       "loss_scale": (float(eng.scaler[0]) if eng.scaler is not None else None),
+                       "steps_skipped_by_overflow": (int(eng.scaler[5]) if eng.scaler is not None else None),
+                       "optimizer_steps_applied": (int(eng.scaler[4]) if eng.scaler is not None else None),
                        "rows": (f"padding removed: encoder on the valid rows only (mean {rows_mean:.1f} of {L} positions per sample; "
                                 "results equal the padded run)") if packed else "padded",
                        "last_layer": "output projection / FFN / LayerNorms of the last layer on the consumed rows only (labelled rows + "

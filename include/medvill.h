@@ -34,14 +34,17 @@
 extern "C" {
 #endif
 
-#define MV_ABI_VERSION 2
+#define MV_ABI_VERSION 3
 
-/* MV_F16 is the encoding of the FORWARD operands of the 16-bit path (weights' f16 shadow, stored activations that
- * feed y = x.W^T and the attention forward): 11 significand bits instead of bf16's 8 at the same MFMA rate.  At
- * BERT-base depth bf16-encoded forward operands cannot meet the 1e-2 logit tolerance (the weight rounding alone gives
- * 1.4e-2, profiles/r02_bf16_error.txt); gradients keep MV_BF16 for its exponent range.  Kernels that produce a forward
- * activation can write it twice from one accumulator: the f16 copy for the next forward product and the bf16 copy that
- * the backward's gradient products (dW = dy^T.x, attention backward) pair with bf16 gradients. */
+/* MV_F16 is the encoding of the 16-bit path (weights' f16 shadow, stored activations, gradients): 11 significand bits
+ * instead of bf16's 8 at the same MFMA rate.  At BERT-base depth bf16-encoded forward operands cannot meet the 1e-2 logit
+ * tolerance (the weight rounding alone gives 1.4e-2, profiles/r02_bf16_error.txt).  Gradients in f16 need a LOSS SCALE
+ * (f16 has 5 exponent bits): the loss gradients are multiplied by S where they enter the 16-bit chain (mv_ce_fwd_bwd),
+ * every kernel that writes an f32 PARAMETER gradient multiplies by 1/S again (grad_unscale_dev of mv_gemm / mv_colsum /
+ * mv_layernorm_bwd / mv_embed_bwd), so the flat f32 gradient always holds true values; S lives on the device and is
+ * adapted by mv_scaler_update from mv_count_nonfinite's overflow count (an overflowed step is skipped by mv_adamw_step).
+ * The round-2 form remains available: f16 forward operands with MV_BF16 gradient operands, for which kernels that produce
+ * a forward activation write it twice from one accumulator (C3 / y_bf16 / ctx_bf16 / x0_bf16 below). */
 enum { MV_F32 = 0, MV_BF16 = 1, MV_F16 = 2 };
 
 enum {
@@ -90,7 +93,7 @@ void mv_set_gemm_variant(int force, int nj);
  * so  y = x.W^T            is (ta=0, tb=0, A=x,  B=W)
  *     dx = dy.W            is (ta=0, tb=1, A=dy, B=W)
  *     dW = dy^T.x          is (ta=1, tb=1, A=dy, B=x)
- * dtype applies to A and B (MV_F16 only for ta = tb = 0); c_dtype to C (and C2); r_dtype to R; bias is always f32.
+ * dtype applies to A and B (MV_F16 for every form but ta = 1, tb = 0); c_dtype to C (and C2); r_dtype to R; bias is always f32.
  * C3 (nullable, leading dimension ldc3): a second copy of C in the 16-bit encoding c3_dtype (see MV_F16 above).
  * 16-bit operands need 16-byte aligned bases and lda, ldb multiples of 8; a contraction length
  * K that is not a multiple of 8 is allowed only when the k-contiguous operand's rows are
@@ -100,7 +103,9 @@ void mv_set_gemm_variant(int force, int nj);
  * (>= splitk*M*N floats) and are summed by a second kernel; only with MV_EPI_NONE and an f32 C.
  * accumulate != 0: C += result (f32 C, MV_EPI_NONE only).
  * p_drop > 0 (MV_EPI_BIAS_RES only, N % 4 == 0): C = dropout(A.B + bias) + R -- the hidden-state dropout
- * of HF BertSelfOutput / BertOutput; mask = mv_dropout_mask(p_drop, drop_key) over index m*N + n.  */
+ * of HF BertSelfOutput / BertOutput; mask = mv_dropout_mask(p_drop, drop_key) over index m*N + n.
+ * alpha_dev (nullable; MV_EPI_NONE with an f32 C only): C = *alpha_dev * (A.B) -- the weight gradients of the f16-gradient
+ * path are un-scaled (1 / loss scale, read from the device) where they are written.  */
 int mv_gemm(int dtype, int ta, int tb, int M, int N, int K,
             const void* A, int lda, const void* B, int ldb,
             void* C, int ldc, int c_dtype,
@@ -109,7 +114,7 @@ int mv_gemm(int dtype, int ta, int tb, int M, int N, int K,
             void* C2, int ldc2,
             void* C3, int ldc3, int c3_dtype,
             int splitk, float* ws, size_t ws_bytes, int accumulate,
-            float p_drop, unsigned long long drop_key, void* stream);
+            float p_drop, unsigned long long drop_key, const float* alpha_dev, void* stream);
 
 /* ---- attention masks ----------------------------------------------------------------------
  * Replaces CXRBertEncoder.get_extended_attn_mask (cxrbert_origin.py:75-85): instead of an
@@ -184,7 +189,8 @@ int mv_attn_fwd(int dtype, const void* qkv, const uint32_t* bits, const uint8_t*
                 void* ctx, void* ctx_bf16, float* lse, int B, int L, int A, int dh,
                 float p_drop, unsigned long long drop_key, const int32_t* cu, int total_rows, void* stream);
 
-/* dqkv [B*L,3H] from dctx [B*L,H]; `delta` is a [B,A,L] f32 scratch (rowsum(dctx*ctx)). */
+/* dqkv [B*L,3H] from dctx [B*L,H]; `delta` is a [B,A,L] f32 scratch (rowsum(dctx*ctx)).  dtype (MV_F32, MV_BF16 or
+ * MV_F16) is the encoding of qkv, ctx, dctx and dqkv alike. */
 int mv_attn_bwd(int dtype, const void* qkv, const void* ctx, const void* dctx, const float* lse,
                 const uint32_t* bits, const uint8_t* tileinfo,
                 void* dqkv, float* delta, int B, int L, int A, int dh,
@@ -202,11 +208,12 @@ int mv_layernorm_fwd(int dtype, const void* x, int x_dtype, const float* gamma, 
  * (atomically) -- zero them first; colsum (f32 [H], nullable) accumulates sum_m dx[m,:]
  * (the bias gradient of the projection that produced x).
  * dx_drop (nullable): second output = dx * dropout_mask / (1 - p), the gradient w.r.t. the projection
- * output when x = dropout(projection) + residual (mask index m*H + c); colsum then sums dx_drop.  */
+ * output when x = dropout(projection) + residual (mask index m*H + c); colsum then sums dx_drop.
+ * grad_unscale_dev (nullable): *grad_unscale_dev multiplies what is added to dgamma / dbeta / colsum (1 / loss scale). */
 int mv_layernorm_bwd(int dtype, const void* dy, const void* x, int x_dtype, const float* mean,
                      const float* rstd, const float* gamma, void* dx, float* dgamma, float* dbeta,
                      float* colsum, int M, int H,
-                     void* dx_drop, float p_drop, unsigned long long drop_key, void* stream);
+                     void* dx_drop, float p_drop, unsigned long long drop_key, const float* grad_unscale_dev, void* stream);
 
 /* ---- sequence assembly + embeddings ---------------------------------------------------------
  * Replaces CXRBertEncoder.forward's else-branch assembly (cxrbert_origin.py:114-125),
@@ -226,13 +233,14 @@ int mv_embed_fwd(int dtype, const int64_t* cls_tok, const int64_t* txt, const in
 /* Backward of the above: LN backward of dx0, scatter-add (f32 atomics) into dE [V,H], dP, dTy,
  * dgamma, dbeta (all ACCUMULATED) and write d(imgproj) [B,N,H] in `dtype`.  Row `pad_token_id`
  * of dE receives no look-up gradient (HF BertEmbeddings builds nn.Embedding(..., padding_idx=
- * pad_token_id = 0)); pass -1 for none.                                                       */
+ * pad_token_id = 0)); pass -1 for none.  grad_unscale_dev (nullable): factor on everything added to the f32 gradients. */
 int mv_embed_bwd(int dtype, const void* dx0, const float* pre, const float* mean, const float* rstd,
                  const float* gamma, const int64_t* cls_tok, const int64_t* txt, const int64_t* segment,
                  const int64_t* img_pos, const int64_t* sep_tok,
                  float* dE, float* dP, float* dTy, float* dgamma, float* dbeta, void* dimgproj,
                  int B, int N, int T, int H, int V, int maxpos, int pad_token_id,
-                 float p_drop, unsigned long long drop_key, const int32_t* rowmap, int n_rows, void* stream);
+                 float p_drop, unsigned long long drop_key, const int32_t* rowmap, int n_rows,
+                 const float* grad_unscale_dev, void* stream);
 
 /* ---- losses + step metrics ------------------------------------------------------------------
  * Replaces nn.CrossEntropyLoss(ignore_index=-100) on mlm.transpose(1,2) and
@@ -244,10 +252,11 @@ int mv_embed_bwd(int dtype, const void* dx0, const float* pre, const float* mean
  * dlogits (nullable; d_dtype) = (softmax - onehot) * grad_scale for labelled rows, 0 otherwise;
  * columns V..ldd-1 are zero-filled (so dlogits can feed mv_gemm with K = V).
  * grad_scale is read from the device (*grad_scale_dev) when non-null (so 1/n_labelled_global
- * can be produced by an all-reduce without a host sync), else grad_scale_host.                */
+ * can be produced by an all-reduce without a host sync), else grad_scale_host; loss_scale_dev
+ * (nullable) multiplies it by the loss scale of the f16-gradient path (device state [0]).       */
 int mv_ce_fwd_bwd(const void* logits, int l_dtype, int ld, const int32_t* labels, int R, int V,
                   float* out, void* dlogits, int d_dtype, int ldd,
-                  const float* grad_scale_dev, float grad_scale_host, void* stream);
+                  const float* grad_scale_dev, float grad_scale_host, const float* loss_scale_dev, void* stream);
 
 /* ---- row gather / scatter (labelled-row compaction for the MLM head) ------------------------
  * dst[i,:] = src[rows[i],:]  /  dst[rows[i],:] (+)= src[i,:]; rows int32 [R].  A negative rows[i] means "no such
@@ -257,8 +266,9 @@ int mv_gather_rows(int dtype, const void* src, int lds, const int32_t* rows, int
 int mv_scatter_rows(int dtype, const void* src, int lds, const int32_t* rows, int R, int H,
                     void* dst, int ldd, int accumulate, void* stream);
 
-/* out[n] (+)= sum_m x[m,n]  (bias gradients). x [M,N] in dtype, out f32.                      */
-int mv_colsum(int dtype, const void* x, int ldx, int M, int N, float* out, int accumulate, void* stream);
+/* out[n] (+)= [*grad_unscale_dev] * sum_m x[m,n]  (bias gradients). x [M,N] in dtype, out f32.   */
+int mv_colsum(int dtype, const void* x, int ldx, int M, int N, float* out, int accumulate, const float* grad_unscale_dev,
+              void* stream);
 
 /* elementwise c = a + b (dtype), n elements */
 int mv_add(int dtype, const void* a, const void* b, void* c, size_t n, void* stream);
@@ -323,10 +333,24 @@ int mv_dropout_mask(float p_drop, unsigned long long drop_key, size_t n, uint8_t
  *   p -= lr*wd*p            (eps added BEFORE the bias correction, decoupled decay)
  * over one flat f32 buffer of n elements (all parameters live in one flat buffer);
  * g is multiplied by grad_scale first; shadow_bf16 / shadow_f16 (nullable) receive the 16-bit copies of
- * the updated parameters that the MFMA kernels read (bf16: gradient products, f16: forward).   */
+ * the updated parameters that the MFMA kernels read.
+ * scaler_state (nullable; the f32 [8] device state of mv_scaler_update): when given, the step is SKIPPED entirely if
+ * state[3] != 0 (the backward overflowed) and t of the bias correction is state[4] instead of `step`.   */
 int mv_adamw_step(float* p, const float* g, float* m, float* v, void* shadow_bf16, void* shadow_f16, size_t n,
                   float lr, float beta1, float beta2, float eps, float weight_decay, int step,
-                  int correct_bias, float grad_scale, void* stream);
+                  int correct_bias, float grad_scale, const float* scaler_state, void* stream);
+
+/* ---- dynamic loss scale of the f16-gradient path -------------------------------------------
+ * No counterpart in the reference (its gradients never leave f32; train_origin.py:129-131): f16 gradient operands need
+ * the loss scaled into f16's range.  state f32 [8] on the device: [0] scale S (read by mv_ce_fwd_bwd as loss_scale_dev),
+ * [1] 1/S (read as grad_unscale_dev / alpha_dev), [2] clean steps since S changed, [3] skip flag, [4] optimizer steps
+ * applied, [5] steps skipped, [6] non-finite count.  Initialise to {S0, 1/S0, 0, 0, 0, 0, 0, 0}.
+ *   mv_count_nonfinite: counter[0] += #elements of x (f32 [n], 16-byte aligned) that are inf or nan
+ *   mv_scaler_update  : count > 0 -> skip = 1, S = max(S*backoff, min_scale); else skip = 0, t += 1 and after
+ *                       growth_interval clean steps S = min(S*growth, max_scale); clears the count.        */
+int mv_count_nonfinite(const float* x, size_t n, float* counter, void* stream);
+int mv_scaler_update(float* state, int growth_interval, float growth, float backoff, float max_scale, float min_scale,
+                     void* stream);
 
 #ifdef __cplusplus
 }

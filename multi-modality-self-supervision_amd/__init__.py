@@ -11,6 +11,7 @@ import os as _os
 # small pool of hardware queues (4 by default); once RCCL has created its own streams the engine's second stream lands on the SAME
 # hardware queue as the first and everything serialises (measured on a one-rank RCCL group: 26.6 -> 29.5 ms/step; with 8 queues
 # 26.9).  The variable is read when the HIP runtime initialises, i.e. at the first device call -- importing torch is not one.
+_hwq_preset = "GPU_MAX_HW_QUEUES" in _os.environ          # exported by the caller (bench.py does) before anything could start HIP
 _os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 
@@ -23,7 +24,7 @@ def _warn_if_hip_started():
         started = _torch is not None and _torch.cuda.is_initialized()
     except Exception:
         started = False
-    if started and _os.environ.get("GPU_MAX_HW_QUEUES") == "8" and not _os.environ.get("_MV_HWQ_SET_EARLY"):
+    if started and not _hwq_preset:
         import warnings as _w
         _w.warn("medvill_amd was imported after the HIP runtime had started: GPU_MAX_HW_QUEUES=8 could not take effect in this "
                 "process.  With fewer hardware queues the backward's side stream may serialise behind the main stream (about 10 % "
@@ -31,8 +32,6 @@ def _warn_if_hip_started():
                 RuntimeWarning, stacklevel=3)
 
 
-if _os.environ.get("GPU_MAX_HW_QUEUES") == "8" and "torch" not in __import__("sys").modules:
-    _os.environ["_MV_HWQ_SET_EARLY"] = "1"
 _warn_if_hip_started()
 
 from .engine import Engine, ModelConfig, param_layout  # noqa: F401

@@ -16,7 +16,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libmedvill_hip.so")
-SOURCES = ["mv_api.hip", "mv_gemm.hip", "mv_gemm_ring.hip", "mv_attn.hip", "mv_rowops.hip", "mv_batch.hip", "mv_conv.hip"]
+SOURCES = ["mv_gemm_ring_tn.hip", "mv_gemm_ring_nt.hip", "mv_gemm_ring_nn.hip", "mv_gemm_ring_tnn.hip", "mv_gemm.hip", "mv_attn.hip",
+           "mv_rowops.hip", "mv_batch.hip", "mv_conv.hip", "mv_api.hip"]      # slowest translation units first
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
 
 
@@ -37,7 +38,8 @@ def _stale(target: str, deps) -> bool:
 def build(force: bool = False, verbose: bool = False) -> str:
     hipcc = _hipcc()
     os.makedirs(OBJ, exist_ok=True)
-    headers = [os.path.join(CSRC, "mv_common.h"), os.path.join(CSRC, "mv_gemm_common.h"), os.path.join(os.path.dirname(HERE), "include", "medvill.h")]
+    headers = [os.path.join(CSRC, "mv_common.h"), os.path.join(CSRC, "mv_gemm_common.h"), os.path.join(CSRC, "mv_gemm_ring.h"),
+               os.path.join(os.path.dirname(HERE), "include", "medvill.h")]
     jobs = []
     for s in SOURCES:
         src = os.path.join(CSRC, s)
@@ -55,7 +57,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
             raise RuntimeError(f"hipcc failed on {src}:\n{r.stderr[-4000:]}")
         return obj
 
-    with ThreadPoolExecutor(max_workers=6) as ex:
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 4)) as ex:
         list(ex.map(cc, jobs))
     objs = [os.path.join(OBJ, s.replace(".hip", ".o")) for s in SOURCES]
     if force or jobs or _stale(LIB, objs):

@@ -29,7 +29,7 @@ PROTOTYPES = {
     "mv_build_info": [],
     "mv_set_gemm_variant": [i32, i32],
     "mv_gemm": [i32, i32, i32, i32, i32, i32, vp, i32, vp, i32, vp, i32, i32, vp, i32, vp, i32, i32, vp, i32, vp, i32, i32,
-                i32, vp, sz, i32, f32, u64, vp],
+                i32, vp, sz, i32, f32, u64, vp, vp],
     "mv_mask_pack": [vp, i32, i32, i32, vp, vp, vp],
     "mv_mask_build": [vp, i32, i32, vp, vp, vp],
     "mv_mlm_draws": [u64, i32, i32, i32, vp, vp, vp],
@@ -38,16 +38,16 @@ PROTOTYPES = {
     "mv_attn_fwd": [i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, u64, vp, i32, vp],
     "mv_attn_bwd": [i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, u64, vp, i32, vp],
     "mv_layernorm_fwd": [i32, vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, f32, vp],
-    "mv_layernorm_bwd": [i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, f32, u64, vp],
+    "mv_layernorm_bwd": [i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, f32, u64, vp, vp],
     "mv_embed_fwd": [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, f32,
                      u64, vp, i32, vp],
     "mv_embed_bwd": [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32,
-                     u64, vp, i32, vp],
+                     u64, vp, i32, vp, vp],
     "mv_dropout_mask": [f32, u64, sz, vp, C.POINTER(C.c_float), vp],
-    "mv_ce_fwd_bwd": [vp, i32, i32, vp, i32, i32, vp, vp, i32, i32, vp, f32, vp],
+    "mv_ce_fwd_bwd": [vp, i32, i32, vp, i32, i32, vp, vp, i32, i32, vp, f32, vp, vp],
     "mv_gather_rows": [i32, vp, i32, vp, i32, i32, vp, i32, vp],
     "mv_scatter_rows": [i32, vp, i32, vp, i32, i32, vp, i32, i32, vp],
-    "mv_colsum": [i32, vp, i32, i32, i32, vp, i32, vp],
+    "mv_colsum": [i32, vp, i32, i32, i32, vp, i32, vp, vp],
     "mv_add": [i32, vp, vp, vp, sz, vp],
     "mv_dact": [i32, i32, vp, vp, vp, sz, vp],
     "mv_cast2d": [vp, i32, i64, vp, i32, i64, i32, i32, vp],
@@ -60,7 +60,9 @@ PROTOTYPES = {
     "mv_bn_finalize": [vp, i32, i64, f32, f32, vp, vp, vp, vp, vp],
     "mv_bn_act": [i32, vp, i32, vp, vp, vp, vp, vp, vp, i64, i32, i32, vp],
     "mv_maxpool3x3s2": [i32, vp, vp, i32, i32, i32, i32, vp],
-    "mv_adamw_step": [vp, vp, vp, vp, vp, vp, sz, f32, f32, f32, f32, f32, i32, i32, f32, vp],
+    "mv_adamw_step": [vp, vp, vp, vp, vp, vp, sz, f32, f32, f32, f32, f32, i32, i32, f32, vp, vp],
+    "mv_count_nonfinite": [vp, sz, vp, vp],
+    "mv_scaler_update": [vp, i32, f32, f32, f32, f32, vp],
 }
 _RESTYPE = {"mv_set_impl": None, "mv_set_gemm_variant": None, "mv_build_info": C.c_char_p}
 
@@ -85,7 +87,7 @@ def load(build_if_missing: bool = False):
         fn = getattr(lib, name)          # AttributeError if an exported symbol is missing
         fn.argtypes = args
         fn.restype = _RESTYPE.get(name, C.c_int)
-    if lib.mv_abi_version() != 2:
+    if lib.mv_abi_version() != 3:
         raise RuntimeError("libmedvill_hip.so ABI version mismatch")
     _lib = lib
     return lib

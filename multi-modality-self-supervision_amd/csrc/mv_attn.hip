@@ -211,10 +211,10 @@ __device__ __forceinline__ dma_rsrc_t dma_rsrc(const void* p, unsigned bytes) { 
   return (dma_rsrc_t){(int)(unsigned)v, (int)((unsigned)(v >> 32) & 0xffffu), (int)bytes, 0x00020000};
 }
 __device__ __forceinline__ void lds_dma16(dma_rsrc_t rs, MV_LDS void* dst, unsigned voff) {   // dst: wave-uniform, lane i lands at +16 i
-  asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"((unsigned)(uintptr_t)dst), "v"(voff), "s"(rs) : "memory");
+  asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"((unsigned)(uintptr_t)dst), "v"(voff), "s"(rs) : "memory", "m0");
 }
 __device__ __forceinline__ void lds_dma4(dma_rsrc_t rs, MV_LDS void* dst, unsigned voff) {
-  asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dword %1, %2, 0 offen lds" ::"s"((unsigned)(uintptr_t)dst), "v"(voff), "s"(rs) : "memory");
+  asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dword %1, %2, 0 offen lds" ::"s"((unsigned)(uintptr_t)dst), "v"(voff), "s"(rs) : "memory", "m0");
 }
 template <int NW>
 __device__ __forceinline__ void tile_dma(dma_rsrc_t rs, unsigned bytes, size_t rowbase, int row0, int nrows, int ld,
@@ -283,6 +283,17 @@ __device__ __forceinline__ bf16x8 pack8t(const f32x16& v, int s2) {
   } else {
     return pack8(v, s2);
   }
+}
+template <bool F16>
+__device__ __forceinline__ float frag_elem(bf16x8 v, int j) {
+  if constexpr (F16) return (float)__builtin_bit_cast(f16x8, v)[j];
+  else return (float)v[j];
+}
+template <bool F16>
+__device__ __forceinline__ void store4_16(bf16_t* p, float a, float b, float c, float d) {
+  const f32x4 v = {a, b, c, d};
+  if constexpr (F16) st4<f16_t>((f16_t*)p, v);
+  else st4<bf16_t>(p, v);
 }
 __device__ __forceinline__ bf16x8 load_rowfrag_global(__amdgpu_buffer_rsrc_t rs, unsigned bytes, size_t row, bool ok, int ld,
                                                       int col) {
@@ -485,7 +496,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_mfma_kernel(AttnArgs a) {
 // One 64-key tile of the dQ pass for a wave's 32 queries.  MASKED: the tile needs its mask words (class 2; a ragged
 // TAIL tile is always run as masked), DROP: attention dropout is on -- compile-time, so the per-element loops are
 // straight-line code the scheduler can interleave with the MFMAs.
-template <bool MASKED, bool DROP, bool TAIL>
+template <bool MASKED, bool DROP, bool TAIL, bool F16>
 __device__ __forceinline__ void dq_tile(const AttnArgs& a, const char* tK, const char* tV, const bf16x8 (&qf)[4], const bf16x8 (&dof)[4],
                                         f32x16 (&dq)[2], const uint32_t* myw, bool q_ok, int q, int b, int head, int k0, int Lv,
                                         float lse2, float dlt, float c2, int lane) {
@@ -499,8 +510,8 @@ __device__ __forceinline__ void dq_tile(const AttnArgs& a, const char* tK, const
     for (int i = 0; i < 16; ++i) { st[i] = 0.f; dp[i] = 0.f; }
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(tK, 32 * kk, s, l31, h), qf[s], st, 0, 0, 0);
-      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(tV, 32 * kk, s, l31, h), dof[s], dp, 0, 0, 0);
+      st = mma32<F16>(frag_row(tK, 32 * kk, s, l31, h), qf[s], st);
+      dp = mma32<F16>(frag_row(tV, 32 * kk, s, l31, h), dof[s], dp);
     }
     uint32_t w = 0xffffffffu;
     if (MASKED) { const int wi = (k0 >> 5) + kk; w = (q_ok && wi < a.W) ? myw[wi] : 0xffffffffu; }
@@ -527,15 +538,16 @@ __device__ __forceinline__ void dq_tile(const AttnArgs& a, const char* tK, const
     }
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
-      const bf16x8 dsf = pack8(st, s2);
+      const bf16x8 dsf = pack8t<F16>(st, s2);
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt)
-        dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(tK, 32 * dt, 32 * kk + 16 * s2, lane), dsf, dq[dt], 0, 0, 0);
+        dq[dt] = mma32<F16>(frag_tr(tK, 32 * dt, 32 * kk + 16 * s2, lane), dsf, dq[dt]);
     }
   }
 }
 
 #define DQ_NS 4       // 64 KiB of LDS per block, two blocks per CU (register-limited)
+template <bool F16>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_mfma_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
@@ -569,7 +581,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_mfma_kernel(AttnArgs a) {
     for (int s = 0; s < 4; ++s) {
       const bf16x8 of = load_rowfrag_global(rsc, a.bytes_ctx, rowbase + q, q_ok, H, head * 64 + 16 * s + 8 * h);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) dlt = fmaf((float)of[j], (float)dof[s][j], dlt);
+      for (int j = 0; j < 8; ++j) dlt = fmaf(frag_elem<F16>(of, j), frag_elem<F16>(dof[s], j), dlt);
     }
     dlt += __shfl_xor(dlt, 32, 64);
     if (q_ok && h == 0) a.delta_out[sidx] = dlt;
@@ -609,12 +621,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_mfma_kernel(AttnArgs a) {
       // one wave-uniform dispatch per tile: the element loops below contain no branches
       const int variant = (cls == 1 ? 0 : 1) | (a.drop.thr ? 2 : 0) | (tail ? 4 : 0);
       switch (variant) {
-        case 0: dq_tile<false, false, false>(a, tK, tV, qf, dof, dq, myw, q_ok, q, b, head, k0, Lv, lse2, dlt, c2, lane); break;
-        case 1: dq_tile<true, false, false>(a, tK, tV, qf, dof, dq, myw, q_ok, q, b, head, k0, Lv, lse2, dlt, c2, lane); break;
-        case 2: dq_tile<false, true, false>(a, tK, tV, qf, dof, dq, myw, q_ok, q, b, head, k0, Lv, lse2, dlt, c2, lane); break;
-        case 3: dq_tile<true, true, false>(a, tK, tV, qf, dof, dq, myw, q_ok, q, b, head, k0, Lv, lse2, dlt, c2, lane); break;
-        case 4: case 5: dq_tile<true, false, true>(a, tK, tV, qf, dof, dq, myw, q_ok, q, b, head, k0, Lv, lse2, dlt, c2, lane); break;
-        default: dq_tile<true, true, true>(a, tK, tV, qf, dof, dq, myw, q_ok, q, b, head, k0, Lv, lse2, dlt, c2, lane); break;
+        case 0: dq_tile<false, false, false, F16>(a, tK, tV, qf, dof, dq, myw, q_ok, q, b, head, k0, Lv, lse2, dlt, c2, lane); break;
+        case 1: dq_tile<true, false, false, F16>(a, tK, tV, qf, dof, dq, myw, q_ok, q, b, head, k0, Lv, lse2, dlt, c2, lane); break;
+        case 2: dq_tile<false, true, false, F16>(a, tK, tV, qf, dof, dq, myw, q_ok, q, b, head, k0, Lv, lse2, dlt, c2, lane); break;
+        case 3: dq_tile<true, true, false, F16>(a, tK, tV, qf, dof, dq, myw, q_ok, q, b, head, k0, Lv, lse2, dlt, c2, lane); break;
+        case 4: case 5: dq_tile<true, false, true, F16>(a, tK, tV, qf, dof, dq, myw, q_ok, q, b, head, k0, Lv, lse2, dlt, c2, lane); break;
+        default: dq_tile<true, true, true, F16>(a, tK, tV, qf, dof, dq, myw, q_ok, q, b, head, k0, Lv, lse2, dlt, c2, lane); break;
       }
     }
     if (ATT_ISSUE_LATE && iss < nkt) issue();
@@ -627,8 +639,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_mfma_kernel(AttnArgs a) {
   for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      bf16x4 v = {(bf16_t)dq[dt][4 * g], (bf16_t)dq[dt][4 * g + 1], (bf16_t)dq[dt][4 * g + 2], (bf16_t)dq[dt][4 * g + 3]};
-      *(bf16x4*)(orow + 32 * dt + 8 * g + 4 * h) = v;
+      store4_16<F16>(orow + 32 * dt + 8 * g + 4 * h, dq[dt][4 * g], dq[dt][4 * g + 1], dq[dt][4 * g + 2], dq[dt][4 * g + 3]);
     }
 }
 
@@ -637,7 +648,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_mfma_kernel(AttnArgs a) {
 #define KV_STAGE (8192 + 8192 + 256 + 256 + 1024)
 // One 64-query tile of the dK/dV pass for a wave's 32 keys (key on the lane).  MASKED: class-2 tile (mask words from LDS);
 // DROP: attention dropout on -- compile-time, so the element loops are branch-free.
-template <bool MASKED, bool DROP>
+template <bool MASKED, bool DROP, bool F16>
 __device__ __forceinline__ void dkv_tile(const AttnArgs& a, const char* tQ, const char* tD, const float* s_lse, const float* s_dl,
                                          const uint32_t* s_w, const bf16x8 (&kf)[4], const bf16x8 (&vf)[4], f32x16 (&dk)[2],
                                          f32x16 (&dv)[2], int b, int head, int cur, int key, int wid, float c2, int lane) {
@@ -650,8 +661,8 @@ __device__ __forceinline__ void dkv_tile(const AttnArgs& a, const char* tQ, cons
     for (int i = 0; i < 16; ++i) { sc[i] = 0.f; dp[i] = 0.f; }
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(tQ, 32 * qq, s, l31, h), kf[s], sc, 0, 0, 0);
-      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(tD, 32 * qq, s, l31, h), vf[s], dp, 0, 0, 0);
+      sc = mma32<F16>(frag_row(tQ, 32 * qq, s, l31, h), kf[s], sc);
+      dp = mma32<F16>(frag_row(tD, 32 * qq, s, l31, h), vf[s], dp);
     }
     f32x16& pv = dp;                          // P (dropped-out) overwrites dP element by element
 #pragma unroll
@@ -688,17 +699,18 @@ __device__ __forceinline__ void dkv_tile(const AttnArgs& a, const char* tQ, cons
     }
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
-      const bf16x8 pf = pack8(pv, s2);
-      const bf16x8 dsf = pack8(sc, s2);
+      const bf16x8 pf = pack8t<F16>(pv, s2);
+      const bf16x8 dsf = pack8t<F16>(sc, s2);
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt) {
-        dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(tD, 32 * dt, 32 * qq + 16 * s2, lane), pf, dv[dt], 0, 0, 0);
-        dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(tQ, 32 * dt, 32 * qq + 16 * s2, lane), dsf, dk[dt], 0, 0, 0);
+        dv[dt] = mma32<F16>(frag_tr(tD, 32 * dt, 32 * qq + 16 * s2, lane), pf, dv[dt]);
+        dk[dt] = mma32<F16>(frag_tr(tQ, 32 * dt, 32 * qq + 16 * s2, lane), dsf, dk[dt]);
       }
     }
   }
 }
 #define DKV_NS 4      // 70 KiB of LDS per block, two blocks per CU (register-limited)
+template <bool F16>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_mfma_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
@@ -775,10 +787,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_mfma_kernel(AttnArgs a) {
     if (wave_on && cls != 0) {
       const int variant = (cls == 1 ? 0 : 1) | (a.drop.thr ? 2 : 0);        // one wave-uniform dispatch per tile
       switch (variant) {
-        case 0: dkv_tile<false, false>(a, tQ, tD, s_lse, s_dl, s_w, kf, vf, dk, dv, b, head, cur, key, wid, c2, lane); break;
-        case 1: dkv_tile<true, false>(a, tQ, tD, s_lse, s_dl, s_w, kf, vf, dk, dv, b, head, cur, key, wid, c2, lane); break;
-        case 2: dkv_tile<false, true>(a, tQ, tD, s_lse, s_dl, s_w, kf, vf, dk, dv, b, head, cur, key, wid, c2, lane); break;
-        default: dkv_tile<true, true>(a, tQ, tD, s_lse, s_dl, s_w, kf, vf, dk, dv, b, head, cur, key, wid, c2, lane); break;
+        case 0: dkv_tile<false, false, F16>(a, tQ, tD, s_lse, s_dl, s_w, kf, vf, dk, dv, b, head, cur, key, wid, c2, lane); break;
+        case 1: dkv_tile<true, false, F16>(a, tQ, tD, s_lse, s_dl, s_w, kf, vf, dk, dv, b, head, cur, key, wid, c2, lane); break;
+        case 2: dkv_tile<false, true, F16>(a, tQ, tD, s_lse, s_dl, s_w, kf, vf, dk, dv, b, head, cur, key, wid, c2, lane); break;
+        default: dkv_tile<true, true, F16>(a, tQ, tD, s_lse, s_dl, s_w, kf, vf, dk, dv, b, head, cur, key, wid, c2, lane); break;
       }
     }
     if (ATT_ISSUE_LATE && iss < nqt) issue();
@@ -792,10 +804,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_mfma_kernel(AttnArgs a) {
   for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      bf16x4 v1 = {(bf16_t)dk[dt][4 * g], (bf16_t)dk[dt][4 * g + 1], (bf16_t)dk[dt][4 * g + 2], (bf16_t)dk[dt][4 * g + 3]};
-      bf16x4 v2 = {(bf16_t)dv[dt][4 * g], (bf16_t)dv[dt][4 * g + 1], (bf16_t)dv[dt][4 * g + 2], (bf16_t)dv[dt][4 * g + 3]};
-      *(bf16x4*)(krow + 32 * dt + 8 * g + 4 * h) = v1;
-      *(bf16x4*)(vrow + 32 * dt + 8 * g + 4 * h) = v2;
+      store4_16<F16>(krow + 32 * dt + 8 * g + 4 * h, dk[dt][4 * g], dk[dt][4 * g + 1], dk[dt][4 * g + 2], dk[dt][4 * g + 3]);
+      store4_16<F16>(vrow + 32 * dt + 8 * g + 4 * h, dv[dt][4 * g], dv[dt][4 * g + 1], dv[dt][4 * g + 2], dv[dt][4 * g + 3]);
     }
 }
 
@@ -1075,9 +1085,9 @@ extern "C" int mv_attn_bwd(int dtype, const void* qkv, const void* ctx, const vo
   const DropCfg drop = mv_make_drop(p_drop, drop_key);
   if (!qkv || !ctx || !dctx || !lse || !bits || !tileinfo || !dqkv || !delta || B <= 0 || L <= 0 || A <= 0 || dh <= 0)
     return MV_E_ARG;
-  if (dtype != MV_F32 && dtype != MV_BF16) return MV_E_DTYPE;
+  if (!mv_dtype_ok(dtype)) return MV_E_DTYPE;
   const int H = A * dh;
-  if (dtype == MV_BF16 && g_mv_impl == 0) {
+  if (mv_is16(dtype) && g_mv_impl == 0) {
     if (dh != 64) return MV_E_SHAPE;
     if (cu && (total_rows <= 0 || total_rows > B * L)) return MV_E_ARG;
     const size_t nrow = cu ? (size_t)total_rows : (size_t)B * L;
@@ -1094,18 +1104,23 @@ extern "C" int mv_attn_bwd(int dtype, const void* qkv, const void* ctx, const vo
     a.drop = drop; a.Lp = (L + 3) & ~3;
     static bool attr = false;
     if (!attr) {
-      (void)hipFuncSetAttribute((const void*)attn_bwd_dq_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DQ_NS * 16384);
-      (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DKV_NS * KV_STAGE);
+      (void)hipFuncSetAttribute((const void*)attn_bwd_dq_mfma_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, DQ_NS * 16384);
+      (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_mfma_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV_NS * KV_STAGE);
+      (void)hipFuncSetAttribute((const void*)attn_bwd_dq_mfma_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, DQ_NS * 16384);
+      (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_mfma_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV_NS * KV_STAGE);
       attr = true;
     }
     dim3 grid((L + 127) / 128, A, B);
-    hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel, grid, dim3(256), DQ_NS * 16384, stream, a);
+    if (dtype == MV_F16) hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel<true>, grid, dim3(256), DQ_NS * 16384, stream, a);
+    else hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel<false>, grid, dim3(256), DQ_NS * 16384, stream, a);
     MV_CHECK_LAUNCH();
-    hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel, grid, dim3(256), DKV_NS * KV_STAGE, stream, a);
+    if (dtype == MV_F16) hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel<true>, grid, dim3(256), DKV_NS * KV_STAGE, stream, a);
+    else hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel<false>, grid, dim3(256), DKV_NS * KV_STAGE, stream, a);
     MV_CHECK_LAUNCH();
     return MV_OK;
   }
   if (dh > 128 || cu) return MV_E_SHAPE;
+  if (dtype == MV_F16) return launch_simple_bwd<f16_t>(qkv, ctx, dctx, lse, bits, dqkv, delta, B, L, A, dh, drop, stream);
   return dtype == MV_F32 ? launch_simple_bwd<float>(qkv, ctx, dctx, lse, bits, dqkv, delta, B, L, A, dh, drop, stream)
                          : launch_simple_bwd<bf16_t>(qkv, ctx, dctx, lse, bits, dqkv, delta, B, L, A, dh, drop, stream);
 }

@@ -325,7 +325,7 @@ static inline bool aligned_to(const void* p, size_t a) { return p == nullptr || 
 extern "C" int mv_gemm(int dtype, int ta, int tb, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
                        void* C, int ldc, int c_dtype, const float* bias, int epi, const void* R, int ldr, int r_dtype,
                        void* C2, int ldc2, void* C3, int ldc3, int c3_dtype, int splitk, float* ws, size_t ws_bytes,
-                       int accumulate, float p_drop, unsigned long long drop_key, void* stream_) {
+                       int accumulate, float p_drop, unsigned long long drop_key, const float* alpha_dev, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) return MV_E_ARG;
   if (!mv_dtype_ok(dtype) || !mv_dtype_ok(c_dtype)) return MV_E_DTYPE;
@@ -345,12 +345,13 @@ extern "C" int mv_gemm(int dtype, int ta, int tb, int M, int N, int K, const voi
   if (splitk > 1) {
     if (!ws || ws_bytes < (size_t)splitk * M * N * sizeof(float)) return MV_E_WORKSPACE;
   }
+  if (alpha_dev && (epi != MV_EPI_NONE || c_dtype != MV_F32 || C3)) return MV_E_ARG;
   if (splitk == 0 && (!mv_is16(dtype) || g_mv_impl != 0)) splitk = 1;   // auto split-K only on the MFMA kernels
   GemmArgs p;
   p.A = A; p.B = B; p.C = C; p.C2 = C2; p.bias = bias; p.R = R; p.C3 = C3;
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldc2 = ldc2; p.ldr = ldr; p.ldc3 = ldc3;
   p.c_dtype = c_dtype; p.r_dtype = r_dtype; p.c3_dtype = c3_dtype; p.epi = epi; p.accumulate = accumulate;
-  p.splitk = splitk; p.ws = ws; p.dbg = g_mv_gemm_dbg;
+  p.splitk = splitk; p.ws = ws; p.dbg = g_mv_gemm_dbg; p.alpha = alpha_dev;
   p.drop = mv_make_drop(epi == MV_EPI_BIAS_RES ? p_drop : 0.f, drop_key);
   if (p.drop.thr && (N & 3)) return MV_E_SHAPE;   // the mask is keyed on groups of 4 consecutive columns
   const size_t csz = (c_dtype == MV_F32) ? 16 : 8;
@@ -365,7 +366,7 @@ extern "C" int mv_gemm(int dtype, int ta, int tb, int M, int N, int K, const voi
               ((epi != MV_EPI_BIAS_GELU && epi != MV_EPI_BIAS_GELU_D) || (((ldc2 & 7) == 0) && aligned_to(C2, 16))) && ((N & 3) == 0);
   const bool mfma = mv_is16(dtype) && (g_mv_impl == 0);
   const bool f16 = dtype == MV_F16;
-  if (mfma && f16 && (ta || tb)) return MV_E_DTYPE;   // f16 operands exist for the forward form y = x.W^T only
+  if (mfma && f16 && ta && !tb) return MV_E_DTYPE;    // f16 operands: y = x.W^T, dx = dy.W and dW = dy^T.x
   if (mfma) {
     if ((lda & 7) || (ldb & 7) || !aligned_to(A, 16) || !aligned_to(B, 16)) return MV_E_SHAPE;
     const size_t bytesA = ((size_t)((ta ? K : M) - 1) * lda + (size_t)(((ta ? M : K) + 7) & ~7)) * 2;
@@ -462,19 +463,26 @@ extern "C" int mv_gemm(int dtype, int ta, int tb, int M, int N, int K, const voi
       // one LDS stage and three blocks per CU by default (10-15 % faster on the model's 768-column GEMMs at ~25k rows:
       // profiles/r01_gemm_variants.txt); the two-stage form stays reachable for cross-checks (mv_set_gemm_variant(., 32))
       const bool sb = g_mv_gemm_nj != 32;
-      if (f16) {
-        static bool attr_h = false;
-        if (!attr_h) {
-          (void)hipFuncSetAttribute((const void*)gemm_mfma_kernel<false, false, false, true, true>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, GT_STAGE_BYTES);
-          attr_h = true;
-        }
-        hipLaunchKernelGGL((gemm_mfma_kernel<false, false, false, true, true>), grid, block, GT_STAGE_BYTES, stream, p);
+#define LAUNCH_MFMA_H(TA_, TB_)                                                                            \
+  do {                                                                                                     \
+    static bool attr_h = false;                                                                            \
+    if (!attr_h) {                                                                                         \
+      (void)hipFuncSetAttribute((const void*)gemm_mfma_kernel<TA_, TB_, false, true, true>,                \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, GT_STAGE_BYTES);               \
+      attr_h = true;                                                                                       \
+    }                                                                                                      \
+    hipLaunchKernelGGL((gemm_mfma_kernel<TA_, TB_, false, true, true>), grid, block, GT_STAGE_BYTES, stream, p); \
+  } while (0)
+      if (f16) {        // f16-encoded operands: always the one-stage form
+        if (!ta && !tb) LAUNCH_MFMA_H(false, false);
+        else if (!ta && tb) LAUNCH_MFMA_H(false, true);
+        else LAUNCH_MFMA_H(true, true);
       }
       else if (!ta && !tb) { if (sb) LAUNCH_MFMA_SB(false, false); else LAUNCH_MFMA(false, false); }
       else if (!ta && tb) { if (sb) LAUNCH_MFMA_SB(false, true); else LAUNCH_MFMA(false, true); }
       else if (ta && tb) { if (sb) LAUNCH_MFMA_SB(true, true); else LAUNCH_MFMA(true, true); }
       else { if (sb) LAUNCH_MFMA_SB(true, false); else LAUNCH_MFMA(true, false); }
+#undef LAUNCH_MFMA_H
 #undef LAUNCH_MFMA_SB
 #undef LAUNCH_MFMA
     }

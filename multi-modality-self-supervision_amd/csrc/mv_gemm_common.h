@@ -15,6 +15,8 @@ struct GemmArgs {
   int kchunk, splitk;
   float* ws;
   unsigned bytesA, bytesB;
+  const float* alpha;   // nullable, MV_EPI_NONE with an f32 C only: C = *alpha * (A.B) (+ C when accumulating) -- 1 / loss scale of the
+                        // f16-gradient path, applied where a weight gradient is written (mv_gemm's alpha_dev)
   DropCfg drop;   // MV_EPI_BIAS_RES only: C = dropout(A.B + bias) + R
   int dbg;   // ablation bits (timing experiments only): 1 skip C stores, 2 skip operand loads, 4 skip LDS reads + MFMA
   // implicit convolution (mv_conv2d): A is an NHWC activation [B, cvH, cvW, cvC]; its logical row m = (b, oy, ox) and column
@@ -30,8 +32,9 @@ __device__ __forceinline__ void epilogue4_slow(const GemmArgs& p, int m, int n, 
   if (m >= p.M || nv <= 0) return;
   const size_t co = (size_t)m * p.ldc + n;
   const int lim = nv < 4 ? nv : 4;
+  const float al = p.alpha ? *p.alpha : 1.0f;
   for (int i = 0; i < lim; ++i) {
-    float x = v[i];
+    float x = v[i] * al;
     const int e = p.epi;
     float b = 0.f, r = 0.f;
     if (e == MV_EPI_BIAS || e == MV_EPI_BIAS_GELU || e == MV_EPI_BIAS_RES || e == MV_EPI_BIAS_TANH || e == MV_EPI_BIAS_GELU_D || e == MV_EPI_BIAS_RELU || e == MV_EPI_BIAS_RES_RELU) b = p.bias[n + i];
@@ -92,6 +95,7 @@ __device__ __forceinline__ void epilogue4v(const GemmArgs& p, int m, int n, f32x
   if (m >= p.M) return;
   const size_t co = (size_t)m * p.ldc + n;
   f32x4 o = v;
+  if (E == MV_EPI_NONE && p.alpha) o *= *p.alpha;
   if (E == MV_EPI_BIAS || E == MV_EPI_BIAS_GELU || E == MV_EPI_BIAS_RES || E == MV_EPI_BIAS_TANH || E == MV_EPI_BIAS_GELU_D || E == MV_EPI_BIAS_RELU || E == MV_EPI_BIAS_RES_RELU) o += b4;
   if (E == MV_EPI_BIAS_RES && p.drop.thr) o = mv_drop4(o, (size_t)m * p.N + n, p.drop);
   if (E == MV_EPI_DGELU) {
@@ -384,6 +388,15 @@ __device__ __forceinline__ bf16x8 g2_frag(const char* tile, int base, int l15, i
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 
-// launchers of the 256-row kernels (one translation unit per family)
-// variant: 14 = ring 256x256, 64-deep stages x2;  24 = persistent form;  f16: f16-encoded operands (NT form only)
-int mv_launch_ring(const GemmArgs& p, int ta, int tb, bool f16, int variant, int tiles, int splitk, int n_cu, hipStream_t stream);
+// launchers of the 256-row kernels: one translation unit per operand layout (mv_gemm_ring_{nt,nn,tn,tnn}.hip; they compile
+// in parallel).  variant: 14 = ring 256x256, 64-deep stages x2;  24 = persistent form;  f16: f16-encoded operands
+int mv_launch_ring_nt(const GemmArgs& p, bool f16, int variant, int tiles, int splitk, int n_cu, hipStream_t stream);    // y = x.W^T
+int mv_launch_ring_nn(const GemmArgs& p, bool f16, int variant, int tiles, int splitk, int n_cu, hipStream_t stream);    // dx = dy.W
+int mv_launch_ring_tn(const GemmArgs& p, bool f16, int variant, int tiles, int splitk, int n_cu, hipStream_t stream);    // dW = dy^T.x
+int mv_launch_ring_tnn(const GemmArgs& p, bool f16, int variant, int tiles, int splitk, int n_cu, hipStream_t stream);   // A^T.B^T (bf16 only)
+static inline int mv_launch_ring(const GemmArgs& p, int ta, int tb, bool f16, int variant, int tiles, int splitk, int n_cu, hipStream_t stream) {
+  if (!ta && !tb) return mv_launch_ring_nt(p, f16, variant, tiles, splitk, n_cu, stream);
+  if (!ta && tb) return mv_launch_ring_nn(p, f16, variant, tiles, splitk, n_cu, stream);
+  if (ta && tb) return mv_launch_ring_tn(p, f16, variant, tiles, splitk, n_cu, stream);
+  return mv_launch_ring_tnn(p, f16, variant, tiles, splitk, n_cu, stream);
+}

@@ -1,4 +1,6 @@
-// The 256-row LDS-DMA GEMM kernels (ring and persistent ring); see mv_gemm_common.h / mv_gemm.hip.
+// The 256-row LDS-DMA GEMM kernels (ring and persistent ring); see mv_gemm_common.h / mv_gemm.hip.  Templates only: the
+// instantiations and their launchers live in mv_gemm_ring_{nt,nn,tn,tnn}.hip, one translation unit per operand layout.
+#pragma once
 #include "mv_gemm_common.h"
 
 template <bool TA, bool TB, int NJ, int WN, int NSTAGE, int KS, bool F16 = false>
@@ -153,7 +155,7 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_ring_kernel(GemmArgs p) {
 // the next tile's MFMAs instead of in a chip-wide burst at the end of every round of tiles.
 #undef G2_RG
 #define G2_RG 2   // the persistent kernel keeps its issue cursor live across the epilogue: fewer registers to spare
-template <bool TA, bool TB, int NJ, int WN, int NSTAGE>
+template <bool TA, bool TB, int NJ, int WN, int NSTAGE, bool F16 = false>
 __global__ __launch_bounds__(128 * WN, 1) void gemm_pring_kernel(GemmArgs p, int units, int tiles) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int KS = 2;
@@ -253,7 +255,7 @@ __global__ __launch_bounds__(128 * WN, 1) void gemm_pring_kernel(GemmArgs p, int
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
-          for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < NJ; ++j) acc[i][j] = mma16<F16>(fb[j], fa[i], acc[i][j]);
       }
       ++cfs;
     }
@@ -282,17 +284,18 @@ __global__ __launch_bounds__(128 * WN, 1) void gemm_pring_kernel(GemmArgs p, int
 }
 
 
-#define LAUNCH_PRING(TA_, TB_, NJ_, WN_, NS_)                                                                        \
+
+#define LAUNCH_PRING(TA_, TB_, NJ_, WN_, NS_, F16_)                                                                  \
   do {                                                                                                               \
     constexpr size_t shm = (size_t)(NS_) * 2 * (16384 + ((WN_) * 16 * (NJ_) > 128 ? 16384 : 8192));                  \
     static bool attr_set = false;                                                                                    \
     if (!attr_set) {                                                                                                 \
-      (void)hipFuncSetAttribute((const void*)gemm_pring_kernel<TA_, TB_, NJ_, WN_, NS_>,                             \
+      (void)hipFuncSetAttribute((const void*)gemm_pring_kernel<TA_, TB_, NJ_, WN_, NS_, F16_>,                       \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);                               \
       attr_set = true;                                                                                               \
     }                                                                                                                \
     const int units = tiles * splitk;                                                                                \
-    hipLaunchKernelGGL((gemm_pring_kernel<TA_, TB_, NJ_, WN_, NS_>), dim3(units < n_cu ? units : n_cu),              \
+    hipLaunchKernelGGL((gemm_pring_kernel<TA_, TB_, NJ_, WN_, NS_, F16_>), dim3(units < n_cu ? units : n_cu),        \
                        dim3(128 * (WN_)), shm, stream, p, units, tiles);                                             \
   } while (0)
 #define LAUNCH_RING(TA_, TB_, NJ_, WN_, NS_, KS_, F16_)                                                              \
@@ -306,21 +309,3 @@ __global__ __launch_bounds__(128 * WN, 1) void gemm_pring_kernel(GemmArgs p, int
     }                                                                                                                \
     hipLaunchKernelGGL((gemm_ring_kernel<TA_, TB_, NJ_, WN_, NS_, KS_, F16_>), grid, dim3(128 * (WN_)), shm, stream, p); \
   } while (0)
-#define LAUNCH_RING_V(TA_, TB_)                                  \
-  do {                                                           \
-    if (variant == 24) LAUNCH_PRING(TA_, TB_, 4, 4, 2);          \
-    else LAUNCH_RING(TA_, TB_, 4, 4, 2, 2, false);               \
-  } while (0)
-
-int mv_launch_ring(const GemmArgs& p, int ta, int tb, bool f16, int variant, int tiles, int splitk, int n_cu, hipStream_t stream) {
-  dim3 grid(tiles, splitk);
-  if (f16) {
-    if (ta || tb) return MV_E_DTYPE;
-    LAUNCH_RING(false, false, 4, 4, 2, 2, true);
-  }
-  else if (!ta && !tb) LAUNCH_RING_V(false, false);
-  else if (!ta && tb) LAUNCH_RING_V(false, true);
-  else if (ta && tb) LAUNCH_RING_V(true, true);
-  else LAUNCH_RING_V(true, false);
-  return MV_OK;
-}

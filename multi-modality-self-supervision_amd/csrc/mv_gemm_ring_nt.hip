@@ -1,0 +1,13 @@
+// 256-row LDS-DMA GEMM kernels, operand layout: y = x.W^T (both operands k-contiguous).  See mv_gemm_ring.h.
+#include "mv_gemm_ring.h"
+
+int mv_launch_ring_nt(const GemmArgs& p, bool f16, int variant, int tiles, int splitk, int n_cu, hipStream_t stream) {
+  dim3 grid(tiles, splitk);
+  if (f16) {
+    LAUNCH_RING(false, false, 4, 4, 2, 2, true);
+  } else {
+    if (variant == 24) LAUNCH_PRING(false, false, 4, 4, 2, false);
+    else LAUNCH_RING(false, false, 4, 4, 2, 2, false);
+  }
+  return MV_OK;
+}

@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TD* __restrict__ dy, 
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ g, TD* __restrict__ dx, float* __restrict__ dgamma,
                                                      float* __restrict__ dbeta, float* __restrict__ colsum, int M, int H,
-                                                     TD* __restrict__ dx_drop, DropCfg drop) {
+                                                     TD* __restrict__ dx_drop, DropCfg drop, const float* __restrict__ gscale) {
   __shared__ float red[3][4][260];
   const int lane = threadIdx.x & 63, wl = threadIdx.x >> 6;
   f32x4 ag[NC], ab[NC], ac[NC];
@@ -129,9 +129,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TD* __restrict__ dy, 
     const int col = c0 + threadIdx.x;
     if (col < H) {
       const int t = threadIdx.x;
-      atomicAdd(dgamma + col, red[0][0][t] + red[0][1][t] + red[0][2][t] + red[0][3][t]);
-      atomicAdd(dbeta + col, red[1][0][t] + red[1][1][t] + red[1][2][t] + red[1][3][t]);
-      if (colsum) atomicAdd(colsum + col, red[2][0][t] + red[2][1][t] + red[2][2][t] + red[2][3][t]);
+      const float gs = gscale ? *gscale : 1.0f;       // 1 / loss scale: the f32 parameter gradients are kept unscaled
+      atomicAdd(dgamma + col, gs * (red[0][0][t] + red[0][1][t] + red[0][2][t] + red[0][3][t]));
+      atomicAdd(dbeta + col, gs * (red[1][0][t] + red[1][1][t] + red[1][2][t] + red[1][3][t]));
+      if (colsum) atomicAdd(colsum + col, gs * (red[2][0][t] + red[2][1][t] + red[2][2][t] + red[2][3][t]));
     }
     __syncthreads();
   }
@@ -158,7 +159,7 @@ extern "C" int mv_layernorm_fwd(int dtype, const void* x, int x_dtype, const flo
 
 extern "C" int mv_layernorm_bwd(int dtype, const void* dy, const void* x, int x_dtype, const float* mean, const float* rstd,
                                 const float* gamma, void* dx, float* dgamma, float* dbeta, float* colsum, int M, int H,
-                                void* dx_drop, float p_drop, unsigned long long drop_key, void* stream_) {
+                                void* dx_drop, float p_drop, unsigned long long drop_key, const float* grad_unscale_dev, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!dy || !x || !mean || !rstd || !gamma || !dx || !dgamma || !dbeta || M <= 0 || H <= 0) return MV_E_ARG;
   if ((H & 3) || H > MV_MAX_H) return MV_E_SHAPE;
@@ -167,11 +168,13 @@ extern "C" int mv_layernorm_bwd(int dtype, const void* dy, const void* x, int x_
   dim3 grid(blocks), block(256);
   const DropCfg drop = mv_make_drop(dx_drop ? p_drop : 0.f, drop_key);
   if (dx_drop && drop.thr == 0) dx_drop = nullptr;
-#define LNB(NC_) hipLaunchKernelGGL((ln_bwd_kernel<TX_, TD_, NC_>), grid, block, 0, stream, (const TD_*)dy, (const TX_*)x, mean, rstd, gamma, (TD_*)dx, dgamma, dbeta, colsum, M, H, (TD_*)dx_drop, drop)
+#define LNB(NC_) hipLaunchKernelGGL((ln_bwd_kernel<TX_, TD_, NC_>), grid, block, 0, stream, (const TD_*)dy, (const TX_*)x, mean, rstd, gamma, (TD_*)dx, dgamma, dbeta, colsum, M, H, (TD_*)dx_drop, drop, grad_unscale_dev)
   if (dtype == MV_F32 && x_dtype == MV_F32) { typedef float TX_; typedef float TD_; NC_DISPATCH(H, LNB); }
   else if (dtype == MV_BF16 && x_dtype == MV_F32) { typedef float TX_; typedef bf16_t TD_; NC_DISPATCH(H, LNB); }
   else if (dtype == MV_BF16 && x_dtype == MV_BF16) { typedef bf16_t TX_; typedef bf16_t TD_; NC_DISPATCH(H, LNB); }
   else if (dtype == MV_BF16 && x_dtype == MV_F16) { typedef f16_t TX_; typedef bf16_t TD_; NC_DISPATCH(H, LNB); }
+  else if (dtype == MV_F16 && x_dtype == MV_F32) { typedef float TX_; typedef f16_t TD_; NC_DISPATCH(H, LNB); }
+  else if (dtype == MV_F16 && x_dtype == MV_F16) { typedef f16_t TX_; typedef f16_t TD_; NC_DISPATCH(H, LNB); }
   else return MV_E_DTYPE;
 #undef LNB
   MV_CHECK_LAUNCH();
@@ -262,7 +265,8 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(EmbArgs a, const T* __re
                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
                                                         const float* __restrict__ g, float* __restrict__ dE, float* __restrict__ dP,
                                                         float* __restrict__ dTy, float* __restrict__ dgamma,
-                                                        float* __restrict__ dbeta, T* __restrict__ dimg, int pad_id, DropCfg drop) {
+                                                        float* __restrict__ dbeta, T* __restrict__ dimg, int pad_id, DropCfg drop,
+                                                        const float* __restrict__ gscale) {
   __shared__ float red[4][4][260];
   __shared__ __attribute__((aligned(16))) float rowbuf[4][MV_MAX_H];   // per-wave row, re-read lane-contiguously for the atomics
   const int lane = threadIdx.x & 63, wl = threadIdx.x >> 6, H = a.H;
@@ -270,6 +274,7 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(EmbArgs a, const T* __re
 #pragma unroll
   for (int i = 0; i < NC; ++i) { ag[i] = (f32x4){0, 0, 0, 0}; ab[i] = ag[i]; at0[i] = ag[i]; at1[i] = ag[i]; }
   const int M = a.n_rows;
+  const float gs = gscale ? *gscale : 1.0f;        // 1 / loss scale: table / LayerNorm gradients (f32) are kept unscaled
   for (int row = blockIdx.x * 4 + wl; row < M; row += gridDim.x * 4) {
     const int li = a.rowmap ? a.rowmap[row] : row;
     const int b = li / a.L, l = li - b * a.L;
@@ -314,7 +319,7 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(EmbArgs a, const T* __re
     float* pp = dP + (size_t)pos * H;
     float* ep = dE + (size_t)(tok >= 0 ? tok : 0) * H;
     for (int c = lane; c < H; c += 64) {
-      const float v = rowbuf[wl][c];
+      const float v = rowbuf[wl][c] * gs;
       atomicAdd(pp + c, v);
       if (do_e) atomicAdd(ep + c, v);
     }
@@ -331,10 +336,10 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(EmbArgs a, const T* __re
     __syncthreads();
     const int col = c0 + threadIdx.x, t = threadIdx.x;
     if (col < H) {
-      atomicAdd(dgamma + col, red[0][0][t] + red[0][1][t] + red[0][2][t] + red[0][3][t]);
-      atomicAdd(dbeta + col, red[1][0][t] + red[1][1][t] + red[1][2][t] + red[1][3][t]);
-      atomicAdd(dTy + col, red[2][0][t] + red[2][1][t] + red[2][2][t] + red[2][3][t]);
-      atomicAdd(dTy + H + col, red[3][0][t] + red[3][1][t] + red[3][2][t] + red[3][3][t]);
+      atomicAdd(dgamma + col, gs * (red[0][0][t] + red[0][1][t] + red[0][2][t] + red[0][3][t]));
+      atomicAdd(dbeta + col, gs * (red[1][0][t] + red[1][1][t] + red[1][2][t] + red[1][3][t]));
+      atomicAdd(dTy + col, gs * (red[2][0][t] + red[2][1][t] + red[2][2][t] + red[2][3][t]));
+      atomicAdd(dTy + H + col, gs * (red[3][0][t] + red[3][1][t] + red[3][2][t] + red[3][3][t]));
     }
     __syncthreads();
   }
@@ -376,7 +381,8 @@ extern "C" int mv_embed_bwd(int dtype, const void* dx0, const float* pre, const 
                             const int64_t* cls_tok, const int64_t* txt, const int64_t* segment, const int64_t* img_pos,
                             const int64_t* sep_tok, float* dE, float* dP, float* dTy, float* dgamma, float* dbeta, void* dimgproj,
                             int B, int N, int T, int H, int V, int maxpos, int pad_token_id, float p_drop,
-                            unsigned long long drop_key, const int32_t* rowmap, int n_rows, void* stream_) {
+                            unsigned long long drop_key, const int32_t* rowmap, int n_rows, const float* grad_unscale_dev,
+                            void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!dx0 || !pre || !mean || !rstd || !gamma || !cls_tok || !txt || !segment || !sep_tok || !dE || !dP || !dTy || !dgamma || !dbeta)
     return MV_E_ARG;
@@ -389,9 +395,10 @@ extern "C" int mv_embed_bwd(int dtype, const void* dx0, const float* pre, const 
   if (blocks > 1024) blocks = 1024;
   dim3 grid(blocks), block(256);
   const DropCfg drop = mv_make_drop(p_drop, drop_key);
-#define EMB(NC_) hipLaunchKernelGGL((embed_bwd_kernel<T_, NC_>), grid, block, 0, stream, a, (const T_*)dx0, pre, mean, rstd, gamma, dE, dP, dTy, dgamma, dbeta, (T_*)dimgproj, pad_token_id, drop)
+#define EMB(NC_) hipLaunchKernelGGL((embed_bwd_kernel<T_, NC_>), grid, block, 0, stream, a, (const T_*)dx0, pre, mean, rstd, gamma, dE, dP, dTy, dgamma, dbeta, (T_*)dimgproj, pad_token_id, drop, grad_unscale_dev)
   if (dtype == MV_F32) { typedef float T_; NC_DISPATCH(H, EMB); }
   else if (dtype == MV_BF16) { typedef bf16_t T_; NC_DISPATCH(H, EMB); }
+  else if (dtype == MV_F16) { typedef f16_t T_; NC_DISPATCH(H, EMB); }
   else return MV_E_DTYPE;
 #undef EMB
   MV_CHECK_LAUNCH();
@@ -406,7 +413,7 @@ extern "C" int mv_embed_bwd(int dtype, const void* dx0, const float* pre, const 
 template <typename TL, typename TD, int MAXPER>
 __global__ __launch_bounds__(256) void ce_kernel(const TL* __restrict__ logits, int ld, const int32_t* __restrict__ labels, int R,
                                                  int V, float* __restrict__ out, TD* __restrict__ dlogits, int ldd,
-                                                 const float* __restrict__ gs_dev, float gs_host) {
+                                                 const float* __restrict__ gs_dev, float gs_host, const float* __restrict__ ls_dev) {
   __shared__ float smax[4];
   __shared__ int sarg[4];
   __shared__ float ssum[4];
@@ -456,7 +463,7 @@ __global__ __launch_bounds__(256) void ce_kernel(const TL* __restrict__ logits, 
     if (am == label) atomicAdd(out + 2, 1.0f);
   }
   if (drow) {
-    const float gs = gs_dev ? *gs_dev : gs_host;
+    const float gs = (gs_dev ? *gs_dev : gs_host) * (ls_dev ? *ls_dev : 1.0f);   // x loss scale (16-bit gradients)
     const float inv = gs / s;
 #pragma unroll
     for (int n = 0; n < MAXPER; ++n) {
@@ -472,7 +479,7 @@ __global__ __launch_bounds__(256) void ce_kernel(const TL* __restrict__ logits, 
 template <typename TL, typename TD, int MAXV>
 __global__ __launch_bounds__(256) void ce_vec_kernel(const TL* __restrict__ logits, int ld, const int32_t* __restrict__ labels,
                                                      int R, int V, float* __restrict__ out, TD* __restrict__ dlogits, int ldd,
-                                                     const float* __restrict__ gs_dev, float gs_host) {
+                                                     const float* __restrict__ gs_dev, float gs_host, const float* __restrict__ ls_dev) {
   __shared__ float smax[4];
   __shared__ int sarg[4];
   __shared__ float ssum[4];
@@ -529,7 +536,7 @@ __global__ __launch_bounds__(256) void ce_vec_kernel(const TL* __restrict__ logi
     if (am == label) atomicAdd(out + 2, 1.0f);
   }
   if (drow) {
-    const float gs = gs_dev ? *gs_dev : gs_host;
+    const float gs = (gs_dev ? *gs_dev : gs_host) * (ls_dev ? *ls_dev : 1.0f);   // x loss scale (16-bit gradients)
     const float inv = gs / s;
 #pragma unroll
     for (int n = 0; n < MAXV; ++n) {
@@ -545,7 +552,8 @@ __global__ __launch_bounds__(256) void ce_vec_kernel(const TL* __restrict__ logi
 }
 
 extern "C" int mv_ce_fwd_bwd(const void* logits, int l_dtype, int ld, const int32_t* labels, int R, int V, float* out, void* dlogits,
-                             int d_dtype, int ldd, const float* grad_scale_dev, float grad_scale_host, void* stream_) {
+                             int d_dtype, int ldd, const float* grad_scale_dev, float grad_scale_host, const float* loss_scale_dev,
+                             void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!logits || !labels || !out || R <= 0 || V <= 0 || ld < V) return MV_E_ARG;
   if (V > 256 * CE_MAXPER) return MV_E_SHAPE;
@@ -554,8 +562,9 @@ extern "C" int mv_ce_fwd_bwd(const void* logits, int l_dtype, int ld, const int3
   const bool vec_ok = ((ld & 3) == 0) && (!dlogits || (ldd & 3) == 0) && ((((uintptr_t)logits) & 15) == 0) &&
                       (!dlogits || (((uintptr_t)dlogits) & 15) == 0) && V > 2048 && ldd <= 1024 * 32 && V <= 1024 * 32;
   if (vec_ok) {
-#define CEV_LAUNCH(TL, TD) hipLaunchKernelGGL((ce_vec_kernel<TL, TD, 32>), grid, block, 0, stream, (const TL*)logits, ld, labels, R, V, out, (TD*)dlogits, ldd, grad_scale_dev, grad_scale_host)
+#define CEV_LAUNCH(TL, TD) hipLaunchKernelGGL((ce_vec_kernel<TL, TD, 32>), grid, block, 0, stream, (const TL*)logits, ld, labels, R, V, out, (TD*)dlogits, ldd, grad_scale_dev, grad_scale_host, loss_scale_dev)
     if (l_dtype == MV_F32 && d_dtype == MV_F32) CEV_LAUNCH(float, float);
+    else if (l_dtype == MV_F32 && d_dtype == MV_F16) CEV_LAUNCH(float, f16_t);
     else if (l_dtype == MV_F32 && d_dtype == MV_BF16) CEV_LAUNCH(float, bf16_t);
     else if (l_dtype == MV_BF16 && d_dtype == MV_BF16) CEV_LAUNCH(bf16_t, bf16_t);
     else if (l_dtype == MV_BF16 && d_dtype == MV_F32) CEV_LAUNCH(bf16_t, float);
@@ -566,10 +575,11 @@ extern "C" int mv_ce_fwd_bwd(const void* logits, int l_dtype, int ld, const int3
   }
 #define CE_LAUNCH(TL, TD)                                                                                              \
   do {                                                                                                                 \
-    if (V <= 256 * 8) hipLaunchKernelGGL((ce_kernel<TL, TD, 8>), grid, block, 0, stream, (const TL*)logits, ld, labels, R, V, out, (TD*)dlogits, ldd, grad_scale_dev, grad_scale_host); \
-    else hipLaunchKernelGGL((ce_kernel<TL, TD, CE_MAXPER>), grid, block, 0, stream, (const TL*)logits, ld, labels, R, V, out, (TD*)dlogits, ldd, grad_scale_dev, grad_scale_host); \
+    if (V <= 256 * 8) hipLaunchKernelGGL((ce_kernel<TL, TD, 8>), grid, block, 0, stream, (const TL*)logits, ld, labels, R, V, out, (TD*)dlogits, ldd, grad_scale_dev, grad_scale_host, loss_scale_dev); \
+    else hipLaunchKernelGGL((ce_kernel<TL, TD, CE_MAXPER>), grid, block, 0, stream, (const TL*)logits, ld, labels, R, V, out, (TD*)dlogits, ldd, grad_scale_dev, grad_scale_host, loss_scale_dev); \
   } while (0)
   if (l_dtype == MV_F32 && d_dtype == MV_F32) CE_LAUNCH(float, float);
+  else if (l_dtype == MV_F32 && d_dtype == MV_F16) CE_LAUNCH(float, f16_t);
   else if (l_dtype == MV_F32 && d_dtype == MV_BF16) CE_LAUNCH(float, bf16_t);
   else if (l_dtype == MV_BF16 && d_dtype == MV_BF16) CE_LAUNCH(bf16_t, bf16_t);
   else if (l_dtype == MV_BF16 && d_dtype == MV_F32) CE_LAUNCH(bf16_t, float);
@@ -632,6 +642,7 @@ extern "C" int mv_scatter_rows(int dtype, const void* src, int lds_, const int32
   dim3 grid((R + 3) / 4), block(256);
   if (dtype == MV_F32) hipLaunchKernelGGL(scatter_rows_kernel<float>, grid, block, 0, stream, (const float*)src, lds_, rows, R, H, (float*)dst, ldd, accumulate);
   else if (dtype == MV_BF16) hipLaunchKernelGGL(scatter_rows_kernel<bf16_t>, grid, block, 0, stream, (const bf16_t*)src, lds_, rows, R, H, (bf16_t*)dst, ldd, accumulate);
+  else if (dtype == MV_F16) hipLaunchKernelGGL(scatter_rows_kernel<f16_t>, grid, block, 0, stream, (const f16_t*)src, lds_, rows, R, H, (f16_t*)dst, ldd, accumulate);
   else return MV_E_DTYPE;
   MV_CHECK_LAUNCH();
   return MV_OK;
@@ -640,7 +651,8 @@ extern "C" int mv_scatter_rows(int dtype, const void* src, int lds_, const int32
 // out[n] += sum_m x[m,n].  A block owns a strip of 128 (f32) / 256 (bf16) columns: 32 lanes x one 16-byte vector
 // per row, 8 row-lanes walking a slice of the rows, LDS reduction over the row-lanes, one atomic per column.
 template <typename T>
-__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, int ldx, int M, int N, float* __restrict__ out) {
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, int ldx, int M, int N, float* __restrict__ out,
+                                                     const float* __restrict__ gscale) {
   constexpr int VEC = 16 / sizeof(T);
   __shared__ float red[8][32 * VEC + 1];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -655,8 +667,9 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, in
     for (int r = r0 + ty; r < r1; r += 8) {
       const T* p = x + (size_t)r * ldx + col;
       if (vec) {
-        if (sizeof(T) == 2) {
-          const bf16x8 v = *(const bf16x8*)p;
+        if constexpr (sizeof(T) == 2) {
+          typedef __attribute__((ext_vector_type(8))) T t8;
+          const t8 v = *(const t8*)p;
 #pragma unroll
           for (int e = 0; e < VEC; ++e) acc[e] += (float)v[e];
         } else {
@@ -678,7 +691,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, in
       float s_ = 0.f;
 #pragma unroll
       for (int k = 0; k < 8; ++k) s_ += red[k][c];
-      atomicAdd(out + gc, s_);
+      atomicAdd(out + gc, gscale ? s_ * *gscale : s_);
     }
   }
 }
@@ -686,7 +699,8 @@ __global__ void zero_f32_kernel(float* p, size_t n) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = 0.f;
 }
 
-extern "C" int mv_colsum(int dtype, const void* x, int ldx, int M, int N, float* out, int accumulate, void* stream_) {
+extern "C" int mv_colsum(int dtype, const void* x, int ldx, int M, int N, float* out, int accumulate, const float* grad_unscale_dev,
+                         void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!x || !out || M <= 0 || N <= 0 || ldx < N) return MV_E_ARG;
   if (!accumulate) {
@@ -700,8 +714,9 @@ extern "C" int mv_colsum(int dtype, const void* x, int ldx, int M, int N, float*
   if (ysplit > want) ysplit = want;
   if (ysplit < 1) ysplit = 1;
   dim3 grid(xb, ysplit), block(256);
-  if (dtype == MV_F32) hipLaunchKernelGGL(colsum_kernel<float>, grid, block, 0, stream, (const float*)x, ldx, M, N, out);
-  else if (dtype == MV_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, block, 0, stream, (const bf16_t*)x, ldx, M, N, out);
+  if (dtype == MV_F32) hipLaunchKernelGGL(colsum_kernel<float>, grid, block, 0, stream, (const float*)x, ldx, M, N, out, grad_unscale_dev);
+  else if (dtype == MV_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, block, 0, stream, (const bf16_t*)x, ldx, M, N, out, grad_unscale_dev);
+  else if (dtype == MV_F16) hipLaunchKernelGGL(colsum_kernel<f16_t>, grid, block, 0, stream, (const f16_t*)x, ldx, M, N, out, grad_unscale_dev);
   else return MV_E_DTYPE;
   MV_CHECK_LAUNCH();
   return MV_OK;
@@ -740,6 +755,7 @@ extern "C" int mv_add(int dtype, const void* a, const void* b, void* c, size_t n
   if (blocks > 2048) blocks = 2048;
   if (dtype == MV_F32) hipLaunchKernelGGL(add_kernel<float>, dim3(blocks), dim3(256), 0, stream, (const float*)a, (const float*)b, (float*)c, n4);
   else if (dtype == MV_BF16) hipLaunchKernelGGL(add_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)c, n4);
+  else if (dtype == MV_F16) hipLaunchKernelGGL(add_kernel<f16_t>, dim3(blocks), dim3(256), 0, stream, (const f16_t*)a, (const f16_t*)b, (f16_t*)c, n4);
   else return MV_E_DTYPE;
   MV_CHECK_LAUNCH();
   return MV_OK;
@@ -765,6 +781,7 @@ extern "C" int mv_dact(int dtype, int mode, const void* dy, const void* z, void*
   if (blocks > 2048) blocks = 2048;
   if (dtype == MV_F32) hipLaunchKernelGGL(dact_kernel<float>, dim3(blocks), dim3(256), 0, stream, (const float*)dy, (const float*)z, (float*)out, n4, mode);
   else if (dtype == MV_BF16) hipLaunchKernelGGL(dact_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream, (const bf16_t*)dy, (const bf16_t*)z, (bf16_t*)out, n4, mode);
+  else if (dtype == MV_F16) hipLaunchKernelGGL(dact_kernel<f16_t>, dim3(blocks), dim3(256), 0, stream, (const f16_t*)dy, (const f16_t*)z, (f16_t*)out, n4, mode);
   else return MV_E_DTYPE;
   MV_CHECK_LAUNCH();
   return MV_OK;
@@ -795,6 +812,9 @@ extern "C" int mv_cast2d(const void* src, int src_dtype, long long lds_, void* d
     else if (src_dtype == MV_BF16 && dst_dtype == MV_F32) hipLaunchKernelGGL((cast2d_kernel<bf16_t, float>), grid, block, 0, stream, (const bf16_t*)sp, lds_, (float*)dp, ldd, nr, cols);
     else if (src_dtype == MV_F32 && dst_dtype == MV_F32) hipLaunchKernelGGL((cast2d_kernel<float, float>), grid, block, 0, stream, (const float*)sp, lds_, (float*)dp, ldd, nr, cols);
     else if (src_dtype == MV_BF16 && dst_dtype == MV_BF16) hipLaunchKernelGGL((cast2d_kernel<bf16_t, bf16_t>), grid, block, 0, stream, (const bf16_t*)sp, lds_, (bf16_t*)dp, ldd, nr, cols);
+    else if (src_dtype == MV_F32 && dst_dtype == MV_F16) hipLaunchKernelGGL((cast2d_kernel<float, f16_t>), grid, block, 0, stream, (const float*)sp, lds_, (f16_t*)dp, ldd, nr, cols);
+    else if (src_dtype == MV_F16 && dst_dtype == MV_F32) hipLaunchKernelGGL((cast2d_kernel<f16_t, float>), grid, block, 0, stream, (const f16_t*)sp, lds_, (float*)dp, ldd, nr, cols);
+    else if (src_dtype == MV_F16 && dst_dtype == MV_F16) hipLaunchKernelGGL((cast2d_kernel<f16_t, f16_t>), grid, block, 0, stream, (const f16_t*)sp, lds_, (f16_t*)dp, ldd, nr, cols);
     else return MV_E_DTYPE;
     MV_CHECK_LAUNCH();
   }
@@ -826,7 +846,7 @@ extern "C" int mv_transpose(int dtype, const void* src, long long lds_, void* ds
   if (!src || !dst || rows <= 0 || cols <= 0 || lds_ < cols || ldd < rows) return MV_E_ARG;
   dim3 grid((cols + 63) / 64, (rows + 63) / 64), block(256);
   if (grid.y > 65535) return MV_E_SHAPE;
-  if (dtype == MV_BF16) hipLaunchKernelGGL(transpose_kernel<bf16_t>, grid, block, 0, stream, (const bf16_t*)src, lds_, (bf16_t*)dst, ldd, rows, cols);
+  if (dtype == MV_BF16 || dtype == MV_F16) hipLaunchKernelGGL(transpose_kernel<bf16_t>, grid, block, 0, stream, (const bf16_t*)src, lds_, (bf16_t*)dst, ldd, rows, cols);   // 2-byte elements move as bits
   else if (dtype == MV_F32) hipLaunchKernelGGL(transpose_kernel<float>, grid, block, 0, stream, (const float*)src, lds_, (float*)dst, ldd, rows, cols);
   else return MV_E_DTYPE;
   MV_CHECK_LAUNCH();
@@ -854,6 +874,7 @@ extern "C" int mv_cast(const void* src, int src_dtype, void* dst, int dst_dtype,
   else if (src_dtype == MV_F16 && dst_dtype == MV_F32) hipLaunchKernelGGL((cast_kernel<f16_t, float>), dim3(blocks), dim3(256), 0, stream, (const f16_t*)src, (float*)dst, n);
   else if (src_dtype == MV_F16 && dst_dtype == MV_BF16) hipLaunchKernelGGL((cast_kernel<f16_t, bf16_t>), dim3(blocks), dim3(256), 0, stream, (const f16_t*)src, (bf16_t*)dst, n);
   else if (src_dtype == MV_BF16 && dst_dtype == MV_F16) hipLaunchKernelGGL((cast_kernel<bf16_t, f16_t>), dim3(blocks), dim3(256), 0, stream, (const bf16_t*)src, (f16_t*)dst, n);
+  else if (src_dtype == MV_F16 && dst_dtype == MV_F16) hipLaunchKernelGGL((cast_kernel<f16_t, f16_t>), dim3(blocks), dim3(256), 0, stream, (const f16_t*)src, (f16_t*)dst, n);
   else return MV_E_DTYPE;
   MV_CHECK_LAUNCH();
   return MV_OK;
@@ -862,9 +883,29 @@ extern "C" int mv_cast(const void* src, int src_dtype, void* dst, int dst_dtype,
 // =========================================================================================
 // fused HF AdamW over the flat parameter buffer  (train_origin.py:60,131)
 // =========================================================================================
+// Device-resident state of the dynamic loss scale of the f16-gradient path (f32 [8]); written only by mv_scaler_update:
+//   [0] loss scale S the NEXT backward multiplies its loss gradients by      [1] 1 / S (what the f32 gradient writers multiply by)
+//   [2] clean steps since S last changed      [3] 1.0 = the step just finished overflowed: the optimizer must skip it
+//   [4] number of optimizer steps applied so far (t of the bias correction)   [5] number of skipped steps
+//   [6] non-finite gradient elements counted since the last update (mv_count_nonfinite adds, mv_scaler_update clears)
+#define MV_LS_SCALE 0
+#define MV_LS_INV 1
+#define MV_LS_GOOD 2
+#define MV_LS_SKIP 3
+#define MV_LS_T 4
+#define MV_LS_NSKIP 5
+#define MV_LS_NONFINITE 6
+
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, bf16_t* __restrict__ shadow, f16_t* __restrict__ shadow16,
-                                                    size_t n, float step_size, float b1, float b2, float eps, float lr_wd, float gscale) {
+                                                    size_t n, float step_size, float b1, float b2, float eps, float lr_wd, float gscale,
+                                                    const float* __restrict__ state, float lr, int correct_bias) {
+  if (state) {
+    if (state[MV_LS_SKIP] != 0.f) return;             // overflowed step: parameters, moments and shadows stay as they are
+    // t = steps applied so far + this one (mv_scaler_update has already counted it); HF's bias correction, in double like the host
+    const double t = (double)state[MV_LS_T];
+    step_size = correct_bias ? (float)((double)lr * sqrt(1.0 - pow((double)b2, t)) / (1.0 - pow((double)b1, t))) : lr;
+  }
   const size_t n4 = n / 4;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
     f32x4 pp = *(const f32x4*)(p + 4 * i), gg = *(const f32x4*)(g + 4 * i), mm = *(const f32x4*)(m + 4 * i), vv = *(const f32x4*)(v + 4 * i);
@@ -895,18 +936,78 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
 
 extern "C" int mv_adamw_step(float* p, const float* g, float* m, float* v, void* shadow_bf16, void* shadow_f16, size_t n, float lr,
                              float beta1, float beta2, float eps, float weight_decay, int step, int correct_bias, float grad_scale,
-                             void* stream_) {
+                             const float* scaler_state, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  if (!p || !g || !m || !v || n == 0 || step < 1) return MV_E_ARG;
+  if (!p || !g || !m || !v || n == 0 || (step < 1 && !scaler_state)) return MV_E_ARG;
   if ((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) return MV_E_SHAPE;
   if ((shadow_bf16 && (((uintptr_t)shadow_bf16) & 7)) || (shadow_f16 && (((uintptr_t)shadow_f16) & 7))) return MV_E_SHAPE;
   double ss = lr;
-  if (correct_bias) ss = ss * sqrt(1.0 - pow((double)beta2, step)) / (1.0 - pow((double)beta1, step));
+  if (correct_bias && !scaler_state) ss = ss * sqrt(1.0 - pow((double)beta2, step)) / (1.0 - pow((double)beta1, step));
   int blocks = (int)((n / 4 + 255) / 256);
   if (blocks > 4096) blocks = 4096;
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(256), 0, stream, p, g, m, v, (bf16_t*)shadow_bf16, (f16_t*)shadow_f16, n, (float)ss, beta1, beta2, eps,
-                     lr * weight_decay, grad_scale);
+                     lr * weight_decay, grad_scale, scaler_state, lr, correct_bias);
+  MV_CHECK_LAUNCH();
+  return MV_OK;
+}
+
+// =========================================================================================
+// dynamic loss scale of the f16-gradient path (no counterpart in the fp32 reference: its gradients never leave f32)
+// =========================================================================================
+// counter += number of elements of x that are inf or nan (one pass at HBM speed over the flat gradient)
+__global__ __launch_bounds__(256) void count_nonfinite_kernel(const float* __restrict__ x, size_t n, float* __restrict__ counter) {
+  const size_t n4 = n / 4;
+  int bad = 0;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const u32x4 v = *(const u32x4*)(x + 4 * i);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bad += ((v[e] & 0x7f800000u) == 0x7f800000u) ? 1 : 0;      // exponent all ones: inf or nan
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const unsigned u = __float_as_uint(x[n4 * 4 + threadIdx.x]);
+    bad += ((u & 0x7f800000u) == 0x7f800000u) ? 1 : 0;
+  }
+  if (__any(bad != 0)) {
+    const float s = wave_sum((float)bad);
+    if ((threadIdx.x & 63) == 0) atomicAdd(counter, s);
+  }
+}
+extern "C" int mv_count_nonfinite(const float* x, size_t n, float* counter, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!x || !counter || n == 0) return MV_E_ARG;
+  if (((uintptr_t)x) & 15) return MV_E_SHAPE;
+  int blocks = (int)((n / 4 + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(count_nonfinite_kernel, dim3(blocks), dim3(256), 0, stream, x, n, counter);
+  MV_CHECK_LAUNCH();
+  return MV_OK;
+}
+
+__global__ void scaler_update_kernel(float* __restrict__ st, int growth_interval, float growth, float backoff, float max_scale, float min_scale) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float scale = st[MV_LS_SCALE], good = st[MV_LS_GOOD];
+  if (st[MV_LS_NONFINITE] > 0.f) {
+    st[MV_LS_SKIP] = 1.f;
+    st[MV_LS_NSKIP] += 1.f;
+    scale = fmaxf(scale * backoff, min_scale);
+    good = 0.f;
+  } else {
+    st[MV_LS_SKIP] = 0.f;
+    st[MV_LS_T] += 1.f;
+    good += 1.f;
+    if (growth_interval > 0 && good >= (float)growth_interval) { scale = fminf(scale * growth, max_scale); good = 0.f; }
+  }
+  st[MV_LS_SCALE] = scale;
+  st[MV_LS_INV] = 1.0f / scale;
+  st[MV_LS_GOOD] = good;
+  st[MV_LS_NONFINITE] = 0.f;
+}
+extern "C" int mv_scaler_update(float* state, int growth_interval, float growth, float backoff, float max_scale, float min_scale, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!state || growth < 1.f || backoff <= 0.f || backoff > 1.f || min_scale <= 0.f || max_scale < min_scale) return MV_E_ARG;
+  hipLaunchKernelGGL(scaler_update_kernel, dim3(1), dim3(64), 0, stream, state, growth_interval, growth, backoff, max_scale, min_scale);
   MV_CHECK_LAUNCH();
   return MV_OK;
 }

@@ -59,7 +59,7 @@ class _CXRBertFn(torch.autograd.Function):
         return hidden.clone(), pooled.clone()
 
     @staticmethod
-    def backward(ctx, g0, g1=None):
+    def _backward_once(ctx, g0, g1):
         model = ctx.model
         eng = model.engine
         eng.zero_grad()
@@ -69,21 +69,42 @@ class _CXRBertFn(torch.autograd.Function):
             eng.heads_full_backward(g0, g1)
         else:
             S, H = eng.S, eng.cfg.hidden
+            ls = eng.loss_scale_dev          # f16 gradients: the incoming f32 gradients enter the chain multiplied by S
+            sc = (lambda t: t) if ls is None else (lambda t: t.float() * ls)
             dh = S["dhidden"] = eng._buf("dhidden", (S["M"], H), eng.adt)
-            dh.copy_(g0.reshape(S["M"], H)) if g0 is not None else dh.zero_()
+            dh.copy_(sc(g0.reshape(S["M"], H))) if g0 is not None else dh.zero_()
             if g1 is not None:
                 # pooled = tanh(hidden[:,0].Wp^T + bp)
                 from . import hip_ops as ops
                 B, Lq = S["B"], S["L"]
                 dpre = eng._buf("dpoolpre", (B, H), eng.adt)
-                ops.dact(1, g1.to(eng.adt).contiguous(), S["pooled"], dpre, B * H)
-                ops.colsum(dpre, H, B, H, eng.g["enc.pooler.dense.bias"], accumulate=True)
+                ops.dact(1, sc(g1).to(eng.adt).contiguous(), S["pooled"], dpre, B * H)
+                ops.colsum(dpre, H, B, H, eng.g["enc.pooler.dense.bias"], accumulate=True, unscale=eng.unscale_dev)
                 eng._dW(dpre, S["hidden"], eng.g["enc.pooler.dense.weight"], H, H, B, lda=H, ldb=Lq * H)
                 dh0 = eng._buf("dh0", (B, H), eng.adt)
                 ops.gemm(dpre, eng.w["enc.pooler.dense.weight"], dh0, tb=True, M=B, N=H, K=H)
                 rows0 = (torch.arange(B, device=eng.device, dtype=torch.int32) * Lq)
                 ops.scatter_rows(dh0, H, rows0, B, H, dh, H, accumulate=True)
         eng.encoder_backward()
+
+    @staticmethod
+    def backward(ctx, g0, g1=None):
+        model = ctx.model
+        eng = model.engine
+        _CXRBertFn._backward_once(ctx, g0, g1)
+        if eng.scaler is not None:
+            # f16 gradient operands under a loss scale: this path hands gradients to torch (an external optimizer), so an
+            # overflow cannot be turned into a skipped step -- the backward is redone with a smaller scale instead (the saved
+            # activations are still there).  One host sync per try; this is the drop-in path, not the fused training step.
+            for _ in range(8):
+                eng.scaler[6:7].zero_()
+                from . import hip_ops as ops
+                ops.count_nonfinite(eng.flat_g, eng.scaler[6:7])
+                if float(eng.scaler[6]) == 0.0:
+                    break
+                s_new = max(float(eng.scaler[0]) / 16.0, 1.0)
+                eng.reset_scaler(s_new)
+                _CXRBertFn._backward_once(ctx, g0, g1)
         grads = tuple(eng.g[n].clone() for n in model._param_names)
         return (None,) * 9 + grads
 
@@ -95,9 +116,9 @@ class _Sub(nn.Module):
 class CXRBERT(nn.Module):
     """Multimodal BERT: Masked Language Model + Image Text Matching (cxrbert_origin.py:132-149)."""
 
-    def __init__(self, config, args=None, dtype=torch.bfloat16, device=None, img_encoder=None, fwd_operand=None):
-        """dtype: torch.float32 (exact path) or torch.bfloat16 (16-bit MFMA path); fwd_operand: encoding of the forward
-        operands of the 16-bit path, "f16" (default) or "bf16" -- see engine.Engine."""
+    def __init__(self, config, args=None, dtype=torch.bfloat16, device=None, img_encoder=None, fwd_operand=None, grad_operand=None):
+        """dtype: torch.float32 (exact path) or torch.bfloat16 (16-bit MFMA path); fwd_operand / grad_operand: encodings of the
+        operands of the forward / gradient products of the 16-bit path ("f16" (default) or "bf16") -- see engine.Engine."""
         super().__init__()
         self.cfg = model_config_from(config)
         self.config = config
@@ -106,7 +127,7 @@ class CXRBERT(nn.Module):
             # the reference's disturbing_mask branch is shape-inconsistent and cannot run
             raise NotImplementedError("disturbing_mask model branch: use the non-cross MASK pattern with the standard branch")
         dev = torch.device(device) if device is not None else torch.device("cuda" if torch.cuda.is_available() else "cpu")
-        self.engine = Engine(self.cfg, dtype=dtype, device=dev, fwd_operand=fwd_operand)
+        self.engine = Engine(self.cfg, dtype=dtype, device=dev, fwd_operand=fwd_operand, grad_operand=grad_operand)
         if isinstance(img_encoder, str):
             if img_encoder.lower() not in ("resnet50", "cnn"):
                 raise NotImplementedError(f"img_encoder {img_encoder!r}: only the ResNet-50 region encoder is mirrored")

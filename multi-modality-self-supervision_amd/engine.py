@@ -114,37 +114,54 @@ ALIASES = {  # reference state-dict aliases -> canonical tensor (cxrbert_origin.
 
 class Engine:
     """dtype = torch.float32: the exact path (VALU kernels).  dtype = torch.bfloat16: the 16-bit MFMA path -- fp32 master
-    weights, accumulation, residual sums, LayerNorm / softmax statistics, losses and optimizer; every MFMA operand is 16
-    bits wide.  `fwd_operand` picks the ENCODING of the forward operands of that path:
-      "f16"  (default) weights and stored activations that feed a forward product (y = x.W^T, Q.K^T, P.V) are f16 (11-bit
-             significand); every gradient product keeps bf16 operands (8-bit exponent), so a forward activation that the
-             backward needs as a gradient-product operand is stored twice, written from the same registers.  Both
-             encodings run the same MFMA at the same rate.  This is the path that meets the 1e-2 logit tolerance at
-             BERT-base (profiles/r02_bf16_error.txt: with bf16-encoded forward operands the weight rounding alone is
-             1.4e-2 max-abs);
-      "bf16" one bf16 copy of everything (no duplicate activations; the round-1 behaviour)."""
+    weights, accumulation, LayerNorm / softmax statistics, losses and optimizer; every MFMA operand is 16 bits wide.
+    `fwd_operand` / `grad_operand` pick the ENCODING of the operands of the forward / gradient products of that path:
+      fwd "f16", grad "f16" (default)  ONE f16 copy (11-bit significand) of every weight and stored activation.  This is
+             the encoding that meets the 1e-2 logit tolerance at BERT-base (profiles/r02_bf16_error.txt: with bf16-encoded
+             forward operands the weight rounding alone is 1.4e-2 max-abs).  f16 gradients need a loss scale: the loss
+             gradients enter the chain multiplied by S, the kernels that write f32 parameter gradients multiply by 1/S, S
+             lives on the device and backs off when a step overflows (that step is skipped) -- `scaler` below;
+      fwd "f16", grad "bf16"  round 2's form: gradient products keep bf16 operands (8-bit exponent, no loss scale), so a
+             forward activation that the backward needs as a gradient-product operand is stored twice (+4.7 GB of writes
+             per step at the benchmark shape);
+      fwd "bf16", grad "bf16"  one bf16 copy of everything (round 1)."""
 
-    def __init__(self, cfg: ModelConfig, dtype=torch.bfloat16, device="cuda", fwd_operand=None):
+    def __init__(self, cfg: ModelConfig, dtype=torch.bfloat16, device="cuda", fwd_operand=None, grad_operand=None):
         if dtype not in (torch.float32, torch.bfloat16):
             raise TypeError("compute dtype must be float32 or bfloat16")
         if fwd_operand is None:
             fwd_operand = os.environ.get("MV_FWD_OPERAND", "f16")
         if fwd_operand not in ("f16", "bf16"):
             raise ValueError("fwd_operand must be 'f16' or 'bf16'")
+        if grad_operand is None:
+            grad_operand = os.environ.get("MV_GRAD_OPERAND", "f16" if fwd_operand == "f16" else "bf16")
+        if grad_operand not in ("f16", "bf16") or (grad_operand == "f16" and fwd_operand != "f16"):
+            raise ValueError("grad_operand must be 'f16' (with f16 forward operands) or 'bf16'")
         self.cfg = cfg
-        self.adt = dtype                 # encoding of gradients and of the activations the gradient products read
-        self.dt = MV_F32 if dtype == torch.float32 else MV_BF16
-        self.dual = self.dt == MV_BF16 and fwd_operand == "f16"
-        self.fadt = torch.float16 if self.dual else dtype       # encoding of the forward operands
-        self.fdt = MV_F16 if self.dual else self.dt
+        self.is16 = dtype != torch.float32
+        # encoding of gradients and of the activations the gradient products read
+        self.adt = torch.float32 if not self.is16 else (torch.float16 if grad_operand == "f16" else torch.bfloat16)
+        self.dt = MV_F32 if not self.is16 else (MV_F16 if grad_operand == "f16" else MV_BF16)
+        # encoding of the forward operands
+        self.fadt = torch.float32 if not self.is16 else (torch.float16 if fwd_operand == "f16" else torch.bfloat16)
+        self.fdt = MV_F32 if not self.is16 else (MV_F16 if fwd_operand == "f16" else MV_BF16)
+        self.dual = self.is16 and self.fdt != self.dt          # two encodings of every stored activation / weight
         self.device = torch.device(device)
         self.layout, self.n_flat = param_layout(cfg)
         self.flat_p = torch.zeros(self.n_flat, dtype=torch.float32, device=self.device)
         self.flat_g = None
         self.flat_m = None
         self.flat_v = None
-        self.shadow = torch.zeros(self.n_flat, dtype=torch.bfloat16, device=self.device) if self.dt == MV_BF16 else None
-        self.shadow_f = torch.zeros(self.n_flat, dtype=torch.float16, device=self.device) if self.dual else None
+        # 16-bit copies of the weights that the MFMA kernels read: bf16 and / or f16, whichever encodings are in use
+        self.shadow = torch.zeros(self.n_flat, dtype=torch.bfloat16, device=self.device) if MV_BF16 in (self.dt, self.fdt) else None
+        self.shadow_f = torch.zeros(self.n_flat, dtype=torch.float16, device=self.device) if MV_F16 in (self.dt, self.fdt) else None
+        # dynamic loss scale of the f16-gradient path: device state f32[8] (include/medvill.h, mv_scaler_update)
+        self.scaler = None
+        self.loss_scale_init = float(os.environ.get("MV_LOSS_SCALE", 2.0 ** 15))
+        self.scale_growth_interval = 2000
+        if self.dt == MV_F16:
+            self.scaler = torch.zeros(8, dtype=torch.float32, device=self.device)
+            self.reset_scaler()
         self.shadow_dirty = True
         self._ws = {}
         self._gemm_ws = {}             # split-K workspaces, one per stream that runs split-K GEMMs (never shared across streams)
@@ -171,12 +188,30 @@ class Engine:
         self.drop_counter = 0
         self._bind()
 
+    # ------------------------------------------------------------------ loss scale (f16 gradients)
+    def reset_scaler(self, scale=None):
+        if self.scaler is None:
+            return
+        s0 = float(scale if scale is not None else self.loss_scale_init)
+        self.scaler.copy_(torch.tensor([s0, 1.0 / s0, 0, 0, 0, 0, 0, 0], dtype=torch.float32))
+
+    @property
+    def loss_scale_dev(self):      # f32[1] device view: S (None when gradients are not f16)
+        return None if self.scaler is None else self.scaler[0:1]
+
+    @property
+    def unscale_dev(self):         # f32[1] device view: 1 / S
+        return None if self.scaler is None else self.scaler[1:2]
+
+    def _shadow_of(self, dt):
+        return self.flat_p if dt == MV_F32 else (self.shadow_f if dt == MV_F16 else self.shadow)
+
     # ------------------------------------------------------------------ storage
     def _bind(self):
-        # p: fp32 master weights; w: what the gradient products read (bf16 shadow); wf: what the forward products read
+        # p: fp32 master weights; w: what the gradient products read (16-bit shadow); wf: what the forward products read
         self.p, self.w, self.wf = {}, {}, {}
-        src_w = self.shadow if self.dt == MV_BF16 else self.flat_p
-        src_f = self.shadow_f if self.dual else src_w
+        src_w = self._shadow_of(self.dt)
+        src_f = self._shadow_of(self.fdt)
         for name, (off, shape) in self.layout.items():
             n = math.prod(shape)
             self.p[name] = self.flat_p[off:off + n].view(shape)
@@ -206,7 +241,7 @@ class Engine:
             self.wait_optimizer()          # an overlapped AdamW may still be writing the buffers that are copied below
             torch.cuda.current_stream().synchronize()
         # host storage is allowed (state-dict I/O); every kernel call requires device tensors and raises otherwise
-        for k in ("flat_p", "flat_g", "flat_m", "flat_v", "shadow", "shadow_f"):
+        for k in ("flat_p", "flat_g", "flat_m", "flat_v", "shadow", "shadow_f", "scaler"):
             t = getattr(self, k)
             if t is not None:
                 setattr(self, k, t.to(device))
@@ -220,9 +255,9 @@ class Engine:
     def sync_shadow(self):
         """16-bit path: refresh the copies the MFMA kernels read from the fp32 master weights."""
         self.wait_optimizer()
-        if self.dt == MV_BF16:
+        if self.shadow is not None:
             ops.cast(self.flat_p, self.shadow, self.n_flat)
-        if self.dual:
+        if self.shadow_f is not None:
             ops.cast(self.flat_p, self.shadow_f, self.n_flat)
         self.shadow_dirty = False
         self._w2t_stale = True
@@ -230,7 +265,7 @@ class Engine:
     def refresh_w2t(self, on_side=True):
         """Transposed bf16 copies of the FFN-down weights ([I, H] each) for the NT form of dz; enqueued on the side stream (idle
         outside the backward) so that the main stream only waits for an event at its first dz."""
-        if not (self.dz_nt and self.dt == MV_BF16):
+        if not (self.dz_nt and self.is16):
             return
         cfg = self.cfg
         H, I = cfg.hidden, cfg.intermediate
@@ -269,7 +304,7 @@ class Engine:
         bname = f"enc.encoder.layer.{l}.attention.self.query.bias"
         off, _ = self.layout[name]
         boff, _ = self.layout[bname]
-        src_w = (self.shadow_f if (fwd and self.dual) else self.shadow) if self.dt == MV_BF16 else self.flat_p
+        src_w = self._shadow_of(self.fdt if fwd else self.dt)
         W = src_w[off:off + 3 * H * H].view(3 * H, H)
         b = self.flat_p[boff:boff + 3 * H]
         gW = gb = None
@@ -335,9 +370,11 @@ class Engine:
     def _dW(self, dy, x, gW, No, Ko, Mtok, lda, ldb, ldc=None):
         # split-K is chosen by the library (splitk=0) from the tile grid and the workspace: up to 32 partial slabs for the small
         # [H, H] gradients (9 tiles of 256x256 need ~24 slabs to occupy the chip), 16 for the large ones
-        auto = self.dt == MV_BF16 and Mtok >= 2048 and No * Ko <= 4 * 1024 * 1024
+        auto = self.is16 and Mtok >= 2048 and No * Ko <= 4 * 1024 * 1024
         ws = self._gemm_workspace((32 if No * Ko <= 1024 * 1024 else 16) * No * Ko) if auto else None
-        ops.gemm(dy, x, gW, ta=True, tb=True, M=No, N=Ko, K=Mtok, lda=lda, ldb=ldb, ldc=ldc, splitk=self.dw_splitk if auto else 1, ws=ws)
+        # f16 gradients are loss-scaled: the weight gradient is un-scaled where it is written (alpha = 1 / S from the device)
+        ops.gemm(dy, x, gW, ta=True, tb=True, M=No, N=Ko, K=Mtok, lda=lda, ldb=ldb, ldc=ldc, splitk=self.dw_splitk if auto else 1, ws=ws,
+                 alpha=self.unscale_dev)
 
     # ------------------------------------------------------------------ encoder forward
     def encoder_forward(self, cls_tok, input_txt, attn_mask, segment, img_feats, img_pos, sep_tok, pack=False, tail_rows=None):
@@ -373,7 +410,7 @@ class Engine:
         f32 = torch.float32
         S = self.S = dict(B=B, T=T, N=N, L=Lq, M=M, cu=None, rowmap=None, inv=None, sel=None, n_lab=0)
         if pack:
-            if not isinstance(attn_mask, MaskDesc) or dt != MV_BF16:
+            if not isinstance(attn_mask, MaskDesc) or not self.is16:
                 raise ValueError("pack=True needs mask descriptors (data.MaskDesc) and the bf16 path")
             hd = attn_mask.host_desc()
             if not bool(((hd[:, 0] == 0) | (hd[:, 0] == 1) | (hd[:, 0] == 4)).all()):
@@ -472,7 +509,7 @@ class Engine:
                 a_["ctx_tail"] = ctx_sb
             a_["rows"] = Mr
             M_all, M = M, Mr        # (restored after the layer; nothing follows the last layer)
-            pre_dt = self.fadt if (self.dual and self.ln_in_16) else f32
+            pre_dt = self.fadt if (self.fdt == MV_F16 and self.ln_in_16) else f32
             pre1 = a_["pre1"] = self._buf(f"pre1_{l}" + ("h" if pre_dt != f32 else ""), (M, H), pre_dt)
             ops.gemm(ctx, wf[p + "attention.output.dense.weight"], pre1, M=M, N=H, K=H,
                      bias=self.p[p + "attention.output.dense.bias"], epi=EPI_BIAS_RES, r=x, p_drop=pd,
@@ -552,8 +589,8 @@ class Engine:
         cfg, H, V = self.cfg, self.cfg.hidden, self.cfg.vocab_size
         hs = self.S[tag]
         R, Vp = hs["R"], hs["Vp"]
-        g = self.g
-        ops.colsum(dlogits, Vp, R, V, g["mlm.predictions.bias"], accumulate=True)
+        g, us = self.g, self.unscale_dev
+        ops.colsum(dlogits, Vp, R, V, g["mlm.predictions.bias"], accumulate=True, unscale=us)
         # tied decoder: dE = dlogits^T . t  (the embedding scatter-add comes later, in embed_bwd).  360 tiles, no split-K, no
         # workspace: it runs on the side stream, which is idle until the encoder's backward starts; embed_bwd waits for it.
         main = torch.cuda.current_stream()
@@ -568,7 +605,7 @@ class Engine:
         if side is not main:
             dlogits.record_stream(side)     # a per-step allocation of the caller: not to be reused before the side stream has read it
         dt_ = self._buf(tag + "dt", (R, H), self.adt)
-        if self.dt == MV_BF16 and self.head_splitk and R * H <= 4 * 1024 * 1024:
+        if self.is16 and self.head_splitk and R * H <= 4 * 1024 * 1024:
             # dt = dlogits . E contracts over the vocabulary (K = 30,522) into a [R, 768] result: 156 tiles of 128x128 for the
             # ~3,300 labelled rows -- a fifth of the chip's tile slots, 477 K-steps each.  Split-K (partial sums in f32, one
             # reduction, one cast) spreads it over the whole chip.
@@ -580,16 +617,17 @@ class Engine:
             ops.gemm(dlogits, self.w["enc.txt_embeddings.word_embeddings.weight"], dt_, tb=True, M=R, N=H, K=V, lda=Vp, ldb=H)
         dtact = self._buf(tag + "dtact", (R, H), self.adt)
         ops.layernorm_bwd(dt_, hs["tact"], hs["mean"], hs["rstd"], self.p["mlm.predictions.transform.LayerNorm.weight"], dtact,
-                          g["mlm.predictions.transform.LayerNorm.weight"], g["mlm.predictions.transform.LayerNorm.bias"], None, R, H)
+                          g["mlm.predictions.transform.LayerNorm.weight"], g["mlm.predictions.transform.LayerNorm.bias"], None, R, H,
+                          unscale=us)
         # dtz = dtact * gelu'(tz); tz is f32, dtact compute dtype -> bring tz to compute dtype first
-        if self.dt == MV_BF16:
+        if self.is16:
             tzc = self._buf(tag + "tzc", (R, H), self.adt)
             ops.cast(hs["tz"], tzc, R * H)
         else:
             tzc = hs["tz"]
         dtz = self._buf(tag + "dtz", (R, H), self.adt)
         ops.dact(0, dtact, tzc, dtz, R * H)
-        ops.colsum(dtz, H, R, H, g["mlm.predictions.transform.dense.bias"], accumulate=True)
+        ops.colsum(dtz, H, R, H, g["mlm.predictions.transform.dense.bias"], accumulate=True, unscale=us)
         self._dW(dtz, hs["xr"], g["mlm.predictions.transform.dense.weight"], H, H, R, lda=H, ldb=H)
         dxr = self._buf(tag + "dxr", (R, H), self.adt)
         ops.gemm(dtz, self.w["mlm.predictions.transform.dense.weight"], dxr, tb=True, M=R, N=H, K=H)
@@ -599,14 +637,14 @@ class Engine:
         """ditm8 [B,8] compute dtype (cols 2..7 zero). Adds the pooler-path gradient into dhidden rows b*L."""
         S, H = self.S, self.cfg.hidden
         B, Lq = S["B"], S["L"]
-        g = self.g
-        ops.colsum(ditm8, 8, B, 2, g["itm.linear.bias"], accumulate=True)
+        g, us = self.g, self.unscale_dev
+        ops.colsum(ditm8, 8, B, 2, g["itm.linear.bias"], accumulate=True, unscale=us)
         self._dW(ditm8, S["pooled"], g["itm.linear.weight"], 2, H, B, lda=8, ldb=H)
         dpool = self._buf("dpool", (B, H), self.adt)
         ops.gemm(ditm8, self.w["itm.linear.weight"], dpool, tb=True, M=B, N=H, K=2, lda=8, ldb=H)
         dpre = self._buf("dpoolpre", (B, H), self.adt)
         ops.dact(1, dpool, S["pooled"], dpre, B * H)
-        ops.colsum(dpre, H, B, H, g["enc.pooler.dense.bias"], accumulate=True)
+        ops.colsum(dpre, H, B, H, g["enc.pooler.dense.bias"], accumulate=True, unscale=us)
         self._dW(dpre, S["h0"], g["enc.pooler.dense.weight"], H, H, B, lda=H, ldb=S["h0_ld"])
         dh0 = self._buf("dh0", (B, H), self.adt)
         ops.gemm(dpre, self.w["enc.pooler.dense.weight"], dh0, tb=True, M=B, N=H, K=H)
@@ -635,16 +673,19 @@ class Engine:
         self.S.setdefault("hf_", {})["Vp"] = Vp
         self.ensure_grad()
         dhid = S["dhidden"] = self._buf("dhidden", (M, H), self.adt)
+        ls = self.loss_scale_dev                # f16 gradients: the incoming f32 gradients enter the chain multiplied by S
         if dmlm is not None:
             dl = torch.empty((M, Vp), dtype=self.adt, device=self.device)
-            ops.cast2d(dmlm.contiguous().view(M, V).float(), V, dl, Vp, M, V)
+            d32 = dmlm.contiguous().view(M, V).float()
+            ops.cast2d(d32 if ls is None else d32 * ls, V, dl, Vp, M, V)
             dxr = self._mlm_backward(dl, "hf_")
             ops.cast(dxr, dhid, M * H)
         else:
             dhid.zero_()
         if ditm is not None:
             d8 = self._buf("ditm8", (B, 8), self.adt)
-            ops.cast2d(ditm.contiguous().float(), 2, d8, 8, B, 2)
+            i32_ = ditm.contiguous().float()
+            ops.cast2d(i32_ if ls is None else i32_ * ls, 2, d8, 8, B, 2)
             self._itm_backward(d8)
 
     # ------------------------------------------------------------------ training heads: labelled rows only
@@ -681,7 +722,7 @@ class Engine:
             Vp = logits.shape[1]
             dl = torch.empty((R, Vp), dtype=self.adt, device=self.device) if compute_grad else None
             ops.ce_fwd_bwd(logits, Vp, label_ids, R, V, stats[0:3], dl, Vp, grad_scale_dev=mlm_scale_dev,
-                           grad_scale=(mlm_scale if mlm_scale is not None else 1.0 / R))
+                           grad_scale=(mlm_scale if mlm_scale is not None else 1.0 / R), loss_scale_dev=self.loss_scale_dev)
             if compute_grad:
                 dxr = self._mlm_backward(dl, "ht_")
                 if compact:
@@ -691,7 +732,7 @@ class Engine:
         itm = self._itm_forward()
         d8 = self._buf("ditm8", (B, 8), self.adt) if compute_grad else None
         ops.ce_fwd_bwd(itm, 2, is_aligned, B, 2, stats[3:6], d8, 8, grad_scale_dev=itm_scale_dev,
-                       grad_scale=(itm_scale if itm_scale is not None else 1.0 / B))
+                       grad_scale=(itm_scale if itm_scale is not None else 1.0 / B), loss_scale_dev=self.loss_scale_dev)
         if compute_grad:
             self._itm_backward(d8)
         return stats
@@ -712,7 +753,7 @@ class Engine:
         H, A, I, D = cfg.hidden, cfg.heads, cfg.intermediate, cfg.img_hidden
         dh = H // A
         B, Lq, M, N, T = S["B"], S["L"], S["M"], S["N"], S["T"]
-        adt, g = self.adt, self.g
+        adt, g, us = self.adt, self.g, self.unscale_dev
         dy = S["dhidden"]
         main = torch.cuda.current_stream()
         if self._side is None:
@@ -732,7 +773,7 @@ class Engine:
 
         if bucket_hook:
             bucket_hook("heads", None)
-        use_w2t = self.dz_nt and self.dt == MV_BF16
+        use_w2t = self.dz_nt and self.is16
         if use_w2t:
             if self._w2t_stale or self._w2t is None:
                 self.refresh_w2t(on_side=False)
@@ -760,7 +801,7 @@ class Engine:
             # LN2 backward (+ bias grad of output.dense)
             ops.layernorm_bwd(dy, a_["pre2"], a_["mean2"], a_["rstd2"], self.p[p + "output.LayerNorm.weight"], dpre2,
                               g[p + "output.LayerNorm.weight"], g[p + "output.LayerNorm.bias"], g[p + "output.dense.bias"], M, H,
-                              dx_drop=dprd2, p_drop=pd, drop_key=dk[(self.SITE_OUT2, l)])
+                              dx_drop=dprd2, p_drop=pd, drop_key=dk[(self.SITE_OUT2, l)], unscale=us)
             dproj2 = dprd2 if dprd2 is not None else dpre2
             fork()
             with torch.cuda.stream(side):
@@ -771,14 +812,14 @@ class Engine:
                 ops.gemm(dproj2, self.w[p + "output.dense.weight"], dz, tb=True, M=M, N=I, K=H, epi=EPI_MUL, r=a_["dgelu"])
             fork()
             with torch.cuda.stream(side):
-                ops.colsum(dz, I, M, I, g[p + "intermediate.dense.bias"], accumulate=True)
+                ops.colsum(dz, I, M, I, g[p + "intermediate.dense.bias"], accumulate=True, unscale=us)
                 self._dW(dz, a_["a"], g[p + "intermediate.dense.weight"], I, H, M, lda=I, ldb=H)
             ops.gemm(dz, self.w[p + "intermediate.dense.weight"], da, tb=True, M=M, N=H, K=I, epi=EPI_RES, r=dpre2)
             # LN1 backward (+ bias grad of attention.output.dense)
             ops.layernorm_bwd(da, a_["pre1"], a_["mean1"], a_["rstd1"], self.p[p + "attention.output.LayerNorm.weight"], dpre1,
                               g[p + "attention.output.LayerNorm.weight"], g[p + "attention.output.LayerNorm.bias"],
                               g[p + "attention.output.dense.bias"], M, H, dx_drop=dprd1, p_drop=pd,
-                              drop_key=dk[(self.SITE_OUT1, l)])
+                              drop_key=dk[(self.SITE_OUT1, l)], unscale=us)
             dproj1 = dprd1 if dprd1 is not None else dpre1
             fork()
             with torch.cuda.stream(side):
@@ -797,7 +838,7 @@ class Engine:
                          drop_key=dk[(self.SITE_ATTN, l)])
             fork()
             with torch.cuda.stream(side):
-                ops.colsum(dqkv, 3 * H, M, 3 * H, gbqkv, accumulate=True)
+                ops.colsum(dqkv, 3 * H, M, 3 * H, gbqkv, accumulate=True, unscale=us)
                 self._dW(dqkv, a_["x"], gWqkv, 3 * H, H, M, lda=3 * H, ldb=H)
                 ev_layer = side_done()
             dx = dxb[l & 1]          # never the buffer dy currently lives in
@@ -820,18 +861,29 @@ class Engine:
                       self.p[e + "LayerNorm.weight"], S["cls_tok"], S["txt"], S["segment"], S["img_pos"], S["sep_tok"],
                       g[e + "word_embeddings.weight"], g[e + "position_embeddings.weight"], g[e + "token_type_embeddings.weight"],
                       g[e + "LayerNorm.weight"], g[e + "LayerNorm.bias"], dimg, B, N, T, H, cfg.vocab_size, cfg.max_pos,
-                      pad_token_id=0, p_drop=pd, drop_key=dk[(self.SITE_EMB, 0)], rowmap=S["rowmap"], n_rows=M)
+                      pad_token_id=0, p_drop=pd, drop_key=dk[(self.SITE_EMB, 0)], rowmap=S["rowmap"], n_rows=M, unscale=us)
         main.wait_stream(side)              # every weight gradient is final; the split-K workspace is ours again
         if N > 0:
-            ops.colsum(dimg, H, B * N, H, g["enc.img_embeddings.img_embeddings.bias"], accumulate=True)
+            ops.colsum(dimg, H, B * N, H, g["enc.img_embeddings.img_embeddings.bias"], accumulate=True, unscale=us)
             self._dW(dimg, S["feats"], g["enc.img_embeddings.img_embeddings.weight"], H, D, B * N, lda=H, ldb=D)
         if bucket_hook:
             bucket_hook("embeddings", None)
 
     # ------------------------------------------------------------------ optimizer
+    def check_overflow(self):
+        """f16-gradient path, after the backward (and the gradient all-reduce): count the non-finite elements of the flat
+        gradient and let the device-side scaler decide -- skip flag for the optimizer, loss scale of the next step.  No host
+        synchronisation; under data parallelism every rank sees the same all-reduced gradient and decides alike."""
+        if self.scaler is None:
+            return
+        ops.count_nonfinite(self.flat_g, self.scaler[6:7])
+        ops.scaler_update(self.scaler, growth_interval=self.scale_growth_interval)
+
     def adamw_step(self, step, lr=1e-5, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.0, correct_bias=True, grad_scale=1.0,
-                   overlap=False):
-        """HF AdamW over the flat buffer; also refreshes the 16-bit shadows.
+                   overlap=False, use_scaler=False):
+        """HF AdamW over the flat buffer; also refreshes the 16-bit shadows.  use_scaler (f16-gradient path, after
+        `check_overflow`): the kernels read the skip flag and the step count t from the device-side scaler state, so an
+        overflowed step changes nothing and does not advance the bias correction.
 
         overlap=False: one kernel on the current stream.  overlap=True: one kernel per contiguous parameter range in FORWARD
         order (embeddings, layer 0 .. L-1, heads) on the side stream, an event after each; the next `encoder_forward` makes the
@@ -839,10 +891,11 @@ class Engine:
         under the next step's first layers (MFMA-bound).  Anything else that reads parameters on the current stream must call
         `wait_optimizer()` first (CXRBERT.state_dict / save / load do)."""
         self.ensure_opt()
+        scaler_state = self.scaler if (use_scaler and self.scaler is not None) else None
         if not (overlap and self.device.type == "cuda" and os.environ.get("MV_SINGLE_STREAM") != "1"):
             self.wait_optimizer()
             ops.adamw_step(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.shadow, self.n_flat, lr, betas[0], betas[1], eps,
-                           weight_decay, step, correct_bias, grad_scale, shadow_f16=self.shadow_f)
+                           weight_decay, step, correct_bias, grad_scale, shadow_f16=self.shadow_f, scaler_state=scaler_state)
             self.shadow_dirty = False
             self.refresh_w2t()
             return
@@ -852,7 +905,7 @@ class Engine:
         main, side = torch.cuda.current_stream(), self.side_stream()
         side.wait_stream(main)                  # gradients (and their all-reduce, which the caller finished) are final
         evs = {}
-        use_w2t = self.dz_nt and self.dt == MV_BF16
+        use_w2t = self.dz_nt and self.is16
         if use_w2t and self._w2t is None:
             self._w2t = [torch.empty((cfg.intermediate, cfg.hidden), dtype=self.adt, device=self.device) for _ in range(cfg.layers)]
         with torch.cuda.stream(side):
@@ -862,7 +915,7 @@ class Engine:
                 ops.adamw_step(self.flat_p[sl], self.flat_g[sl], self.flat_m[sl], self.flat_v[sl],
                                None if self.shadow is None else self.shadow[sl], e_ - s_, lr, betas[0], betas[1], eps,
                                weight_decay, step, correct_bias, grad_scale,
-                               shadow_f16=None if self.shadow_f is None else self.shadow_f[sl])
+                               shadow_f16=None if self.shadow_f is None else self.shadow_f[sl], scaler_state=scaler_state)
                 if use_w2t and name.startswith("layer"):
                     l = int(name[5:])
                     ops.transpose(self.w[f"enc.encoder.layer.{l}.output.dense.weight"], self._w2t[l], cfg.hidden, cfg.intermediate)

@@ -15,10 +15,10 @@ def _lib():
 
 
 def gemm(a, b, c, *, ta=False, tb=False, M, N, K, lda=None, ldb=None, ldc=None, bias=None, epi=EPI_NONE, r=None, ldr=None,
-         c2=None, ldc2=None, c3=None, ldc3=None, splitk=1, ws=None, accumulate=False, p_drop=0.0, drop_key=0):
-    """c[M,N] = epi(op(a)[M,K] . op(b)[K,N]); c3 (optional): the same result in a second 16-bit encoding; see mv_gemm in
-    include/medvill.h."""
-    L.require_cuda(a, b, c, bias, r, c2, c3, ws)
+         c2=None, ldc2=None, c3=None, ldc3=None, splitk=1, ws=None, accumulate=False, p_drop=0.0, drop_key=0, alpha=None):
+    """c[M,N] = epi(op(a)[M,K] . op(b)[K,N]); c3 (optional): the same result in a second 16-bit encoding; alpha (optional,
+    f32 device scalar): factor on the product (weight gradients of the f16-gradient path); see mv_gemm in include/medvill.h."""
+    L.require_cuda(a, b, c, bias, r, c2, c3, ws, alpha)
     lda = lda if lda is not None else (M if ta else K)
     ldb = ldb if ldb is not None else (N if tb else K)
     ldc = ldc if ldc is not None else N
@@ -32,7 +32,7 @@ def gemm(a, b, c, *, ta=False, tb=False, M, N, K, lda=None, ldb=None, ldc=None, 
     rc = _lib().mv_gemm(L.dt_of(a), int(ta), int(tb), M, N, K, L.ptr(a), lda, L.ptr(b), ldb, L.ptr(c), ldc, L.dt_of(c),
                         L.ptr(bias), epi, L.ptr(r), ldr, L.dt_of(r) if r is not None else 0, L.ptr(c2), ldc2,
                         L.ptr(c3), ldc3, L.dt_of(c3) if c3 is not None else 0, splitk, L.ptr(ws), (ws.numel() * 4) if ws is not None else 0, int(accumulate), float(p_drop), int(drop_key),
-                        L.stream_ptr())
+                        L.ptr(alpha), L.stream_ptr())
     L.check(rc, f"mv_gemm(M={M},N={N},K={K},ta={ta},tb={tb},epi={epi})")
     return c
 
@@ -135,10 +135,10 @@ def layernorm_fwd(x, gamma, beta, y, mean, rstd, M, H, eps, y_bf16=None):
     L.check(rc, "mv_layernorm_fwd")
 
 
-def layernorm_bwd(dy, x, mean, rstd, gamma, dx, dgamma, dbeta, colsum, M, H, dx_drop=None, p_drop=0.0, drop_key=0):
+def layernorm_bwd(dy, x, mean, rstd, gamma, dx, dgamma, dbeta, colsum, M, H, dx_drop=None, p_drop=0.0, drop_key=0, unscale=None):
     rc = _lib().mv_layernorm_bwd(L.dt_of(dy), L.ptr(dy), L.ptr(x), L.dt_of(x), L.ptr(mean), L.ptr(rstd), L.ptr(gamma),
                                  L.ptr(dx), L.ptr(dgamma), L.ptr(dbeta), L.ptr(colsum), M, H, L.ptr(dx_drop), float(p_drop),
-                                 int(drop_key), L.stream_ptr())
+                                 int(drop_key), L.ptr(unscale), L.stream_ptr())
     L.check(rc, "mv_layernorm_bwd")
 
 
@@ -154,20 +154,20 @@ def embed_fwd(dt, cls_tok, txt, segment, img_pos, sep_tok, imgproj, E, P, Ty, ga
 
 
 def embed_bwd(dt, dx0, pre, mean, rstd, gamma, cls_tok, txt, segment, img_pos, sep_tok, dE, dP, dTy, dgamma, dbeta, dimgproj, B,
-              N, T, H, V, maxpos, pad_token_id=0, p_drop=0.0, drop_key=0, rowmap=None, n_rows=0):
+              N, T, H, V, maxpos, pad_token_id=0, p_drop=0.0, drop_key=0, rowmap=None, n_rows=0, unscale=None):
     rc = _lib().mv_embed_bwd(dt, L.ptr(dx0), L.ptr(pre), L.ptr(mean), L.ptr(rstd), L.ptr(gamma), L.ptr(cls_tok), L.ptr(txt),
                              L.ptr(segment), L.ptr(img_pos), L.ptr(sep_tok), L.ptr(dE), L.ptr(dP), L.ptr(dTy), L.ptr(dgamma),
                              L.ptr(dbeta), L.ptr(dimgproj), B, N, T, H, V, maxpos, int(pad_token_id), float(p_drop), int(drop_key),
-                             L.ptr(rowmap), int(n_rows), L.stream_ptr())
+                             L.ptr(rowmap), int(n_rows), L.ptr(unscale), L.stream_ptr())
     L.check(rc, "mv_embed_bwd")
 
 
-def ce_fwd_bwd(logits, ld, labels, R, V, out, dlogits=None, ldd=0, grad_scale_dev=None, grad_scale=1.0):
+def ce_fwd_bwd(logits, ld, labels, R, V, out, dlogits=None, ldd=0, grad_scale_dev=None, grad_scale=1.0, loss_scale_dev=None):
     if labels.dtype != torch.int32:
         raise TypeError("labels must be int32")
     rc = _lib().mv_ce_fwd_bwd(L.ptr(logits), L.dt_of(logits), ld, L.ptr(labels), R, V, L.ptr(out), L.ptr(dlogits),
                               L.dt_of(dlogits) if dlogits is not None else 0, ldd, L.ptr(grad_scale_dev), float(grad_scale),
-                              L.stream_ptr())
+                              L.ptr(loss_scale_dev), L.stream_ptr())
     L.check(rc, "mv_ce_fwd_bwd")
 
 
@@ -182,8 +182,8 @@ def scatter_rows(src, lds, rows, R, H, dst, ldd, accumulate=False):
     L.check(rc, "mv_scatter_rows")
 
 
-def colsum(x, ldx, M, N, out, accumulate=True):
-    rc = _lib().mv_colsum(L.dt_of(x), L.ptr(x), ldx, M, N, L.ptr(out), int(accumulate), L.stream_ptr())
+def colsum(x, ldx, M, N, out, accumulate=True, unscale=None):
+    rc = _lib().mv_colsum(L.dt_of(x), L.ptr(x), ldx, M, N, L.ptr(out), int(accumulate), L.ptr(unscale), L.stream_ptr())
     L.check(rc, "mv_colsum")
 
 
@@ -266,10 +266,27 @@ def cast2d(src, lds, dst, ldd, rows, cols):
     L.check(rc, "mv_cast2d")
 
 
-def adamw_step(p, g, m, v, shadow, n, lr, b1, b2, eps, wd, step, correct_bias=True, grad_scale=1.0, shadow_f16=None):
+def adamw_step(p, g, m, v, shadow, n, lr, b1, b2, eps, wd, step, correct_bias=True, grad_scale=1.0, shadow_f16=None, scaler_state=None):
     rc = _lib().mv_adamw_step(L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), L.ptr(shadow), L.ptr(shadow_f16), n, float(lr), float(b1), float(b2),
-                              float(eps), float(wd), int(step), int(correct_bias), float(grad_scale), L.stream_ptr())
+                              float(eps), float(wd), int(step), int(correct_bias), float(grad_scale), L.ptr(scaler_state), L.stream_ptr())
     L.check(rc, "mv_adamw_step")
+
+
+def count_nonfinite(x, counter):
+    """counter[0] += number of inf / nan elements of the f32 tensor x (device)."""
+    L.require_cuda(x, counter)
+    if x.dtype != torch.float32 or counter.dtype != torch.float32:
+        raise TypeError("count_nonfinite: f32 tensors")
+    rc = _lib().mv_count_nonfinite(L.ptr(x), x.numel(), L.ptr(counter), L.stream_ptr())
+    L.check(rc, "mv_count_nonfinite")
+
+
+def scaler_update(state, growth_interval=2000, growth=2.0, backoff=0.5, max_scale=2.0 ** 24, min_scale=1.0):
+    """Dynamic loss scale: consume the non-finite count in state[6], set the skip flag / step count, adapt the scale."""
+    L.require_cuda(state)
+    rc = _lib().mv_scaler_update(L.ptr(state), int(growth_interval), float(growth), float(backoff), float(max_scale), float(min_scale),
+                                 L.stream_ptr())
+    L.check(rc, "mv_scaler_update")
 
 
 def dropout_mask(p_drop, drop_key, n, device):

@@ -34,7 +34,7 @@ class CXRBertForRetrieval(nn.Module):
         on the valid rows only (inference form of the padding removal)."""
         from .data import MaskDesc
         eng = self.bert.engine
-        if isinstance(attn_mask, MaskDesc) and eng.adt == torch.bfloat16 and attn_mask.packable():
+        if isinstance(attn_mask, MaskDesc) and eng.is16 and attn_mask.packable():
             feats, pos = self.bert._regions(input_img)
             eng.training = False
             eng.encoder_forward(cls_tok, input_txt, attn_mask, segment, feats, pos, sep_tok, pack=True)

@@ -77,8 +77,10 @@ class TrainStep:
                 stats = self._run(batch, train, use_desc=False)
         if train:
             self.step_cnt += 1
+            # f16 gradients: overflow check of the (all-reduced) flat gradient, device-side skip / loss-scale decision
+            self.eng.check_overflow()
             self.eng.adamw_step(self.step_cnt, lr=self.lr, betas=self.betas, eps=self.eps, weight_decay=self.wd,
-                                overlap=self.overlap_optimizer)
+                                overlap=self.overlap_optimizer, use_scaler=True)
         return stats
 
     def sync(self):
@@ -105,7 +107,7 @@ class TrainStep:
             else:
                 eng.flat_g.zero_()
         desc = batch.get("attn_desc") if use_desc else None
-        pack = bool(self.pack_rows and desc is not None and eng.adt == torch.bfloat16 and desc.packable())
+        pack = bool(self.pack_rows and desc is not None and eng.is16 and desc.packable())
         mask = desc if desc is not None else batch["attn_mask"]      # descriptors when there are any: no [B,L,L] traffic
         # the last layer's per-row work runs only on the rows the heads consume (labelled rows + each sample's first row)
         eng.encoder_forward(batch["cls_tok"], batch["input_txt"], mask, batch["segment"],

@@ -44,14 +44,24 @@ GEMM_SHAPES = [(256, 256, 256), (130, 70, 200), (1024, 768, 768), (64, 2, 768), 
 VARIANT = {"mfma": (1, 0), "mfma2s": (1, 32), "mfma256k64": (2, 14), "pring256": (2, 24), "mfma_auto": (0, 0)}   # mv_set_gemm_variant(force, nj)
 
 
-@pytest.mark.parametrize("impl", ["mfma", "mfma2s", "mfma256k64", "pring256", "simple_bf16", "f32"])
+@pytest.mark.parametrize("impl", ["mfma", "mfma2s", "mfma256k64", "pring256", "simple_bf16", "f32", "mfma:f16", "mfma256k64:f16", "pring256:f16",
+                                  "mfma_auto:f16"])
 @pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 1), (1, 0)])
 @pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
 def test_gemm_layouts(impl, ta, tb, M, N, K):
-    dt = torch.float32 if impl == "f32" else torch.bfloat16
+    """All four operand layouts on every kernel family; ':f16' = f16-encoded operands (forward products and, under the loss
+    scale, the gradient products dx = dy.W and dW = dy^T.x; the fourth layout exists in bf16 only and is refused)."""
+    f16 = impl.endswith(":f16")
+    impl = impl.split(":")[0]
+    dt = torch.float32 if impl == "f32" else (torch.float16 if f16 else torch.bfloat16)
     ops.set_impl(1 if impl == "simple_bf16" else 0)
     ops.set_gemm_variant(*VARIANT.get(impl, (0, 0)))
     try:
+        if f16 and ta and not tb:
+            with pytest.raises(RuntimeError, match="MV_E_DTYPE"):       # refused, never silently computed in another encoding
+                z8 = torch.zeros((64, 64), dtype=dt, device=DEV)
+                ops.gemm(z8, z8, torch.zeros((8, 8), dtype=torch.float32, device=DEV), ta=True, tb=False, M=8, N=8, K=8, lda=64, ldb=64)
+            return
         pad = lambda n: (n + 7) // 8 * 8
         lda = pad(M if ta else K) + 8
         ldb = pad(N if tb else K) + 16
@@ -272,11 +282,12 @@ ATT_CASES = [("full", 2, 2, 16, 45), ("s2s", 2, 2, 16, 45), ("bar", 3, 2, 5, 29)
              ("full", 1, 12, 100, 665)]
 
 
-@pytest.mark.parametrize("impl", ["mfma", "simple_bf16", "f32"])
+@pytest.mark.parametrize("impl", ["mfma", "mfma_f16", "simple_bf16", "simple_f16", "f32"])
 @pytest.mark.parametrize("fam,B,A,N,S", ATT_CASES)
 def test_attention_fwd_bwd(impl, fam, B, A, N, S):
-    dt = torch.float32 if impl == "f32" else torch.bfloat16
-    ops.set_impl(1 if impl == "simple_bf16" else 0)
+    """'_f16': qkv, ctx, dctx and dqkv all f16-encoded (the single-encoding 16-bit path; gradients at unit scale here)."""
+    dt = torch.float32 if impl == "f32" else (torch.float16 if impl.endswith("f16") else torch.bfloat16)
+    ops.set_impl(1 if impl.startswith("simple") else 0)
     try:
         dh, Lq = 64, N + S + 3
         H = A * dh
@@ -293,7 +304,7 @@ def test_attention_fwd_bwd(impl, fam, B, A, N, S):
         rctx, rlse = attn_ref(qd, mask, A)
         # a fully masked row keeps only the fp32-rounded differences of (score - 10000): the fp64 restatement
         # here does not round them, the fp32 reference does (ulp(1e4) = 9.8e-4)
-        tol = (1e-3 if fam == "deadrow" else 1e-5) if impl == "f32" else 1.5e-2
+        tol = (1e-3 if fam == "deadrow" else 1e-5) if impl == "f32" else (3e-3 if dt == torch.float16 else 1.5e-2)
         assert relerr(ctx, rctx) < tol
         assert float((lse.double() - rlse).abs().max()) < ((2e-3 if fam == "deadrow" else 1e-4) if impl == "f32" else 2e-2)
         # backward, with the kernel's own (rounded) ctx as the saved output
@@ -301,18 +312,18 @@ def test_attention_fwd_bwd(impl, fam, B, A, N, S):
         delta = torch.zeros((B, A, Lq), dtype=torch.float32, device=DEV)
         ops.attn_bwd(qkv.view(B * Lq, 3 * H), ctx, dctx, lse, bits, tinfo, dqkv, delta, B, Lq, A, dh)
         (rctx * dctx.double()).sum().backward()
-        assert relerr(dqkv, qd.grad) < ((1e-3 if fam == "deadrow" else 1e-5) if impl == "f32" else 2e-2)
+        assert relerr(dqkv, qd.grad) < ((1e-3 if fam == "deadrow" else 1e-5) if impl == "f32" else (4e-3 if dt == torch.float16 else 2e-2))
     finally:
         ops.set_impl(0)
 
 
-@pytest.mark.parametrize("impl", ["mfma", "simple_bf16", "f32"])
+@pytest.mark.parametrize("impl", ["mfma", "mfma_f16", "simple_bf16", "f32"])
 @pytest.mark.parametrize("fam,B,A,N,S", [("full", 2, 2, 16, 45), ("s2s", 2, 3, 36, 150), ("bar", 2, 2, 36, 221), ("full", 1, 12, 100, 409)])
 def test_attention_dropout_follows_the_mask_function(impl, fam, B, A, N, S):
     """Attention-probability dropout (HF BertSelfAttention.dropout): forward and both backward kernels regenerate the mask that
     mv_dropout_mask defines for this site -- checked by applying that mask in an fp64 restatement and differentiating it."""
-    dt = torch.float32 if impl == "f32" else torch.bfloat16
-    ops.set_impl(1 if impl == "simple_bf16" else 0)
+    dt = torch.float32 if impl == "f32" else (torch.float16 if impl.endswith("f16") else torch.bfloat16)
+    ops.set_impl(1 if impl.startswith("simple") else 0)
     try:
         dh, Lq, key, p = 64, N + S + 3, 0x1234567, 0.1
         H = A * dh
@@ -657,10 +668,6 @@ def test_gemm_f16_operands(impl, M, N, K):
         ref = a[:, :K].double() @ b[:, :K].double().t()
         assert relerr(c[:, :N], ref) < 2e-5 * math.sqrt(K)
         assert (c[:, N:] == 7.0).all()
-        # the gradient forms have no f16 variant: refused, never silently computed in another encoding
-        if impl != "simple":
-            with pytest.raises(RuntimeError, match="MV_E_DTYPE"):
-                ops.gemm(a, b, torch.zeros((K, K), dtype=torch.float32, device=DEV), ta=True, tb=True, M=8, N=8, K=8, lda=lda, ldb=ldb, ldc=K)
     finally:
         ops.set_impl(0)
         ops.set_gemm_variant(0, 0)
@@ -761,3 +768,95 @@ def test_layernorm_embed_adamw_cast_f16():
     sb, sh = torch.zeros(n, dtype=torch.bfloat16, device=DEV), torch.zeros(n, dtype=torch.float16, device=DEV)
     ops.adamw_step(p, gr, m, v, sb, n, 1e-3, 0.9, 0.999, 1e-6, 0.0, 1, shadow_f16=sh)
     assert torch.equal(sb, p.to(torch.bfloat16)) and torch.equal(sh, p.to(torch.float16))
+
+
+# ------------------------------------------------------------------------------------------ f16 gradients under a loss scale
+# No counterpart in the reference (fp32 gradients, train_origin.py:129-131).  Contract (include/medvill.h): the loss gradients
+# enter the 16-bit chain multiplied by S (mv_ce_fwd_bwd), every writer of an f32 parameter gradient multiplies by 1/S, both
+# read from the device; mv_count_nonfinite + mv_scaler_update turn an overflow into a skipped optimizer step and a smaller S.
+@pytest.mark.parametrize("splitk", [1, 0, 4])
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_weight_gradient_gemm_unscales_with_alpha(dt, splitk):
+    M, N, K = 768, 512, 4100                                   # dW [M,N] over K tokens (ragged last K tile)
+    S = 1024.0
+    dy, x = rnd((K, M), torch.float32, 1, 0.01), rnd((K, N), torch.float32, 2)
+    dy_s = (dy * S).to(dt)
+    x16 = x.to(dt)
+    alpha = torch.tensor([1.0 / S], dtype=torch.float32, device=DEV)
+    c = torch.full((M, N), 3.0, dtype=torch.float32, device=DEV)
+    ws = torch.empty(8 * M * N, dtype=torch.float32, device=DEV) if splitk != 1 else None
+    ops.gemm(dy_s, x16, c, ta=True, tb=True, M=M, N=N, K=K, lda=M, ldb=N, splitk=splitk, ws=ws, alpha=alpha, accumulate=True)
+    ref = 3.0 + (dy_s.double().t() @ x16.double()) / S
+    assert relerr(c, ref) < 1e-5 * math.sqrt(K)
+    with pytest.raises(RuntimeError, match="MV_E_ARG"):        # alpha belongs to plain f32 products only
+        ops.gemm(dy_s, x16, torch.zeros((M, N), dtype=dt, device=DEV), ta=True, tb=True, M=M, N=N, K=K, lda=M, ldb=N, alpha=alpha)
+
+
+def test_row_kernels_apply_loss_scale_and_unscale():
+    M, H, V = 300, 256, 1000
+    S = 4096.0
+    ls = torch.tensor([S], dtype=torch.float32, device=DEV)
+    us = torch.tensor([1.0 / S], dtype=torch.float32, device=DEV)
+    # cross-entropy: f16 gradient = (softmax - onehot) * grad_scale * S
+    logits = rnd((M, V), torch.float32, 1)
+    labels = torch.randint(0, V, (M,), generator=torch.Generator().manual_seed(2)).to(torch.int32).to(DEV)
+    labels[::7] = -100
+    out = torch.zeros(3, dtype=torch.float32, device=DEV)
+    dl = torch.zeros((M, V), dtype=torch.float16, device=DEV)
+    ops.ce_fwd_bwd(logits, V, labels, M, V, out, dl, V, grad_scale=1.0 / M, loss_scale_dev=ls)
+    p = torch.softmax(logits.double(), -1)
+    oh = torch.zeros_like(p)
+    keep = labels >= 0
+    oh[keep, labels[keep].long()] = 1.0
+    ref = (p - oh) / M * S * keep.view(-1, 1)
+    assert float((dl.double() - ref).abs().max()) < 2e-3 * float(ref.abs().max())
+    # column sums and LayerNorm backward: what reaches the f32 gradients is divided by S again
+    x = (rnd((M, H), torch.float32, 3, 0.01) * S).to(torch.float16)
+    cs = torch.zeros(H, dtype=torch.float32, device=DEV)
+    ops.colsum(x, H, M, H, cs, accumulate=True, unscale=us)
+    assert relerr(cs, x.double().sum(0) / S) < 1e-5
+    pre = rnd((M, H), torch.float32, 4).to(torch.float16)
+    mean, rstd = pre.float().mean(1), 1.0 / torch.sqrt(pre.float().var(1, unbiased=False) + 1e-12)
+    g = rnd((H,), torch.float32, 5) + 1.0
+    dx = torch.zeros((M, H), dtype=torch.float16, device=DEV)
+    dg, db, cs2 = (torch.zeros(H, dtype=torch.float32, device=DEV) for _ in range(3))
+    ops.layernorm_bwd(x, pre, mean, rstd, g, dx, dg, db, cs2, M, H, unscale=us)
+    xh = (pre.double() - mean.double().view(-1, 1)) * rstd.double().view(-1, 1)
+    assert relerr(dg, (x.double() * xh).sum(0) / S) < 1e-4 and relerr(db, x.double().sum(0) / S) < 1e-4
+    gd = x.double() * g.double()
+    dx_ref = rstd.double().view(-1, 1) * (gd - gd.mean(1, keepdim=True) - xh * (gd * xh).mean(1, keepdim=True))
+    assert relerr(dx, dx_ref) < 2e-3                                        # the chain itself stays scaled
+    assert relerr(cs2, dx_ref.sum(0) / S) < 2e-3
+
+
+def test_dynamic_loss_scale_state_machine_and_skipped_adamw_step():
+    st = torch.tensor([1024.0, 1.0 / 1024.0, 0, 0, 0, 0, 0, 0], dtype=torch.float32, device=DEV)
+    n = 1000
+    p0 = rnd((n,), torch.float32, 1)
+    p, g = p0.clone(), rnd((n,), torch.float32, 2)
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    sh = torch.zeros(n, dtype=torch.float16, device=DEV)
+    # clean step: t = 1, applied
+    ops.count_nonfinite(g, st[6:7])
+    ops.scaler_update(st, growth_interval=2)
+    assert st.tolist()[:7] == [1024.0, 1.0 / 1024.0, 1.0, 0.0, 1.0, 0.0, 0.0]
+    ops.adamw_step(p, g, m, v, None, n, 1e-2, 0.9, 0.999, 1e-6, 0.0, 77, shadow_f16=sh, scaler_state=st)      # host step ignored
+    ref = p0 - 1e-2 * math.sqrt(1 - 0.999) / (1 - 0.9) * (0.1 * g) / (torch.sqrt(0.001 * g * g) + 1e-6)
+    assert float((p - ref).abs().max()) < 1e-6 and torch.equal(sh, p.to(torch.float16))
+    # overflowed step: nothing moves, the scale halves, t stays
+    p1, m1, v1 = p.clone(), m.clone(), v.clone()
+    gb = g.clone()
+    gb[17], gb[500], gb[999] = float("inf"), float("nan"), float("-inf")
+    ops.count_nonfinite(gb, st[6:7])
+    assert float(st[6]) == 3.0
+    ops.scaler_update(st, growth_interval=2)
+    assert st.tolist()[:7] == [512.0, 1.0 / 512.0, 0.0, 1.0, 1.0, 1.0, 0.0]
+    ops.adamw_step(p, gb, m, v, None, n, 1e-2, 0.9, 0.999, 1e-6, 0.0, 78, shadow_f16=sh, scaler_state=st)
+    assert torch.equal(p, p1) and torch.equal(m, m1) and torch.equal(v, v1)
+    # two clean steps: the scale grows back, t = 3
+    for _ in range(2):
+        ops.count_nonfinite(g, st[6:7])
+        ops.scaler_update(st, growth_interval=2)
+    assert st.tolist()[:7] == [1024.0, 1.0 / 1024.0, 0.0, 0.0, 3.0, 1.0, 0.0]
+    ops.scaler_update(st, growth_interval=1, max_scale=1024.0)            # capped
+    assert float(st[0]) == 1024.0
