@@ -105,7 +105,10 @@ void mv_set_gemm_variant(int force, int nj);
  * p_drop > 0 (MV_EPI_BIAS_RES only, N % 4 == 0): C = dropout(A.B + bias) + R -- the hidden-state dropout
  * of HF BertSelfOutput / BertOutput; mask = mv_dropout_mask(p_drop, drop_key) over index m*N + n.
  * alpha_dev (nullable; MV_EPI_NONE with an f32 C only): C = *alpha_dev * (A.B) -- the weight gradients of the f16-gradient
- * path are un-scaled (1 / loss scale, read from the device) where they are written.  */
+ * path are un-scaled (1 / loss scale, read from the device) where they are written.
+ * colsum_part (nullable): f32 [2*ceil(M/256)][N] -- the kernel also writes the column sums of C, one partial row per 128-row
+ * tile half, so a bias gradient needs no second pass over C (fold with mv_colsum_partials).  Only where the 256x256 MFMA
+ * kernel runs with 16-bit C, N % 256 == 0, 16-byte aligned outputs, no split-K (else MV_E_SHAPE: use mv_colsum).  */
 int mv_gemm(int dtype, int ta, int tb, int M, int N, int K,
             const void* A, int lda, const void* B, int ldb,
             void* C, int ldc, int c_dtype,
@@ -114,7 +117,7 @@ int mv_gemm(int dtype, int ta, int tb, int M, int N, int K,
             void* C2, int ldc2,
             void* C3, int ldc3, int c3_dtype,
             int splitk, float* ws, size_t ws_bytes, int accumulate,
-            float p_drop, unsigned long long drop_key, const float* alpha_dev, void* stream);
+            float p_drop, unsigned long long drop_key, const float* alpha_dev, float* colsum_part, void* stream);
 
 /* ---- attention masks ----------------------------------------------------------------------
  * Replaces CXRBertEncoder.get_extended_attn_mask (cxrbert_origin.py:75-85): instead of an
@@ -269,6 +272,8 @@ int mv_scatter_rows(int dtype, const void* src, int lds, const int32_t* rows, in
 /* out[n] (+)= [*grad_unscale_dev] * sum_m x[m,n]  (bias gradients). x [M,N] in dtype, out f32.   */
 int mv_colsum(int dtype, const void* x, int ldx, int M, int N, float* out, int accumulate, const float* grad_unscale_dev,
               void* stream);
+/* out[n] += [*grad_unscale_dev] * sum_{p < P} part[p*ld + n]: folds the partial column sums written by mv_gemm (colsum_part). */
+int mv_colsum_partials(const float* part, int P, int ld, int N, float* out, const float* grad_unscale_dev, void* stream);
 
 /* elementwise c = a + b (dtype), n elements */
 int mv_add(int dtype, const void* a, const void* b, void* c, size_t n, void* stream);

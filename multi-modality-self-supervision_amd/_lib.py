@@ -29,7 +29,7 @@ PROTOTYPES = {
     "mv_build_info": [],
     "mv_set_gemm_variant": [i32, i32],
     "mv_gemm": [i32, i32, i32, i32, i32, i32, vp, i32, vp, i32, vp, i32, i32, vp, i32, vp, i32, i32, vp, i32, vp, i32, i32,
-                i32, vp, sz, i32, f32, u64, vp, vp],
+                i32, vp, sz, i32, f32, u64, vp, vp, vp],
     "mv_mask_pack": [vp, i32, i32, i32, vp, vp, vp],
     "mv_mask_build": [vp, i32, i32, vp, vp, vp],
     "mv_mlm_draws": [u64, i32, i32, i32, vp, vp, vp],
@@ -48,6 +48,7 @@ PROTOTYPES = {
     "mv_gather_rows": [i32, vp, i32, vp, i32, i32, vp, i32, vp],
     "mv_scatter_rows": [i32, vp, i32, vp, i32, i32, vp, i32, i32, vp],
     "mv_colsum": [i32, vp, i32, i32, i32, vp, i32, vp, vp],
+    "mv_colsum_partials": [vp, i32, i32, i32, vp, vp, vp],
     "mv_add": [i32, vp, vp, vp, sz, vp],
     "mv_dact": [i32, i32, vp, vp, vp, sz, vp],
     "mv_cast2d": [vp, i32, i64, vp, i32, i64, i32, i32, vp],

@@ -325,7 +325,8 @@ static inline bool aligned_to(const void* p, size_t a) { return p == nullptr || 
 extern "C" int mv_gemm(int dtype, int ta, int tb, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
                        void* C, int ldc, int c_dtype, const float* bias, int epi, const void* R, int ldr, int r_dtype,
                        void* C2, int ldc2, void* C3, int ldc3, int c3_dtype, int splitk, float* ws, size_t ws_bytes,
-                       int accumulate, float p_drop, unsigned long long drop_key, const float* alpha_dev, void* stream_) {
+                       int accumulate, float p_drop, unsigned long long drop_key, const float* alpha_dev, float* colsum_part,
+                       void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) return MV_E_ARG;
   if (!mv_dtype_ok(dtype) || !mv_dtype_ok(c_dtype)) return MV_E_DTYPE;
@@ -351,7 +352,7 @@ extern "C" int mv_gemm(int dtype, int ta, int tb, int M, int N, int K, const voi
   p.A = A; p.B = B; p.C = C; p.C2 = C2; p.bias = bias; p.R = R; p.C3 = C3;
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldc2 = ldc2; p.ldr = ldr; p.ldc3 = ldc3;
   p.c_dtype = c_dtype; p.r_dtype = r_dtype; p.c3_dtype = c3_dtype; p.epi = epi; p.accumulate = accumulate;
-  p.splitk = splitk; p.ws = ws; p.dbg = g_mv_gemm_dbg; p.alpha = alpha_dev;
+  p.splitk = splitk; p.ws = ws; p.dbg = g_mv_gemm_dbg; p.alpha = alpha_dev; p.csum = colsum_part;
   p.drop = mv_make_drop(epi == MV_EPI_BIAS_RES ? p_drop : 0.f, drop_key);
   if (p.drop.thr && (N & 3)) return MV_E_SHAPE;   // the mask is keyed on groups of 4 consecutive columns
   const size_t csz = (c_dtype == MV_F32) ? 16 : 8;
@@ -386,34 +387,35 @@ extern "C" int mv_gemm(int dtype, int ta, int tb, int M, int N, int K, const voi
     const bool big = (g_mv_gemm_force == 2) || (g_mv_gemm_force == 0 && M >= 256 && N >= 128 && ((K & 7) == 0 || (ta && tb)) && (wide_nt || ta) &&
                                                (t128 >= 128 || (K >= 4096 && splitk != 1)));
     if (big) {
-      long long sk = splitk;
-      if (splitk > 1 || splitk == 0) {      // 0 = auto
-        const long long tiles = t256;
-        sk = 1;
-        // enough slabs to give every CU a unit, each at least 1024 deep; at most 32 and as many as the workspace holds
-        if (tiles < 256 && K >= 2048) { sk = 256 / tiles; if (sk > K / 1024) sk = K / 1024; if (sk > 32) sk = 32; if (sk < 1) sk = 1; }
-        if (splitk > 1 && sk > splitk) sk = splitk;
-        if (sk > 1 && ws) { const long long fit = (long long)(ws_bytes / ((size_t)M * N * sizeof(float))); if (sk > fit) sk = fit < 1 ? 1 : fit; }
-        if (sk > 1 && (!ws || epi != MV_EPI_NONE || c_dtype != MV_F32)) sk = 1;
-      }
-      // cost ~ rounds x tile width (1 block / CU for the 8-wave tiles, 2 blocks / CU for 256x128)
-      const long long r256 = (t256 * sk + 255) / 256 * 256, r192 = (t192 * sk + 255) / 256 * 192,
-                      r128 = (t128 * sk + 511) / 512 * 256;
-      int variant = g_mv_gemm_nj;           // 4: 256x256, 3: 256x192, 2: 256x128
+      int variant = g_mv_gemm_nj;           // test / experiment hook: 14, 24 (below) or 2 = 256x128 tiles, 4 waves, two blocks per CU
       if (variant == 0) {
         // 256x256 with 64-deep stages (whole 128-B lines per LDS-DMA row): best measured.  Weight gradients (split-K
         // units, f32 partial tiles) gain 5-8 % from the persistent form; y = x.W^T does not (profiles/r01_gemm_variants.txt)
         variant = ta ? 24 : 14;
-        (void)r256; (void)r192; (void)r128;
       }
+      const bool v128 = variant == 2;
+      const long long tiles_v = v128 ? t128 : t256, slots = v128 ? 512 : 256;
+      long long sk = splitk;
+      if (splitk > 1 || splitk == 0) {      // 0 = auto
+        const long long tiles = tiles_v;
+        sk = 1;
+        // enough slabs to give every CU a unit, each at least 1024 deep; at most 32 and as many as the workspace holds
+        if (tiles < slots && K >= 2048) { sk = slots / tiles; if (sk > K / 1024) sk = K / 1024; if (sk > 32) sk = 32; if (sk < 1) sk = 1; }
+        if (splitk > 1 && sk > splitk) sk = splitk;
+        if (sk > 1 && ws) { const long long fit = (long long)(ws_bytes / ((size_t)M * N * sizeof(float))); if (sk > fit) sk = fit < 1 ? 1 : fit; }
+        if (sk > 1 && (!ws || epi != MV_EPI_NONE || c_dtype != MV_F32)) sk = 1;
+      }
+      (void)t192;
       int kchunk = (int)((K + sk - 1) / sk);
       kchunk = (kchunk + 63) / 64 * 64;
       p.kchunk = kchunk;
       p.splitk = splitk = (K + kchunk - 1) / kchunk;
-      // variants: 4 = 256x256 (32-deep stages x4), 3 = 256x192, 2 = 256x128 (x3, 2 blocks/CU),
-      //           14 = 256x256 with 64-deep stages x2 (128-B lines), 15 = 256x192 likewise, 12 / 13 = 256x128 with
-      //           64-deep stages x2 / x3
-      const int tiles = (int)t256;
+      // variants: 14 = 256x256 with 64-deep stages x2 (128-B lines), 24 = its persistent form, 2 = 256x128 (32-deep x3, 2 blocks/CU)
+      const int tiles = (int)tiles_v;
+      // fused column sums: only the path that owns whole 64-column strips per wave and stores 16-byte pieces computes them
+      if (colsum_part && !(variant == 14 && splitk == 1 && !accumulate && p.vec8_ok && (N & 255) == 0 && mv_is16(c_dtype) &&
+                           (epi == MV_EPI_NONE || epi == MV_EPI_BIAS || epi == MV_EPI_BIAS_GELU_D || ((epi == MV_EPI_MUL || epi == MV_EPI_RES) && p.r8_ok))))
+        return MV_E_SHAPE;
       dim3 grid(tiles, splitk);
       static int n_cu = 0;
       if (n_cu == 0) {
@@ -425,6 +427,7 @@ extern "C" int mv_gemm(int dtype, int ta, int tb, int M, int N, int K, const voi
       const int rc_ring = mv_launch_ring(p, ta, tb, f16, variant, tiles, splitk, n_cu, stream);
       if (rc_ring != MV_OK) return rc_ring;
     } else {
+      if (colsum_part) return MV_E_SHAPE;        // the 256x256 ring kernel only
       if (splitk == 0) {
         const int tiles = ((M + GT_BM - 1) / GT_BM) * ((N + GT_BN - 1) / GT_BN);
         splitk = 1;
@@ -487,6 +490,7 @@ extern "C" int mv_gemm(int dtype, int ta, int tb, int M, int N, int K, const voi
 #undef LAUNCH_MFMA
     }
   } else {
+    if (colsum_part) return MV_E_SHAPE;
     int kchunk = (K + splitk - 1) / splitk;
     kchunk = (kchunk + 15) / 16 * 16;
     p.kchunk = kchunk;

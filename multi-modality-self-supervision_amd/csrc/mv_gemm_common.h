@@ -17,6 +17,9 @@ struct GemmArgs {
   unsigned bytesA, bytesB;
   const float* alpha;   // nullable, MV_EPI_NONE with an f32 C only: C = *alpha * (A.B) (+ C when accumulating) -- 1 / loss scale of the
                         // f16-gradient path, applied where a weight gradient is written (mv_gemm's alpha_dev)
+  float* csum;    // nullable (256x256 ring kernel, 16-bit C, N % 256 == 0): f32 [2 * ceil(M/256)][N] -- row 2*tm + half receives the sums over
+                  // the 128 rows of that tile half of every output column (taken from the f32 values before they are rounded): the
+                  // column sums of C without a second pass over it (mv_colsum_partials folds the rows)
   DropCfg drop;   // MV_EPI_BIAS_RES only: C = dropout(A.B + bias) + R
   int dbg;   // ablation bits (timing experiments only): 1 skip C stores, 2 skip operand loads, 4 skip LDS reads + MFMA
   // implicit convolution (mv_conv2d): A is an NHWC activation [B, cvH, cvW, cvC]; its logical row m = (b, oy, ox) and column
@@ -164,7 +167,7 @@ __device__ __forceinline__ void dec8_16(u32x4 raw, int dtype, float (&r)[8]) {
   }
 }
 template <int E>
-__device__ __forceinline__ void epilogue8_16(const GemmArgs& p, int m, int n, f32x4 v0, f32x4 v1, f32x4 b0, f32x4 b1,
+__device__ __forceinline__ void epilogue8_16(const GemmArgs& p, int m, int n, f32x4 v0, f32x4 v1, f32x4 b0, f32x4 b1, float (&cs)[8], bool do_cs,
                                              u32x4 rraw = (u32x4){0u, 0u, 0u, 0u}) {
   if (m >= p.M) return;
   float o[8] = {v0[0] + b0[0], v0[1] + b0[1], v0[2] + b0[2], v0[3] + b0[3], v1[0] + b1[0], v1[1] + b1[1], v1[2] + b1[2], v1[3] + b1[3]};
@@ -182,6 +185,10 @@ __device__ __forceinline__ void epilogue8_16(const GemmArgs& p, int m, int n, f3
   }
   st8_16(p.C, (size_t)m * p.ldc + n, p.c_dtype, o);
   if (p.C3) st8_16(p.C3, (size_t)m * p.ldc3 + n, p.c3_dtype, o);
+  if (do_cs) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) cs[e] += o[e];
+  }
 }
 
 // run BODY(E) with the run-time epilogue selector turned into a compile-time constant
@@ -318,6 +325,8 @@ __device__ __forceinline__ bf16x8 g2_frag(const char* tile, int base, int l15, i
       if (WIDE_E && (E_) != MV_EPI_NONE) { b0 = *(const f32x4*)(p.bias + ncol8); b1 = *(const f32x4*)(p.bias + ncol8 + 4); } \
       /* the elementwise operand's rows are requested two 16-row groups ahead of their use (4 x 16 bytes per lane in flight) */ \
       u32x4 rq[2][2];                                                                                          \
+      float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};                                                  \
+      const bool do_cs = p.csum != nullptr;                                                                    \
       if (WIDE_R) {                                                                                            \
         _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                          \
           _Pragma("unroll") for (int rr = 0; rr < 2; ++rr) rq[t][rr] = ld8_raw(p, m0 + wm + t * 16 + rr * 8 + r8, ncol8); \
@@ -331,10 +340,22 @@ __device__ __forceinline__ bf16x8 g2_frag(const char* tile, int base, int l15, i
           if (WIDE_R) {                                                                                        \
             const u32x4 rcur = rq[i & 1][rr];                                                                  \
             if (i + 2 < 8) rq[i & 1][rr] = ld8_raw(p, m0 + wm + (i + 2) * 16 + row, ncol8);                    \
-            epilogue8_16<EE>(p, m0 + wm + i * 16 + row, ncol8, v0, v1, b0, b1, rcur);                          \
+            epilogue8_16<EE>(p, m0 + wm + i * 16 + row, ncol8, v0, v1, b0, b1, cs, do_cs, rcur);               \
           } else {                                                                                             \
-            epilogue8_16<EE>(p, m0 + wm + i * 16 + row, ncol8, v0, v1, b0, b1);                                \
+            epilogue8_16<EE>(p, m0 + wm + i * 16 + row, ncol8, v0, v1, b0, b1, cs, do_cs);                     \
           }                                                                                                    \
+        }                                                                                                      \
+      }                                                                                                        \
+      if (do_cs) {          /* fold the 8 row-lanes that share this lane's 8 columns; one lane per column group stores */ \
+        _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                                        \
+          float v = cs[e];                                                                                     \
+          v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);                   \
+          cs[e] = v;                                                                                           \
+        }                                                                                                      \
+        if (r8 == 0) {                                                                                         \
+          float* cp = p.csum + ((size_t)(2 * (m0 / G2_BM) + wm / 128)) * p.N + ncol8;                          \
+          *(f32x4*)cp = (f32x4){cs[0], cs[1], cs[2], cs[3]};                                                   \
+          *(f32x4*)(cp + 4) = (f32x4){cs[4], cs[5], cs[6], cs[7]};                                             \
         }                                                                                                      \
       }                                                                                                        \
     } else {                                                                                                   \

@@ -4,7 +4,8 @@
 int mv_launch_ring_nt(const GemmArgs& p, bool f16, int variant, int tiles, int splitk, int n_cu, hipStream_t stream) {
   dim3 grid(tiles, splitk);
   if (f16) {
-    LAUNCH_RING(false, false, 4, 4, 2, 2, true);
+    if (variant == 2) LAUNCH_RING(false, false, 4, 2, 3, 1, true);
+    else LAUNCH_RING(false, false, 4, 4, 2, 2, true);
   } else {
     if (variant == 24) LAUNCH_PRING(false, false, 4, 4, 2, false);
     else LAUNCH_RING(false, false, 4, 4, 2, 2, false);

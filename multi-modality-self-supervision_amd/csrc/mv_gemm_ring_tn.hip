@@ -4,7 +4,8 @@
 int mv_launch_ring_tn(const GemmArgs& p, bool f16, int variant, int tiles, int splitk, int n_cu, hipStream_t stream) {
   dim3 grid(tiles, splitk);
   if (f16) {
-    if (variant == 24) LAUNCH_PRING(true, true, 4, 4, 2, true);
+    if (variant == 2) LAUNCH_RING(true, true, 4, 2, 3, 1, true);
+    else if (variant == 24) LAUNCH_PRING(true, true, 4, 4, 2, true);
     else LAUNCH_RING(true, true, 4, 4, 2, 2, true);
   } else {
     if (variant == 24) LAUNCH_PRING(true, true, 4, 4, 2, false);

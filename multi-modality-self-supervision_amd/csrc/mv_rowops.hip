@@ -722,6 +722,39 @@ extern "C" int mv_colsum(int dtype, const void* x, int ldx, int M, int N, float*
   return MV_OK;
 }
 
+// out[n] += [*gscale] * sum_p part[p, n]: folds the per-block partial column sums that the attention backward (and the dz GEMM's
+// epilogue) write next to their outputs -- a bias gradient without a second pass over the [rows, N] matrix.
+__global__ __launch_bounds__(256) void colsum_partials_kernel(const float* __restrict__ part, int P, int ld, int N, float* __restrict__ out,
+                                                              const float* __restrict__ gscale) {
+  // grid (ceil(N/64), row slices): 64 columns x 4 row-lanes per block, every row slice adds its share atomically -- the matrix is
+  // a few MB, so the point is many short independent load chains, not bandwidth
+  __shared__ float red[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int n = blockIdx.x * 64 + tx;
+  const int per = (P + gridDim.y - 1) / gridDim.y;
+  const int p0 = blockIdx.y * per, p1 = min(P, p0 + per);
+  float s_ = 0.f;
+  if (n < N)
+    for (int p = p0 + ty; p < p1; p += 4) s_ += part[(size_t)p * ld + n];
+  red[ty][tx] = s_;
+  __syncthreads();
+  if (ty == 0 && n < N) {
+    const float t = red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx];
+    atomicAdd(out + n, gscale ? t * *gscale : t);
+  }
+}
+extern "C" int mv_colsum_partials(const float* part, int P, int ld, int N, float* out, const float* grad_unscale_dev, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!part || !out || P <= 0 || N <= 0 || ld < N) return MV_E_ARG;
+  const int xb = (N + 63) / 64;
+  int ys = (512 + xb - 1) / xb;                 // ~512 blocks
+  if (ys > (P + 7) / 8) ys = (P + 7) / 8;       // at least 8 rows per slice
+  if (ys < 1) ys = 1;
+  hipLaunchKernelGGL(colsum_partials_kernel, dim3(xb, ys), dim3(256), 0, stream, part, P, ld, N, out, grad_unscale_dev);
+  MV_CHECK_LAUNCH();
+  return MV_OK;
+}
+
 // keep-mask of the counter-based dropout for linear indices 0..n-1 (test / inspection utility)
 __global__ void dropout_mask_kernel(uint8_t* __restrict__ out, size_t n, DropCfg d) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {

@@ -180,6 +180,7 @@ class Engine:
         self.dz_nt = os.environ.get("MV_DZ_NT", "1") != "0"
         self._w2t, self._w2t_ev, self._w2t_stale = None, None, True
         self.head_on_side = True  # the tied decoder's weight gradient on the side stream (see _mlm_backward)
+        self.fused_colsum = os.environ.get("MV_FUSED_COLSUM", "1") != "0"   # bias gradients from partial sums of the producing kernels
         self._dE_ev = None
         self._opt_ev = None       # overlapped AdamW: parameter range -> event (see adamw_step)
         self.head_splitk = True  # split-K for the decoder's input gradient (see _mlm_backward)
@@ -774,6 +775,7 @@ class Engine:
         if bucket_hook:
             bucket_hook("heads", None)
         use_w2t = self.dz_nt and self.is16
+        mfma_on = self.fused_colsum and self.is16 and ops.get_impl() == 0       # partial column sums exist in the MFMA kernels only
         if use_w2t:
             if self._w2t_stale or self._w2t is None:
                 self.refresh_w2t(on_side=False)
@@ -806,13 +808,23 @@ class Engine:
             fork()
             with torch.cuda.stream(side):
                 self._dW(dproj2, a_["i"], g[p + "output.dense.weight"], H, I, M, lda=H, ldb=I)
+            # FFN-up bias gradient without a second pass over dz: the dz GEMM leaves partial column sums (one row per 128-row tile
+            # half) that one small kernel folds (MV_FUSED_COLSUM=0: the column-sum kernel).  The same for dqkv from the attention
+            # backward was built and measured slower (profiles/r03_notes.txt): +80 us on the two kernels for 11 us saved.
+            dz_part = None
+            # (mv_gemm takes the 256x256 MFMA kernel for wide outputs that fill the chip: the same test as in mv_gemm.hip)
+            if use_w2t and mfma_on and M >= 256 and I >= 1024 and I % 256 == 0 and ((M + 255) // 256) * ((I + 127) // 128) >= 128:
+                dz_part = self._buf(f"bw_dzpart_{l}", (2 * ((M + 255) // 256), I), torch.float32)
             if use_w2t:
-                ops.gemm(dproj2, self._w2t[l], dz, M=M, N=I, K=H, epi=EPI_MUL, r=a_["dgelu"])
+                ops.gemm(dproj2, self._w2t[l], dz, M=M, N=I, K=H, epi=EPI_MUL, r=a_["dgelu"], colsum_part=dz_part)
             else:
                 ops.gemm(dproj2, self.w[p + "output.dense.weight"], dz, tb=True, M=M, N=I, K=H, epi=EPI_MUL, r=a_["dgelu"])
             fork()
             with torch.cuda.stream(side):
-                ops.colsum(dz, I, M, I, g[p + "intermediate.dense.bias"], accumulate=True, unscale=us)
+                if dz_part is not None:
+                    ops.colsum_partials(dz_part, dz_part.shape[0], I, I, g[p + "intermediate.dense.bias"], unscale=us)
+                else:
+                    ops.colsum(dz, I, M, I, g[p + "intermediate.dense.bias"], accumulate=True, unscale=us)
                 self._dW(dz, a_["a"], g[p + "intermediate.dense.weight"], I, H, M, lda=I, ldb=H)
             ops.gemm(dz, self.w[p + "intermediate.dense.weight"], da, tb=True, M=M, N=H, K=I, epi=EPI_RES, r=dpre2)
             # LN1 backward (+ bias grad of attention.output.dense)

@@ -15,10 +15,12 @@ def _lib():
 
 
 def gemm(a, b, c, *, ta=False, tb=False, M, N, K, lda=None, ldb=None, ldc=None, bias=None, epi=EPI_NONE, r=None, ldr=None,
-         c2=None, ldc2=None, c3=None, ldc3=None, splitk=1, ws=None, accumulate=False, p_drop=0.0, drop_key=0, alpha=None):
+         c2=None, ldc2=None, c3=None, ldc3=None, splitk=1, ws=None, accumulate=False, p_drop=0.0, drop_key=0, alpha=None, colsum_part=None):
     """c[M,N] = epi(op(a)[M,K] . op(b)[K,N]); c3 (optional): the same result in a second 16-bit encoding; alpha (optional,
     f32 device scalar): factor on the product (weight gradients of the f16-gradient path); see mv_gemm in include/medvill.h."""
-    L.require_cuda(a, b, c, bias, r, c2, c3, ws, alpha)
+    L.require_cuda(a, b, c, bias, r, c2, c3, ws, alpha, colsum_part)
+    if colsum_part is not None and (colsum_part.dtype != torch.float32 or colsum_part.numel() < 2 * ((M + 255) // 256) * N):
+        raise ValueError("colsum_part: f32 [2*ceil(M/256), N]")
     lda = lda if lda is not None else (M if ta else K)
     ldb = ldb if ldb is not None else (N if tb else K)
     ldc = ldc if ldc is not None else N
@@ -32,7 +34,7 @@ def gemm(a, b, c, *, ta=False, tb=False, M, N, K, lda=None, ldb=None, ldc=None, 
     rc = _lib().mv_gemm(L.dt_of(a), int(ta), int(tb), M, N, K, L.ptr(a), lda, L.ptr(b), ldb, L.ptr(c), ldc, L.dt_of(c),
                         L.ptr(bias), epi, L.ptr(r), ldr, L.dt_of(r) if r is not None else 0, L.ptr(c2), ldc2,
                         L.ptr(c3), ldc3, L.dt_of(c3) if c3 is not None else 0, splitk, L.ptr(ws), (ws.numel() * 4) if ws is not None else 0, int(accumulate), float(p_drop), int(drop_key),
-                        L.ptr(alpha), L.stream_ptr())
+                        L.ptr(alpha), L.ptr(colsum_part), L.stream_ptr())
     L.check(rc, f"mv_gemm(M={M},N={N},K={K},ta={ta},tb={tb},epi={epi})")
     return c
 
@@ -187,6 +189,13 @@ def colsum(x, ldx, M, N, out, accumulate=True, unscale=None):
     L.check(rc, "mv_colsum")
 
 
+def colsum_partials(part, P, ld, N, out, unscale=None):
+    """out[n] += [unscale] * sum_p part[p, n] (the partial column sums of gemm(colsum_part=))."""
+    L.require_cuda(part, out, unscale)
+    rc = _lib().mv_colsum_partials(L.ptr(part), P, ld, N, L.ptr(out), L.ptr(unscale), L.stream_ptr())
+    L.check(rc, "mv_colsum_partials")
+
+
 def add(a, b, c, n):
     rc = _lib().mv_add(L.dt_of(a), L.ptr(a), L.ptr(b), L.ptr(c), n, L.stream_ptr())
     L.check(rc, "mv_add")
@@ -301,6 +310,10 @@ def dropout_mask(p_drop, drop_key, n, device):
 
 def set_impl(impl: int):
     _lib().mv_set_impl(int(impl))
+
+
+def get_impl() -> int:
+    return int(_lib().mv_get_impl())
 
 
 def set_gemm_variant(force: int = 0, nj: int = 0):

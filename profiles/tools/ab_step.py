@@ -45,6 +45,8 @@ VARIANTS = {
                ("decoder weight gradient on the side stream", lambda: setattr(model.engine, "head_on_side", True))],
     "optov": [("AdamW on the main stream after the backward", lambda: setattr(step, "overlap_optimizer", False)),
               ("AdamW on the side stream under the next forward", lambda: setattr(step, "overlap_optimizer", True))],
+    "fcs": [("FFN-up bias gradient: column-sum kernel over dz", lambda: setattr(model.engine, "fused_colsum", False)),
+            ("FFN-up bias gradient: partial sums from the dz GEMM", lambda: setattr(model.engine, "fused_colsum", True))],
     "tail": [("last layer on all rows", lambda: setattr(step, "tail_rows", False)), ("last layer on consumed rows", lambda: setattr(step, "tail_rows", True))],
 }
 which = sys.argv[1] if len(sys.argv) > 1 else "pack"

@@ -40,11 +40,12 @@ for (N, S, fam) in ((36, 473, "full"), (36, 473, "s2s"), (36, 473, "noncross"), 
         cu, rowmap, inv = ops.pack_plan(desc.desc, B, L)
         M = int(cu[-1])
     vl = (N + 2 + n_ids).double() if pack else torch.full((B,), float(L)).double()
-    qkv = torch.randn(M, 3 * H, device=dev).to(torch.bfloat16)
+    gdt = torch.float16 if "f16g" in sys.argv[1:] else torch.bfloat16          # encoding of the backward's operands
+    qkv = torch.randn(M, 3 * H, device=dev).to(gdt)
     qkv_f = qkv.to(fdt)
-    dctx = torch.randn(M, H, device=dev).to(torch.bfloat16)
+    dctx = torch.randn(M, H, device=dev).to(gdt)
     ctx = torch.empty(M, H, device=dev, dtype=fdt)
-    ctx_b = torch.empty(M, H, device=dev, dtype=torch.bfloat16) if fdt == torch.float16 else None
+    ctx_b = torch.empty(M, H, device=dev, dtype=torch.bfloat16) if (fdt == torch.float16 and gdt != fdt) else None
     lse = torch.empty(B, A, L, device=dev)
     dqkv = torch.empty_like(qkv)
     delta = torch.empty(B, A, L, device=dev)
@@ -53,4 +54,7 @@ for (N, S, fam) in ((36, 473, "full"), (36, 473, "s2s"), (36, 473, "noncross"), 
         tf = bench(lambda: ops.attn_fwd(qkv_f, bits, ti, ctx, lse, B, L, A, dh, p_drop=p, drop_key=12345, cu=cu, total_rows=M, ctx_bf16=ctx_b))
         cb = ctx_b if ctx_b is not None else ctx
         tb = bench(lambda: ops.attn_bwd(qkv, cb, dctx, lse, bits, ti, dqkv, delta, B, L, A, dh, p_drop=p, drop_key=12345, cu=cu, total_rows=M))
-        print(f"L={L} {fam:9s} rows {M:6d} p={p}: fwd {tf:7.1f} us ({fl / tf / 1e6:6.0f} TF/s)  bwd {tb:7.1f} us ({2.5 * fl / tb / 1e6:6.0f} TF/s)", flush=True)
+        gb = torch.zeros(3 * H, device=dev)
+        tcs = bench(lambda: ops.colsum(dqkv, 3 * H, M, 3 * H, gb))
+        print(f"L={L} {fam:9s} rows {M:6d} p={p}: fwd {tf:7.1f} us ({fl / tf / 1e6:6.0f} TF/s)  bwd {tb:7.1f} us ({2.5 * fl / tb / 1e6:6.0f} TF/s)"
+              f"  | colsum(dqkv) {tcs:5.1f} us", flush=True)

@@ -16,7 +16,7 @@ for line in err.splitlines():
         cur = m.group(1)
         rows[cur] = {}
         continue
-    m = re.search(r"remark: [^ ]+\s+([A-Za-z /\[\]]+?):\s+(\d+)", line)
+    m = re.search(r"remark:\s+([A-Za-z /\[\]]+?):\s+(\d+)", line)
     if m and cur:
         rows[cur][m.group(1).strip()] = int(m.group(2))
 if not rows:

@@ -860,3 +860,38 @@ def test_dynamic_loss_scale_state_machine_and_skipped_adamw_step():
     assert st.tolist()[:7] == [1024.0, 1.0 / 1024.0, 0.0, 0.0, 3.0, 1.0, 0.0]
     ops.scaler_update(st, growth_interval=1, max_scale=1024.0)            # capped
     assert float(st[0]) == 1024.0
+
+
+# ------------------------------------------------------------------------------------------ bias gradients from partial column sums
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("epi", [EPI_MUL, EPI_BIAS, EPI_NONE])
+@pytest.mark.parametrize("M,N,K", [(700, 512, 192), (2048, 3072, 768), (130, 256, 64)])
+def test_gemm_writes_partial_column_sums(dt, epi, M, N, K):
+    """colsum_part: the 256x256 kernel leaves sum over each 128-row tile half of every output column (the dz GEMM's bias gradient
+    without re-reading dz); mv_colsum_partials folds the rows, un-scaled."""
+    a, b = rnd((M, K), dt, 3, 0.5), rnd((N, K), dt, 4, 0.5)
+    r, bias = rnd((M, N), torch.float16, 6), rnd((N,), torch.float32, 7)
+    c = torch.zeros((M, N), dtype=dt, device=DEV)
+    P = 2 * ((M + 255) // 256)
+    part = torch.full((P, N), float("nan"), dtype=torch.float32, device=DEV)
+    ops.set_gemm_variant(2, 14)
+    try:
+        ops.gemm(a, b, c, M=M, N=N, K=K, epi=epi, r=r if epi == EPI_MUL else None, bias=bias if epi == EPI_BIAS else None, colsum_part=part)
+        with pytest.raises(RuntimeError, match="MV_E_SHAPE"):           # a ragged last column tile: refused, never silently wrong
+            ops.gemm(a, b[:N - 8], c[:, :N - 8], M=M, N=N - 8, K=K, ldc=N, colsum_part=part)
+    finally:
+        ops.set_gemm_variant(0, 0)
+    y = a.double() @ b.double().t()
+    ref = y * r.double() if epi == EPI_MUL else (y + bias.double() if epi == EPI_BIAS else y)
+    assert relerr(c, ref) < (2e-3 if dt == torch.float16 else 1e-2)
+    out = torch.full((N,), 2.0, dtype=torch.float32, device=DEV)
+    us = torch.tensor([0.25], dtype=torch.float32, device=DEV)
+    ops.colsum_partials(part, P, N, N, out, unscale=us)
+    assert torch.isfinite(part).all()
+    assert relerr(out, 2.0 + 0.25 * ref.sum(0)) < 1e-4
+    with pytest.raises(RuntimeError, match="MV_E_SHAPE"):               # the 128x128 kernel has no such epilogue
+        ops.set_gemm_variant(1, 0)
+        try:
+            ops.gemm(a, b, c, M=M, N=N, K=K, colsum_part=part)
+        finally:
+            ops.set_gemm_variant(0, 0)
