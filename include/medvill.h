@@ -81,6 +81,10 @@ const char* mv_build_info(void);
 /* test hook for mv_gemm's MFMA tile choice: force = 0 auto / 1 the 128x128x64 kernel / 2 the 256-row
  * LDS-DMA kernel; nj = 0 auto / 3 (256x192 tile) / 4 (256x256 tile). */
 void mv_set_gemm_variant(int force, int nj);
+/* bits per uniform of the attention-dropout mask generator (mv_attn_dropmask): 16 (default), 12 or 8.  P(drop) = round(p * 2^n) / 2^n;
+ * the generator's time is proportional to n.  Process-wide: set before the masks of a forward are generated. */
+void mv_set_attn_planes(int planes);
+int mv_get_attn_planes(void);
 
 /* ---- dense projections --------------------------------------------------------------------
  * Replaces every nn.Linear on the path and its autograd backward:
@@ -184,20 +188,32 @@ int mv_pack_plan(const int32_t* desc, int B, int L, int32_t* cu, int32_t* rowmap
  * qkv is the fused projection output [B*L, 3H] (q | k | v, heads contiguous inside each).
  * lse [B, A, L] (f32) = log-sum-exp of each score row, kept for the backward.
  * dh must be 64 (bf16 MFMA path) or <= 128 (f32 path).
- * p_drop > 0: attention-probability dropout (HF BertSelfAttention.dropout): ctx = dropout(softmax).v with the
- * mask of mv_dropout_mask(p_drop, drop_key) over index ((b*A + h)*L + q)*Lp + k, Lp = L rounded up to 4.
+ * p_drop > 0: attention-probability dropout (HF BertSelfAttention.dropout): ctx = dropout(softmax).v; the mask is the
+ * tensor of keep-bits `dropbits` written by mv_attn_dropmask (required then), survivors scaled by 1 / (1 - P(drop)) with the
+ * P(drop) of that generator: the forward and both backward kernels spend one select per score element (they are bound by vector-instruction
+ * issue, not by MFMA, so nothing is hashed inside them).
  * dtype MV_F16: qkv and ctx in the f16 encoding; ctx_bf16 (nullable, MV_F16 only) receives the bf16 copy of ctx that
  * the backward pairs with bf16 gradients.  */
 int mv_attn_fwd(int dtype, const void* qkv, const uint32_t* bits, const uint8_t* tileinfo,
                 void* ctx, void* ctx_bf16, float* lse, int B, int L, int A, int dh,
-                float p_drop, unsigned long long drop_key, const int32_t* cu, int total_rows, void* stream);
+                float p_drop, const uint32_t* dropbits, const int32_t* cu, int total_rows, void* stream);
+
+/* The attention-probability dropout mask of one layer as keep-bits, laid out as the kernels' select masks:
+ * dropbits uint32 [B*A][ceil(L/32)][ceil(L/64)][64] (64-byte aligned), i.e. per (head, 32-query block, 64-key tile) 32 x uint64;
+ * word 16*kk + r, bit l <-> query 32*qb + (l & 31), key 64*kt + 32*kk + (r&3) + 8*(r>>2) + 4*(l>>5); bit = 1 keeps the entry.
+ * Every entry is an independent Bernoulli draw with P(drop) = round(p_drop * 2^n) / 2^n (n = mv_get_attn_planes() = 16: 0.1 -> 0.100006), a counter-based
+ * hash of (drop_key, word index): the same key reproduces the same mask.  Blocks whose queries or keys all lie beyond the
+ * sample's packed length (cu, nullable) are not written and never read.  Depends on the key only: it can run ahead of the
+ * forward on another stream.  */
+int mv_attn_dropmask(float p_drop, unsigned long long drop_key, int B, int L, int A, const int32_t* cu, uint32_t* dropbits,
+                     void* stream);
 
 /* dqkv [B*L,3H] from dctx [B*L,H]; `delta` is a [B,A,L] f32 scratch (rowsum(dctx*ctx)).  dtype (MV_F32, MV_BF16 or
  * MV_F16) is the encoding of qkv, ctx, dctx and dqkv alike. */
 int mv_attn_bwd(int dtype, const void* qkv, const void* ctx, const void* dctx, const float* lse,
                 const uint32_t* bits, const uint8_t* tileinfo,
                 void* dqkv, float* delta, int B, int L, int A, int dh,
-                float p_drop, unsigned long long drop_key, const int32_t* cu, int total_rows, void* stream);
+                float p_drop, const uint32_t* dropbits, const int32_t* cu, int total_rows, void* stream);
 
 /* ---- LayerNorm ------------------------------------------------------------------------------
  * y = (x-mean)/sqrt(var+eps)*gamma+beta over the last dim (HF LayerNorm eps=1e-12 in the

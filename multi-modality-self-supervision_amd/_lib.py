@@ -28,6 +28,8 @@ PROTOTYPES = {
     "mv_get_impl": [],
     "mv_build_info": [],
     "mv_set_gemm_variant": [i32, i32],
+    "mv_set_attn_planes": [i32],
+    "mv_get_attn_planes": [],
     "mv_gemm": [i32, i32, i32, i32, i32, i32, vp, i32, vp, i32, vp, i32, i32, vp, i32, vp, i32, i32, vp, i32, vp, i32, i32,
                 i32, vp, sz, i32, f32, u64, vp, vp, vp],
     "mv_mask_pack": [vp, i32, i32, i32, vp, vp, vp],
@@ -35,8 +37,9 @@ PROTOTYPES = {
     "mv_mlm_draws": [u64, i32, i32, i32, vp, vp, vp],
     "mv_mlm_corrupt": [vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "mv_pack_plan": [vp, i32, i32, vp, vp, vp, vp],
-    "mv_attn_fwd": [i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, u64, vp, i32, vp],
-    "mv_attn_bwd": [i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, u64, vp, i32, vp],
+    "mv_attn_fwd": [i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp, vp, i32, vp],
+    "mv_attn_dropmask": [f32, u64, i32, i32, i32, vp, vp, vp],
+    "mv_attn_bwd": [i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp, vp, i32, vp],
     "mv_layernorm_fwd": [i32, vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, f32, vp],
     "mv_layernorm_bwd": [i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, f32, u64, vp, vp],
     "mv_embed_fwd": [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, f32,
@@ -65,7 +68,7 @@ PROTOTYPES = {
     "mv_count_nonfinite": [vp, sz, vp, vp],
     "mv_scaler_update": [vp, i32, f32, f32, f32, f32, vp],
 }
-_RESTYPE = {"mv_set_impl": None, "mv_set_gemm_variant": None, "mv_build_info": C.c_char_p}
+_RESTYPE = {"mv_set_impl": None, "mv_set_gemm_variant": None, "mv_set_attn_planes": None, "mv_build_info": C.c_char_p}
 
 _lib = None
 

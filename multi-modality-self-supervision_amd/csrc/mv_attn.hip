@@ -144,30 +144,77 @@ struct AttnArgs {
   float scale;
   unsigned bytes_qkv, bytes_ctx;
   unsigned bytes_stat, bytes_bits;     // sizes of lse / delta ([B,A,L] f32) and of the mask words, for the LDS-DMA descriptors
-  DropCfg drop;   // attention-probability dropout; mask index = ((b*A + h)*L + q)*Lp + k, Lp = L rounded up to 4
-  int Lp;
+  // attention-probability dropout (drop_on): the mask is a tensor of precomputed keep-bits (mv_attn_dropmask): per (b*A + h,
+  // 32-query block, 64-key tile) 32 x u64, word 16*kk + r, bit l = keep(query 32*qb + (l & 31), key 64*kt + 32*kk + acc_row(r, l >> 5))
+  // -- i.e. the 64-lane select mask of accumulator register r of the forward / dQ kernels (queries on the lanes), and for the
+  // dK/dV kernel (keys on the lanes) one dword per key holding the bits of 32 queries.  No kernel hashes: one select per score
+  // element (the kernels are bound by vector-instruction issue).  Survivors are scaled by inv_keep.
+  int drop_on;
+  float inv_keep;
+  const uint32_t* dropbits;
+  unsigned bytes_dbits;
+  int NQB, NKT;     // 32-query blocks / 64-key tiles per (b, h) in dropbits
   // packed rows (nullable): sample b owns rows cu[b] .. cu[b+1]-1 of qkv / ctx / dctx / out / dqkv, i.e. only its first
   // cu[b+1]-cu[b] positions exist; mask words, lse, delta and the dropout counter keep their logical [B, L] indexing
   const int32_t* cu;
 };
-// keep-bits of the 4 consecutive keys k4..k4+3 (k4 % 4 == 0) of query row q
-// (the mask counter is (linear index) >> 2 with linear index = ((b*A + h)*L + q)*Lp + k4 < 2^34 (checked on the host); Lp and k4
-// are multiples of 4, so the counter is (bh*L + q)*(Lp/4) + k4/4 in plain 32-bit arithmetic -- no 64-bit multiplies per hash)
-__device__ __forceinline__ unsigned attn_drop_hash(const DropCfg& d, size_t bh, int L, int Lp, int q, int k4) {
-  return mv_hash32(((unsigned)bh * (unsigned)L + (unsigned)q) * ((unsigned)Lp >> 2) + ((unsigned)k4 >> 2), d.k0, d.k1);
+// ---- precomputed dropout keep-bits -------------------------------------------------------------------------------------------
+typedef unsigned long long u64x8 __attribute__((ext_vector_type(8)));
+// 16 select masks (one 32-key half of a tile) from a wave-uniform address: two scalar loads and their wait in ONE statement --
+// the compiler does not track an asm load, so the destination registers must be complete when the statement ends
+__device__ __forceinline__ void sload_masks16(const void* p, u64x8& m0, u64x8& m1) {
+  asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %2, 0x40\n\ts_waitcnt lgkmcnt(0)" : "=&s"(m0), "=&s"(m1) : "s"(p) : "memory");
+}
+// Selects by a 64-lane mask held in an SGPR pair: one VALU instruction (v_cndmask_b32 with an SGPR condition).  hipcc pads no hazard
+// for an asm statement, so the VGPR inputs must never be the direct result of an MFMA (18 wait states) or of a transcendental
+// (1 wait state): sel_set_else() is fed with fma results, sel_lane_after() names a second value `after` that a compiler-scheduled
+// VALU instruction computed FROM x, which orders the statement behind that instruction.
+__device__ __forceinline__ float sel_set_else(float if_set, float if_clear, unsigned long long m) {
+  float o;
+  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(o) : "v"(if_clear), "v"(if_set), "s"(m));
+  return o;
+}
+__device__ __forceinline__ float sel_lane_after(float x, float after, unsigned long long m) {
+  float o;
+  asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(o) : "v"(x), "s"(m), "v"(after));
+  return o;
+}
+// one bit of the keep-bits for any (query, key): the plain VALU kernels' view of the same tensor
+__device__ __forceinline__ bool attn_keep_bit(const unsigned long long* db, int NQB, int NKT, size_t bh, int q, int k) {
+  const int k32 = k & 31, r = ((k32 >> 3) << 2) | (k32 & 3), hf = (k32 >> 2) & 1;
+  const unsigned long long w = db[((bh * (size_t)NQB + (q >> 5)) * (size_t)NKT + (k >> 6)) * 32 + ((k >> 5) & 1) * 16 + r];
+  return (w >> ((q & 31) + 32 * hf)) & 1ull;
+}
+__device__ __forceinline__ float and_bits(float x, int t) { return __uint_as_float(__float_as_uint(x) & (unsigned)t); }
+__device__ __forceinline__ size_t dbits_block(const AttnArgs& a, size_t bh, int qb, int kt) {      // first u64 of a (32 x 64) block
+  return ((bh * (size_t)a.NQB + qb) * (size_t)a.NKT + kt) * 32;
 }
 
-// value of lane `e` of each quad (DPP quad_perm broadcast); e is a compile-time constant after unrolling
-template <int E> __device__ __forceinline__ unsigned quad_bcast_c(unsigned v) {
-  return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, E * 0x55, 0xf, 0xf, true);
-}
-__device__ __forceinline__ unsigned quad_bcast(unsigned v, int e) {
-  switch (e) {
-    case 0: return quad_bcast_c<0>(v);
-    case 1: return quad_bcast_c<1>(v);
-    case 2: return quad_bcast_c<2>(v);
-    default: return quad_bcast_c<3>(v);
+// One thread per 64-bit word.  The word's 64 keep decisions are 64 independent PL-bit uniforms compared with the threshold
+// thr = round(p * 2^PL), evaluated bit-sliced: PL bit-planes of 64 random bits each (two 32-bit hashes of a counter), most
+// significant plane first -- lt collects the lanes already known to be below the threshold, eq those still equal to its prefix.
+// drop = (x < thr), so P(drop) = thr / 2^PL.  2*PL hashes per 64 mask bits, no cross-lane work; the kernel is bound by the hashes'
+// quarter-rate multiplies, i.e. its time is proportional to PL (profiles/r03_notes.txt).
+template <int PL>
+__global__ __launch_bounds__(256) void attn_dropmask_kernel(unsigned k0, unsigned k1, unsigned thr16, int A, int L, int NQB, int NKT,
+                                                            const int32_t* __restrict__ cu, unsigned long long* __restrict__ out, size_t nwords) {
+  const size_t w = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (w >= nwords) return;
+  const size_t blk = w >> 5;
+  const int kt = (int)(blk % NKT), qb = (int)((blk / NKT) % NQB);
+  const int b = (int)(blk / ((size_t)NKT * NQB * A));
+  const int Lv = cu ? cu[b + 1] - cu[b] : L;
+  if (qb * 32 >= Lv || kt * 64 >= Lv) return;        // no kernel ever looks at a block without an existing query or key
+  const unsigned base = (unsigned)w * 32u;
+  unsigned long long lt = 0ull, eq = ~0ull;
+#pragma unroll
+  for (int j = PL - 1; j >= 0; --j) {
+    const unsigned long long x = ((unsigned long long)mv_hash32(base + 2 * j, k0, k1) << 32) | mv_hash32(base + 2 * j + 1, k0, k1);
+    const unsigned long long tb = 0ull - (unsigned long long)((thr16 >> j) & 1u);      // all ones where the threshold has this bit
+    lt |= eq & ~x & tb;
+    eq &= x ^ ~tb;
   }
+  out[w] = ~lt;
 }
 
 // dual-use LDS image of a [64 rows][64 x bf16] tile: 128-B rows, 16-B chunk index XORed with f(row)
@@ -210,11 +257,13 @@ __device__ __forceinline__ dma_rsrc_t dma_rsrc(const void* p, unsigned bytes) { 
   const unsigned long long v = (unsigned long long)(uintptr_t)p;
   return (dma_rsrc_t){(int)(unsigned)v, (int)((unsigned)(v >> 32) & 0xffffu), (int)bytes, 0x00020000};
 }
+// (M0 is compiler-reserved: it is written inside the SAME statement that reads it, as the CDNA guide prescribes; an "m0" clobber would
+// only draw "clobber list contains reserved registers" from hipcc -- ROCm 7.2 -- on every instantiation)
 __device__ __forceinline__ void lds_dma16(dma_rsrc_t rs, MV_LDS void* dst, unsigned voff) {   // dst: wave-uniform, lane i lands at +16 i
-  asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"((unsigned)(uintptr_t)dst), "v"(voff), "s"(rs) : "memory", "m0");
+  asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"((unsigned)(uintptr_t)dst), "v"(voff), "s"(rs) : "memory");
 }
 __device__ __forceinline__ void lds_dma4(dma_rsrc_t rs, MV_LDS void* dst, unsigned voff) {
-  asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dword %1, %2, 0 offen lds" ::"s"((unsigned)(uintptr_t)dst), "v"(voff), "s"(rs) : "memory", "m0");
+  asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dword %1, %2, 0 offen lds" ::"s"((unsigned)(uintptr_t)dst), "v"(voff), "s"(rs) : "memory");
 }
 template <int NW>
 __device__ __forceinline__ void tile_dma(dma_rsrc_t rs, unsigned bytes, size_t rowbase, int row0, int nrows, int ld,
@@ -442,17 +491,18 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_mfma_kernel(AttnArgs a) {
           for (int r = 0; r < 16; ++r) { const float pv = fexp2(st[kk][r] - mn); st[kk][r] = pv; ps += pv; }
       }
       lsum = lsum * alpha + ps;          // the normaliser sums the UNdropped probabilities
-      if (a.drop.thr) {
-        const size_t bh = (size_t)b * a.A + head;
+      if (a.drop_on) {
+        const unsigned long long* mp = (const unsigned long long*)a.dropbits + dbits_block(a, (size_t)b * a.A + head, q0 >> 5, cur);
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
+        for (int kk = 0; kk < 2; ++kk) {
+          u64x8 m0, m1;
+          sload_masks16(mp + 16 * kk, m0, m1);
 #pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const unsigned hh = attn_drop_hash(a.drop, bh, L, a.Lp, q_ok ? q : 0, k0 + 32 * kk + 8 * g + 4 * h);
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-              if (!mv_keep(hh, e, a.drop.thr)) st[kk][4 * g + e] = 0.f;
+          for (int r = 0; r < 8; ++r) {       // `ps` was computed from these values by compiler-scheduled adds: see sel_lane_after
+            st[kk][r] = sel_lane_after(st[kk][r], ps, m0[r]);
+            st[kk][8 + r] = sel_lane_after(st[kk][8 + r], ps, m1[r]);
           }
+        }
       }
       if (!__all(alpha == 1.0f)) {      // the running maximum rarely moves after the first tiles
 #pragma unroll
@@ -474,7 +524,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_mfma_kernel(AttnArgs a) {
   }
   if (!q_ok) return;
   const float ltot = lsum + __shfl_xor(lsum, 32, 64);
-  const float inv = (a.drop.thr ? a.drop.inv_keep : 1.0f) / ltot;
+  const float inv = (a.drop_on ? a.inv_keep : 1.0f) / ltot;
   bf16_t* orow = a.out + (rowbase + q) * (size_t)H + head * 64;
   bf16_t* orow2 = a.out2 ? a.out2 + (rowbase + q) * (size_t)H + head * 64 : nullptr;
 #pragma unroll
@@ -499,10 +549,10 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_mfma_kernel(AttnArgs a) {
 template <bool MASKED, bool DROP, bool TAIL, bool F16>
 __device__ __forceinline__ void dq_tile(const AttnArgs& a, const char* tK, const char* tV, const bf16x8 (&qf)[4], const bf16x8 (&dof)[4],
                                         f32x16 (&dq)[2], const uint32_t* myw, bool q_ok, int q, int b, int head, int k0, int Lv,
-                                        float lse2, float dlt, float c2, int lane) {
+                                        float lse2, float dlt, float c2, int lane, const unsigned long long* mp) {
   const int l31 = lane & 31, h = lane >> 5;
   const float dlt_s = dlt * a.scale;                          // ds = p * (dp' - delta) * scale, with the scale folded in
-  const float dscale = DROP ? a.drop.inv_keep * a.scale : a.scale;
+  const float dscale = DROP ? a.inv_keep * a.scale : a.scale;
 #pragma unroll
   for (int kk = 0; kk < 2; ++kk) {
     f32x16 st, dp;
@@ -515,12 +565,8 @@ __device__ __forceinline__ void dq_tile(const AttnArgs& a, const char* tK, const
     }
     uint32_t w = 0xffffffffu;
     if (MASKED) { const int wi = (k0 >> 5) + kk; w = (q_ok && wi < a.W) ? myw[wi] : 0xffffffffu; }
-    unsigned hq[4];
-    if (DROP) {
-#pragma unroll
-      for (int g = 0; g < 4; ++g)
-        hq[g] = attn_drop_hash(a.drop, (size_t)b * a.A + head, a.L, a.Lp, q_ok ? q : 0, k0 + 32 * kk + 8 * g + 4 * h);
-    }
+    u64x8 m0, m1;
+    if (DROP) sload_masks16(mp + 16 * kk, m0, m1);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int kr = acc_row(r, h);
@@ -532,9 +578,11 @@ __device__ __forceinline__ void dq_tile(const AttnArgs& a, const char* tK, const
         pv = fexp2(v - lse2);
       }
       if (TAIL) pv = (k0 + 32 * kk + kr >= Lv) ? 0.f : pv;
-      float dpr = dp[r];
-      if (DROP) dpr = mv_keep(hq[r >> 2], r & 3, a.drop.thr) ? dpr : 0.f;
-      st[r] = pv * fmaf(dpr, dscale, -dlt_s);
+      // ds = p * (keep ? dp * inv_keep * scale - delta * scale : -delta * scale): the select takes the fma's result, never dp[r]
+      // itself (an MFMA result feeding an asm statement would not get its wait states)
+      float t = fmaf(dp[r], dscale, -dlt_s);
+      if (DROP) t = sel_set_else(t, -dlt_s, r < 8 ? m0[r & 7] : m1[r & 7]);
+      st[r] = pv * t;
     }
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
@@ -619,15 +667,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_mfma_kernel(AttnArgs a) {
       const int k0 = cur * 64;
       const bool tail = (k0 + 64 > Lv);
       // one wave-uniform dispatch per tile: the element loops below contain no branches
-      const int variant = (cls == 1 ? 0 : 1) | (a.drop.thr ? 2 : 0) | (tail ? 4 : 0);
+      const unsigned long long* mp = a.drop_on ? (const unsigned long long*)a.dropbits + dbits_block(a, (size_t)b * a.A + head, q0 >> 5, cur) : nullptr;
+      const int variant = (cls == 1 ? 0 : 1) | (tail ? 2 : 0) | (a.drop_on ? 4 : 0);
+#define DQ_CALL(M_, D_, T_) dq_tile<M_, D_, T_, F16>(a, tK, tV, qf, dof, dq, myw, q_ok, q, b, head, k0, Lv, lse2, dlt, c2, lane, mp)
       switch (variant) {
-        case 0: dq_tile<false, false, false, F16>(a, tK, tV, qf, dof, dq, myw, q_ok, q, b, head, k0, Lv, lse2, dlt, c2, lane); break;
-        case 1: dq_tile<true, false, false, F16>(a, tK, tV, qf, dof, dq, myw, q_ok, q, b, head, k0, Lv, lse2, dlt, c2, lane); break;
-        case 2: dq_tile<false, true, false, F16>(a, tK, tV, qf, dof, dq, myw, q_ok, q, b, head, k0, Lv, lse2, dlt, c2, lane); break;
-        case 3: dq_tile<true, true, false, F16>(a, tK, tV, qf, dof, dq, myw, q_ok, q, b, head, k0, Lv, lse2, dlt, c2, lane); break;
-        case 4: case 5: dq_tile<true, false, true, F16>(a, tK, tV, qf, dof, dq, myw, q_ok, q, b, head, k0, Lv, lse2, dlt, c2, lane); break;
-        default: dq_tile<true, true, true, F16>(a, tK, tV, qf, dof, dq, myw, q_ok, q, b, head, k0, Lv, lse2, dlt, c2, lane); break;
+        case 0: DQ_CALL(false, false, false); break;
+        case 1: DQ_CALL(true, false, false); break;
+        case 2: case 3: DQ_CALL(true, false, true); break;
+        case 4: DQ_CALL(false, true, false); break;
+        case 5: DQ_CALL(true, true, false); break;
+        default: DQ_CALL(true, true, true); break;
       }
+#undef DQ_CALL
     }
     if (ATT_ISSUE_LATE && iss < nkt) issue();
     cur = next_tile(tmk.need, cur, nkt);
@@ -645,15 +696,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_mfma_kernel(AttnArgs a) {
 
 // ---- backward: dK, dV --------------------------------------------------------------------------
 // LDS stage layout: Q tile 8 KiB | dO tile 8 KiB | lse2[64] f32 | delta[64] f32 | words[64][4] u32
-#define KV_STAGE (8192 + 8192 + 256 + 256 + 1024)
+#define KV_STAGE (8192 + 8192 + 256 + 256 + 1024 + 1024)     // ... | keep-bit dwords [4 waves][2 query halves][32 keys] u32
 // One 64-query tile of the dK/dV pass for a wave's 32 keys (key on the lane).  MASKED: class-2 tile (mask words from LDS);
 // DROP: attention dropout on -- compile-time, so the element loops are branch-free.
 template <bool MASKED, bool DROP, bool F16>
 __device__ __forceinline__ void dkv_tile(const AttnArgs& a, const char* tQ, const char* tD, const float* s_lse, const float* s_dl,
                                          const uint32_t* s_w, const bf16x8 (&kf)[4], const bf16x8 (&vf)[4], f32x16 (&dk)[2],
-                                         f32x16 (&dv)[2], int b, int head, int cur, int key, int wid, float c2, int lane) {
+                                         f32x16 (&dv)[2], int b, int head, int cur, int key, int wid, float c2, int lane, const uint32_t* s_db) {
   const int l31 = lane & 31, h = lane >> 5;
-  const float dscale = DROP ? a.drop.inv_keep * a.scale : a.scale;
+  const float dscale = DROP ? a.inv_keep * a.scale : a.scale;
 #pragma unroll
   for (int qq = 0; qq < 2; ++qq) {
     f32x16 sc, dp;
@@ -672,9 +723,9 @@ __device__ __forceinline__ void dkv_tile(const AttnArgs& a, const char* tQ, cons
       f32x4 d4 = *(const f32x4*)(s_dl + qr0);
       l4 *= LOG2E;
       d4 *= a.scale;
-      unsigned hq = 0;
-      if (DROP)
-        hq = attn_drop_hash(a.drop, (size_t)b * a.A + head, a.L, a.Lp, min(cur * 64 + qr0 + (l31 & 3), a.L - 1), min(key, a.L - 1) & ~3);
+      // keep-bits: this key's dword holds the bits of the 32 queries of the half; element r is query acc_row(r, h) = (r&3) + 8*(r>>2) + 4*h
+      int wsh = 0;
+      if (DROP) wsh = (int)(s_db[wid * 64 + qq * 32 + l31] >> (4 * h));
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int r = 4 * g + e;
@@ -686,11 +737,9 @@ __device__ __forceinline__ void dkv_tile(const AttnArgs& a, const char* tQ, cons
           p = fexp2(fmaf(sc[r], c2, ((w >> l31) & 1u) ? 0.f : MASK_ADD * LOG2E) - l4[e]);
         }
         if (DROP) {
-          // the 4 lanes of a quad hold keys 4j..4j+3 = ONE mask group per query: lane e' of the quad hashed query
-          // qr0+e' (hq above); fetch the hash of query qr0+e from lane e of the quad (DPP quad broadcast)
-          const bool keep = mv_keep(quad_bcast(hq, e), l31 & 3, a.drop.thr);
-          sc[r] = p * fmaf(keep ? dp[r] : 0.f, dscale, -d4[e]);
-          pv[r] = keep ? p * a.drop.inv_keep : 0.f;
+          const int t = __builtin_amdgcn_sbfe(wsh, e + 8 * g, 1);      // 0 or all ones
+          sc[r] = p * fmaf(and_bits(dp[r], t), dscale, -d4[e]);
+          pv[r] = and_bits(p * a.inv_keep, t);
         } else {
           sc[r] = p * fmaf(dp[r], dscale, -d4[e]);
           pv[r] = p;
@@ -747,6 +796,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_mfma_kernel(AttnArgs a) {
   // stages (rows past Lv are zero-filled: a zero dO row and a zero delta make that row contribute nothing to dK or dV)
   const dma_rsrc_t rsdo = dma_rsrc(a.dctx, a.bytes_ctx);
   const dma_rsrc_t rsl = dma_rsrc(a.lse_in, a.bytes_stat), rsdl = dma_rsrc(a.delta, a.bytes_stat), rsw = dma_rsrc(a.bits, a.bytes_bits);
+  const bool use_db = a.drop_on != 0;
+  const dma_rsrc_t rsdb = dma_rsrc(a.dropbits, a.bytes_dbits);
+  // this lane's keep-bit dword inside a (32-query x 64-key) block: key half kk, then the accumulator order of the key (2*r + h)
+  const int kq32 = (lane & 31), kkw = (k0w >> 5) & 1;
+  const unsigned db_in_block = (unsigned)(kkw * 32 + 2 * (((kq32 >> 3) << 2) | (kq32 & 3)) + ((kq32 >> 2) & 1));
   const TileMasks tmk = load_tile_masks_k(a.info, b, T, ka, min(k0w >> 6, T - 1), lane);
   int cur = next_tile(tmk.need, -1, nqt);
   int iss = cur, issued = 0, done = 0;
@@ -766,6 +820,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_mfma_kernel(AttnArgs a) {
       if (wid & 1) lds_dma4(rsdl, (MV_LDS void*)(st_ + 16384 + 256), qi < Lv ? off : a.bytes_stat);
       else lds_dma4(rsl, (MV_LDS void*)(st_ + 16384), qi < Lv ? off : a.bytes_stat);
     }
+    if (use_db) {   // keep-bit dwords of this wave's 32 keys for the tile's two 32-query halves (lane >> 5)
+      const size_t blk = dbits_block(a, (size_t)b * a.A + head, 2 * iss + (lane >> 5), k0w >> 6);
+      const unsigned off = (unsigned)((blk * 2 + db_in_block) * 4);
+      lds_dma4(rsdb, (MV_LDS void*)(st_ + 16384 + 512 + 1024 + wid * 256), (k0w < Lv && (2 * iss + (lane >> 5)) * 32 < Lv) ? off : a.bytes_dbits);
+    }
     ++issued;
     iss = next_tile(tmk.need, iss, nqt);
   };
@@ -773,11 +832,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_mfma_kernel(AttnArgs a) {
   for (int i = 0; i < DKV_NS - 1; ++i)
     if (iss < nqt) issue();
   while (cur < nqt) {
-    att_wait_stage<6>(issued - done - 1);
+    if (use_db) att_wait_stage<7>(issued - done - 1);
+    else att_wait_stage<6>(issued - done - 1);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     if (!ATT_ISSUE_LATE && iss < nqt) issue();
     const char* st = smem + (done % DKV_NS) * KV_STAGE;
+    const uint32_t* s_db = (const uint32_t*)(st + 16384 + 512 + 1024);
     const char* tQ = st;
     const char* tD = st + 8192;
     const float* s_lse = (const float*)(st + 16384);
@@ -785,13 +846,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_mfma_kernel(AttnArgs a) {
     const uint32_t* s_w = (const uint32_t*)(st + 16384 + 512);
     const int cls = !wave_on ? 0 : (((tmk.w_is1 >> cur) & 1) ? 1 : (((tmk.w_nz >> cur) & 1) ? 2 : 0));
     if (wave_on && cls != 0) {
-      const int variant = (cls == 1 ? 0 : 1) | (a.drop.thr ? 2 : 0);        // one wave-uniform dispatch per tile
+      const int variant = (cls == 1 ? 0 : 1) | (use_db ? 2 : 0);        // one wave-uniform dispatch per tile
+#define DKV_CALL(M_, D_) dkv_tile<M_, D_, F16>(a, tQ, tD, s_lse, s_dl, s_w, kf, vf, dk, dv, b, head, cur, key, wid, c2, lane, s_db)
       switch (variant) {
-        case 0: dkv_tile<false, false, F16>(a, tQ, tD, s_lse, s_dl, s_w, kf, vf, dk, dv, b, head, cur, key, wid, c2, lane); break;
-        case 1: dkv_tile<true, false, F16>(a, tQ, tD, s_lse, s_dl, s_w, kf, vf, dk, dv, b, head, cur, key, wid, c2, lane); break;
-        case 2: dkv_tile<false, true, F16>(a, tQ, tD, s_lse, s_dl, s_w, kf, vf, dk, dv, b, head, cur, key, wid, c2, lane); break;
-        default: dkv_tile<true, true, F16>(a, tQ, tD, s_lse, s_dl, s_w, kf, vf, dk, dv, b, head, cur, key, wid, c2, lane); break;
+        case 0: DKV_CALL(false, false); break;
+        case 1: DKV_CALL(true, false); break;
+        case 2: DKV_CALL(false, true); break;
+        default: DKV_CALL(true, true); break;
       }
+#undef DKV_CALL
     }
     if (ATT_ISSUE_LATE && iss < nqt) issue();
     cur = next_tile(tmk.need, cur, nqt);
@@ -818,8 +881,9 @@ struct SArgs {
   const uint32_t* bits; float* lse; const float* lse_in; float* delta;
   int B, L, A, H, W, dh;
   float scale;
-  DropCfg drop;
-  int Lp;
+  const unsigned long long* dropbits;   // nullable = dropout off; layout of AttnArgs::dropbits
+  float inv_keep;
+  int NQB, NKT;
 };
 
 // delta[b,h,q] = sum_d dctx*ctx   (one wave per (b,q,h))
@@ -873,10 +937,7 @@ __global__ __launch_bounds__(256) void attn_fwd_simple_kernel(SArgs<T> a) {
     l = l * alpha + wave_sum(p);
     m = mn;
     float pd = p;
-    if (a.drop.thr && k < a.L) {
-      const unsigned hh = attn_drop_hash(a.drop, (size_t)b * a.A + hd, a.L, a.Lp, q, k & ~3);
-      pd = mv_keep(hh, k & 3, a.drop.thr) ? p * a.drop.inv_keep : 0.f;
-    }
+    if (a.dropbits && k < a.L) pd = attn_keep_bit(a.dropbits, a.NQB, a.NKT, (size_t)b * a.A + hd, q, k) ? p * a.inv_keep : 0.f;
     sp[wl][lane] = pd;
     o0 *= alpha; o1 *= alpha;
     const int kn = min(64, a.L - k0);
@@ -923,10 +984,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_simple_kernel(SArgs<T> a) {
       float acc = 0.f, dp = 0.f;
       for (int i = 0; i < dh; ++i) { acc = fmaf(sq[wl][i], ldf<T>(kp + i), acc); dp = fmaf(sdo[wl][i], ldf<T>(vp + i), dp); }
       const float s = acc * a.scale + (((wrow[k >> 5] >> (k & 31)) & 1u) ? 0.f : MASK_ADD);
-      if (a.drop.thr) {
-        const unsigned hh = attn_drop_hash(a.drop, (size_t)b * a.A + hd, a.L, a.Lp, q, k & ~3);
-        dp = mv_keep(hh, k & 3, a.drop.thr) ? dp * a.drop.inv_keep : 0.f;
-      }
+      if (a.dropbits) dp = attn_keep_bit(a.dropbits, a.NQB, a.NKT, (size_t)b * a.A + hd, q, k) ? dp * a.inv_keep : 0.f;
       ds = expf(s - lse) * (dp - dl) * a.scale;
     }
     sds[wl][lane] = ds;
@@ -975,10 +1033,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_simple_kernel(SArgs<T> a) {
       const float s = acc * a.scale + (((w >> (k & 31)) & 1u) ? 0.f : MASK_ADD);
       p = expf(s - a.lse_in[sb + q]);
       float keepf = 1.0f;
-      if (a.drop.thr) {
-        const unsigned hh = attn_drop_hash(a.drop, (size_t)b * a.A + hd, a.L, a.Lp, q, k & ~3);
-        keepf = mv_keep(hh, k & 3, a.drop.thr) ? a.drop.inv_keep : 0.f;
-      }
+      if (a.dropbits) keepf = attn_keep_bit(a.dropbits, a.NQB, a.NKT, (size_t)b * a.A + hd, q, k) ? a.inv_keep : 0.f;
       ds = p * (keepf * dp - a.delta[sb + q]) * a.scale;
       p *= keepf;
     }
@@ -1002,11 +1057,54 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_simple_kernel(SArgs<T> a) {
 // =========================================================================================
 // host
 // =========================================================================================
+static inline size_t dropbits_words(int B, int L, int A) { return (size_t)B * A * ((L + 31) / 32) * ((L + 63) / 64) * 64; }   // uint32 count
+// bits per uniform of mv_attn_dropmask (8, 12 or 16): P(drop) = thr / 2^planes with thr = round(p * 2^planes); survivors are scaled
+// by 2^planes / (2^planes - thr).  p = 0.1: 16 -> 0.100006, 12 -> 0.100098, 8 -> 0.101563.
+int g_mv_attn_planes = 16;
+extern "C" void mv_set_attn_planes(int planes) { g_mv_attn_planes = (planes == 8 || planes == 12) ? planes : 16; }
+extern "C" int mv_get_attn_planes(void) { return g_mv_attn_planes; }
+static inline unsigned attn_thr16(float p) {          // threshold at the current plane count
+  const int full = 1 << g_mv_attn_planes;
+  int t = (int)(p * (float)full + 0.5f);
+  return (unsigned)(t < 1 ? 1 : (t > full - 1 ? full - 1 : t));
+}
+static inline float attn_inv_keep(float p) {
+  const float full = (float)(1 << g_mv_attn_planes);
+  return p > 0.f ? full / (full - (float)attn_thr16(p)) : 1.0f;
+}
+// p_drop > 0 needs the keep-bits (64-byte aligned: scalar loads of 64-byte pieces; 32-bit buffer offsets)
+static inline int dropbits_check(float p_drop, const uint32_t* dropbits, int B, int L, int A) {
+  if (p_drop <= 0.f) return MV_OK;
+  if (p_drop >= 1.f || !dropbits) return MV_E_ARG;
+  if ((((uintptr_t)dropbits) & 63) || dropbits_words(B, L, A) * 4 >= 0x7fffffffULL) return MV_E_SHAPE;
+  return MV_OK;
+}
+
+extern "C" int mv_attn_dropmask(float p_drop, unsigned long long drop_key, int B, int L, int A, const int32_t* cu, uint32_t* dropbits,
+                                void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!dropbits || B <= 0 || L <= 0 || A <= 0 || p_drop <= 0.f || p_drop >= 1.f) return MV_E_ARG;
+  const size_t nwords = dropbits_words(B, L, A) / 2;         // 64-bit words
+  if (nwords * 32 >= (1ull << 32)) return MV_E_SHAPE;         // 32 hash counters per word, 32-bit counters
+  const int rc = dropbits_check(p_drop, dropbits, B, L, A);
+  if (rc) return rc;
+#define DM_LAUNCH(PL_)                                                                                                                  \
+  hipLaunchKernelGGL(attn_dropmask_kernel<PL_>, dim3((unsigned)((nwords + 255) / 256)), dim3(256), 0, stream, (unsigned)(drop_key & 0xffffffffULL), \
+                     (unsigned)(drop_key >> 32), attn_thr16(p_drop), A, L, (L + 31) / 32, (L + 63) / 64, cu, (unsigned long long*)dropbits, nwords)
+  if (g_mv_attn_planes == 8) DM_LAUNCH(8);
+  else if (g_mv_attn_planes == 12) DM_LAUNCH(12);
+  else DM_LAUNCH(16);
+#undef DM_LAUNCH
+  MV_CHECK_LAUNCH();
+  return MV_OK;
+}
+
 template <typename T>
-static int launch_simple_fwd(const void* qkv, const uint32_t* bits, void* ctx, float* lse, int B, int L, int A, int dh,
-                             DropCfg drop, hipStream_t stream) {
+static int launch_simple_fwd(const void* qkv, const uint32_t* bits, void* ctx, float* lse, int B, int L, int A, int dh, float p_drop,
+                             const uint32_t* dropbits, hipStream_t stream) {
   SArgs<T> s{};
-  s.drop = drop; s.Lp = (L + 3) & ~3;
+  s.dropbits = p_drop > 0.f ? (const unsigned long long*)dropbits : nullptr; s.inv_keep = attn_inv_keep(p_drop);
+  s.NQB = (L + 31) / 32; s.NKT = (L + 63) / 64;
   s.qkv = (const T*)qkv; s.out = (T*)ctx; s.bits = bits; s.lse = lse;
   s.B = B; s.L = L; s.A = A; s.H = A * dh; s.W = (L + 31) / 32; s.dh = dh; s.scale = 1.0f / sqrtf((float)dh);
   const long long waves = (long long)B * A * L;
@@ -1016,14 +1114,14 @@ static int launch_simple_fwd(const void* qkv, const uint32_t* bits, void* ctx, f
 }
 
 extern "C" int mv_attn_fwd(int dtype, const void* qkv, const uint32_t* bits, const uint8_t* tileinfo, void* ctx, void* ctx_bf16,
-                           float* lse, int B, int L, int A, int dh, float p_drop, unsigned long long drop_key, const int32_t* cu,
-                           int total_rows, void* stream_) {
+                           float* lse, int B, int L, int A, int dh, float p_drop, const uint32_t* dropbits,
+                           const int32_t* cu, int total_rows, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  const DropCfg drop = mv_make_drop(p_drop, drop_key);
-  if ((size_t)B * A * L * ((L + 3) & ~3) >= (1ull << 34)) return MV_E_SHAPE;   // mask counter is 32 bits of (index >> 2)
   if (!qkv || !bits || !tileinfo || !ctx || !lse || B <= 0 || L <= 0 || A <= 0 || dh <= 0) return MV_E_ARG;
   if (!mv_dtype_ok(dtype)) return MV_E_DTYPE;
   if (ctx_bf16 && dtype != MV_F16) return MV_E_DTYPE;     // the second context output is the bf16 copy of an f16 forward
+  const int rcd = dropbits_check(p_drop, dropbits, B, L, A);
+  if (rcd) return rcd;
   const int H = A * dh;
   if (mv_is16(dtype) && g_mv_impl == 0) {
     if (dh != 64) return MV_E_SHAPE;
@@ -1037,7 +1135,9 @@ extern "C" int mv_attn_fwd(int dtype, const void* qkv, const uint32_t* bits, con
     a.B = B; a.L = L; a.A = A; a.H = H; a.W = (L + 31) / 32; a.T = (L + 63) / 64;
     a.scale = 1.0f / sqrtf((float)dh);
     a.bytes_qkv = (unsigned)bq;
-    a.drop = drop; a.Lp = (L + 3) & ~3;
+    a.drop_on = p_drop > 0.f; a.inv_keep = attn_inv_keep(p_drop);
+    a.dropbits = a.drop_on ? dropbits : nullptr; a.bytes_dbits = (unsigned)(dropbits_words(B, L, A) * 4);
+    a.NQB = (L + 31) / 32; a.NKT = (L + 63) / 64;
     static bool attr = false;
     if (!attr) {
       (void)hipFuncSetAttribute((const void*)attn_fwd_mfma_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, FWD_NS * 16384);
@@ -1051,19 +1151,20 @@ extern "C" int mv_attn_fwd(int dtype, const void* qkv, const uint32_t* bits, con
   }
   if (dh > 128 || cu) return MV_E_SHAPE;       // packed rows: MFMA kernels only
   if (dtype == MV_F16) {                         // VALU cross-check of the f16 forward (mv_set_impl(1))
-    int rc = launch_simple_fwd<f16_t>(qkv, bits, ctx, lse, B, L, A, dh, drop, stream);
+    int rc = launch_simple_fwd<f16_t>(qkv, bits, ctx, lse, B, L, A, dh, p_drop, dropbits, stream);
     if (rc == MV_OK && ctx_bf16) rc = mv_cast(ctx, MV_F16, ctx_bf16, MV_BF16, (size_t)B * L * H, stream_);
     return rc;
   }
-  return dtype == MV_F32 ? launch_simple_fwd<float>(qkv, bits, ctx, lse, B, L, A, dh, drop, stream)
-                         : launch_simple_fwd<bf16_t>(qkv, bits, ctx, lse, B, L, A, dh, drop, stream);
+  return dtype == MV_F32 ? launch_simple_fwd<float>(qkv, bits, ctx, lse, B, L, A, dh, p_drop, dropbits, stream)
+                         : launch_simple_fwd<bf16_t>(qkv, bits, ctx, lse, B, L, A, dh, p_drop, dropbits, stream);
 }
 
 template <typename T>
 static int launch_simple_bwd(const void* qkv, const void* ctx, const void* dctx, const float* lse, const uint32_t* bits,
-                             void* dqkv, float* delta, int B, int L, int A, int dh, DropCfg drop, hipStream_t stream) {
+                             void* dqkv, float* delta, int B, int L, int A, int dh, float p_drop, const uint32_t* dropbits, hipStream_t stream) {
   SArgs<T> s{};
-  s.drop = drop; s.Lp = (L + 3) & ~3;
+  s.dropbits = p_drop > 0.f ? (const unsigned long long*)dropbits : nullptr; s.inv_keep = attn_inv_keep(p_drop);
+  s.NQB = (L + 31) / 32; s.NKT = (L + 63) / 64;
   s.qkv = (const T*)qkv; s.ctx = (const T*)ctx; s.dctx = (const T*)dctx; s.dqkv = (T*)dqkv; s.bits = bits;
   s.lse_in = lse; s.delta = delta;
   s.B = B; s.L = L; s.A = A; s.H = A * dh; s.W = (L + 31) / 32; s.dh = dh; s.scale = 1.0f / sqrtf((float)dh);
@@ -1080,12 +1181,13 @@ static int launch_simple_bwd(const void* qkv, const void* ctx, const void* dctx,
 
 extern "C" int mv_attn_bwd(int dtype, const void* qkv, const void* ctx, const void* dctx, const float* lse, const uint32_t* bits,
                            const uint8_t* tileinfo, void* dqkv, float* delta, int B, int L, int A, int dh, float p_drop,
-                           unsigned long long drop_key, const int32_t* cu, int total_rows, void* stream_) {
+                           const uint32_t* dropbits, const int32_t* cu, int total_rows, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  const DropCfg drop = mv_make_drop(p_drop, drop_key);
   if (!qkv || !ctx || !dctx || !lse || !bits || !tileinfo || !dqkv || !delta || B <= 0 || L <= 0 || A <= 0 || dh <= 0)
     return MV_E_ARG;
   if (!mv_dtype_ok(dtype)) return MV_E_DTYPE;
+  const int rcd = dropbits_check(p_drop, dropbits, B, L, A);
+  if (rcd) return rcd;
   const int H = A * dh;
   if (mv_is16(dtype) && g_mv_impl == 0) {
     if (dh != 64) return MV_E_SHAPE;
@@ -1101,7 +1203,9 @@ extern "C" int mv_attn_bwd(int dtype, const void* qkv, const void* ctx, const vo
     a.scale = 1.0f / sqrtf((float)dh);
     a.bytes_qkv = (unsigned)bq; a.bytes_ctx = (unsigned)bc;
     a.bytes_stat = (unsigned)((size_t)B * A * L * 4); a.bytes_bits = (unsigned)((size_t)B * L * a.W * 4);
-    a.drop = drop; a.Lp = (L + 3) & ~3;
+    a.drop_on = p_drop > 0.f; a.inv_keep = attn_inv_keep(p_drop);
+    a.dropbits = a.drop_on ? dropbits : nullptr; a.bytes_dbits = (unsigned)(dropbits_words(B, L, A) * 4);
+    a.NQB = (L + 31) / 32; a.NKT = (L + 63) / 64;
     static bool attr = false;
     if (!attr) {
       (void)hipFuncSetAttribute((const void*)attn_bwd_dq_mfma_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, DQ_NS * 16384);
@@ -1120,7 +1224,7 @@ extern "C" int mv_attn_bwd(int dtype, const void* qkv, const void* ctx, const vo
     return MV_OK;
   }
   if (dh > 128 || cu) return MV_E_SHAPE;
-  if (dtype == MV_F16) return launch_simple_bwd<f16_t>(qkv, ctx, dctx, lse, bits, dqkv, delta, B, L, A, dh, drop, stream);
-  return dtype == MV_F32 ? launch_simple_bwd<float>(qkv, ctx, dctx, lse, bits, dqkv, delta, B, L, A, dh, drop, stream)
-                         : launch_simple_bwd<bf16_t>(qkv, ctx, dctx, lse, bits, dqkv, delta, B, L, A, dh, drop, stream);
+  if (dtype == MV_F16) return launch_simple_bwd<f16_t>(qkv, ctx, dctx, lse, bits, dqkv, delta, B, L, A, dh, p_drop, dropbits, stream);
+  return dtype == MV_F32 ? launch_simple_bwd<float>(qkv, ctx, dctx, lse, bits, dqkv, delta, B, L, A, dh, p_drop, dropbits, stream)
+                         : launch_simple_bwd<bf16_t>(qkv, ctx, dctx, lse, bits, dqkv, delta, B, L, A, dh, p_drop, dropbits, stream);
 }

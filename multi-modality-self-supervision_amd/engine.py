@@ -181,6 +181,7 @@ class Engine:
         self._w2t, self._w2t_ev, self._w2t_stale = None, None, True
         self.head_on_side = True  # the tied decoder's weight gradient on the side stream (see _mlm_backward)
         self.fused_colsum = os.environ.get("MV_FUSED_COLSUM", "1") != "0"   # bias gradients from partial sums of the producing kernels
+        self._mask_stream = None      # third stream: the attention-dropout keep-bits of every layer are generated at the start of a forward
         self._dE_ev = None
         self._opt_ev = None       # overlapped AdamW: parameter range -> event (see adamw_step)
         self.head_splitk = True  # split-K for the decoder's input gradient (see _mlm_backward)
@@ -481,6 +482,23 @@ class Engine:
                       x, pre0, mean0, rstd0, B, N, T, H, cfg.vocab_size, cfg.max_pos, cfg.ln_eps, p_drop=pd,
                       drop_key=dk[(self.SITE_EMB, 0)], rowmap=rowmap, n_rows=M, x0_bf16=xb2(x, x_b))
         S["layers"] = []
+        db_ev = None
+        if pd > 0:
+            # attention-probability dropout: the mask is a tensor of keep-bits (mv_attn_dropmask) that the forward and both backward
+            # kernels select with.  It depends on the keys (and the packed lengths) only: all layers' bits are generated now, on
+            # their own stream, under the embedding / first projection kernels
+            if self._mask_stream is None:
+                self._mask_stream = torch.cuda.Stream(device=dev)
+            ms, main_ = self._mask_stream, torch.cuda.current_stream()
+            ms.wait_stream(main_)                     # the previous step's backward has read the buffers; `cu` is ready
+            db_ev = []
+            with torch.cuda.stream(ms):
+                for l in range(cfg.layers):
+                    dbl = self._buf(f"dropbits{l}", (ops.dropbits_numel(B, Lq, A),), torch.int32)
+                    ops.attn_dropmask(pd, dk[(self.SITE_ATTN, l)], B, Lq, A, dbl, cu=cu)
+                    ev = torch.cuda.Event()
+                    ev.record(ms)
+                    db_ev.append((dbl, ev))
         for l in range(cfg.layers):
             self._wait_opt(f"layer{l}")
             p = f"enc.encoder.layer.{l}."
@@ -493,8 +511,12 @@ class Engine:
             ctx, ctx_b = self._pair(f"ctx{l}", (M, H))
             a_["ctx"] = ctx_b
             lse = a_["lse"] = self._buf(f"lse{l}", (B, A, Lq), f32)
-            ops.attn_fwd(qkv, bits, tinfo, ctx, lse, B, Lq, A, dh, p_drop=pd, drop_key=dk[(self.SITE_ATTN, l)], cu=cu,
-                         total_rows=M, ctx_bf16=xb2(ctx, ctx_b))
+            a_["dropbits"] = None
+            if db_ev is not None:
+                a_["dropbits"] = db_ev[l][0]
+                torch.cuda.current_stream().wait_event(db_ev[l][1])
+            ops.attn_fwd(qkv, bits, tinfo, ctx, lse, B, Lq, A, dh, p_drop=pd, cu=cu,
+                         total_rows=M, ctx_bf16=xb2(ctx, ctx_b), dropbits=a_["dropbits"])
             Mr = M                  # rows the rest of this layer runs on
             if l == cfg.layers - 1 and S["sel"] is not None:
                 # last layer: only the labelled rows and the first row of every sample are consumed downstream
@@ -846,8 +868,7 @@ class Engine:
                 ops.gemm(dproj1, self.w[p + "attention.output.dense.weight"], dctx, tb=True, M=M, N=H, K=H)
             M = M_all
             ops.attn_bwd(a_["qkv"], a_["ctx"], dctx, a_["lse"], S["bits"], S["tinfo"], dqkv, delta, B, Lq, A, dh, cu=S["cu"],
-                         total_rows=M, p_drop=pd,
-                         drop_key=dk[(self.SITE_ATTN, l)])
+                         total_rows=M, p_drop=pd, dropbits=a_["dropbits"])
             fork()
             with torch.cuda.stream(side):
                 ops.colsum(dqkv, 3 * H, M, 3 * H, gbqkv, accumulate=True, unscale=us)

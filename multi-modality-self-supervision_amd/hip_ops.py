@@ -114,17 +114,51 @@ def pack_plan(desc, B, Lq):
     return cu, rowmap, inv
 
 
-def attn_fwd(qkv, bits, tileinfo, ctx, lse, B, Lq, A, dh, p_drop=0.0, drop_key=0, cu=None, total_rows=0, ctx_bf16=None):
+def dropbits_numel(B, Lq, A):
+    """uint32 elements of one layer's attention-dropout keep-bits (mv_attn_dropmask)."""
+    return B * A * ((Lq + 31) // 32) * ((Lq + 63) // 64) * 64
+
+
+def attn_dropmask(p_drop, drop_key, B, Lq, A, out, cu=None):
+    """Keep-bits of the attention-probability dropout mask of (p_drop, drop_key), in the layout the MFMA kernels select with."""
+    L.require_cuda(out, cu)
+    if out.dtype != torch.int32 or out.numel() < dropbits_numel(B, Lq, A):
+        raise TypeError("attn_dropmask: out must be int32 with dropbits_numel(B, L, A) elements")
+    rc = _lib().mv_attn_dropmask(float(p_drop), int(drop_key), B, Lq, A, L.ptr(cu), L.ptr(out), L.stream_ptr())
+    L.check(rc, "mv_attn_dropmask")
+    return out
+
+
+def attn_keep_mask(dropbits, B, Lq, A):
+    """The keep-bits of mv_attn_dropmask decoded to a bool tensor [B, A, L, L] (keep[b, h, q, k]) -- inspection / tests.  Blocks the
+    generator skipped (beyond a sample's packed length) decode to whatever the buffer held."""
+    NQB, NKT = (Lq + 31) // 32, (Lq + 63) // 64
+    w = dropbits[:dropbits_numel(B, Lq, A)].view(B, A, NQB, NKT, 2, 16, 2).to(torch.int64) & 0xFFFFFFFF     # [b, h, qb, kt, kk, r, half]
+    i = torch.arange(32, device=dropbits.device, dtype=torch.int64)
+    bit = ((w.unsqueeze(-1) >> i) & 1).bool()                      # [..., r, half, query-in-block]
+    r = torch.arange(16, device=dropbits.device)
+    key_of = ((r & 3) + 8 * (r >> 2)).view(16, 1) + 4 * torch.arange(2, device=dropbits.device).view(1, 2)      # [r, half] -> key in the 32-half
+    out = torch.zeros((B, A, NQB, NKT, 2, 32, 32), dtype=torch.bool, device=dropbits.device)             # [.., kk, key32, q32]
+    out[:, :, :, :, :, key_of.reshape(-1), :] = bit.reshape(B, A, NQB, NKT, 2, 32, 32)
+    # -> [b, h, qb, q32, kt, kk, key32]
+    out = out.permute(0, 1, 2, 6, 3, 4, 5).reshape(B, A, NQB * 32, NKT * 64)
+    return out[:, :, :Lq, :Lq]
+
+
+def attn_fwd(qkv, bits, tileinfo, ctx, lse, B, Lq, A, dh, p_drop=0.0, cu=None, total_rows=0, ctx_bf16=None, dropbits=None):
+    """p_drop > 0 needs `dropbits` (attn_dropmask)."""
     if ctx.dtype != qkv.dtype or (ctx_bf16 is not None and ctx_bf16.dtype != torch.bfloat16):
         raise TypeError("attn_fwd: ctx shares qkv's encoding; the second output is bf16")
+    L.require_cuda(dropbits)
     rc = _lib().mv_attn_fwd(L.dt_of(qkv), L.ptr(qkv), L.ptr(bits), L.ptr(tileinfo), L.ptr(ctx), L.ptr(ctx_bf16), L.ptr(lse), B, Lq, A, dh,
-                            float(p_drop), int(drop_key), L.ptr(cu), int(total_rows), L.stream_ptr())
+                            float(p_drop), L.ptr(dropbits), L.ptr(cu), int(total_rows), L.stream_ptr())
     L.check(rc, "mv_attn_fwd")
 
 
-def attn_bwd(qkv, ctx, dctx, lse, bits, tileinfo, dqkv, delta, B, Lq, A, dh, p_drop=0.0, drop_key=0, cu=None, total_rows=0):
+def attn_bwd(qkv, ctx, dctx, lse, bits, tileinfo, dqkv, delta, B, Lq, A, dh, p_drop=0.0, cu=None, total_rows=0, dropbits=None):
+    L.require_cuda(dropbits)
     rc = _lib().mv_attn_bwd(L.dt_of(qkv), L.ptr(qkv), L.ptr(ctx), L.ptr(dctx), L.ptr(lse), L.ptr(bits), L.ptr(tileinfo),
-                            L.ptr(dqkv), L.ptr(delta), B, Lq, A, dh, float(p_drop), int(drop_key), L.ptr(cu), int(total_rows),
+                            L.ptr(dqkv), L.ptr(delta), B, Lq, A, dh, float(p_drop), L.ptr(dropbits), L.ptr(cu), int(total_rows),
                             L.stream_ptr())
     L.check(rc, "mv_attn_bwd")
 
@@ -314,6 +348,17 @@ def set_impl(impl: int):
 
 def get_impl() -> int:
     return int(_lib().mv_get_impl())
+
+
+def set_attn_planes(planes: int):
+    """Bits per uniform of the attention-dropout mask generator (16, 12 or 8); see mv_set_attn_planes."""
+    _lib().mv_set_attn_planes(int(planes))
+
+
+def attn_drop_prob(p_drop: float) -> float:
+    """The drop probability attn_dropmask realises for p_drop at the current plane count."""
+    n = int(_lib().mv_get_attn_planes())
+    return round(p_drop * (1 << n)) / float(1 << n)
 
 
 def set_gemm_variant(force: int = 0, nj: int = 0):

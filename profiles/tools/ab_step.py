@@ -47,6 +47,9 @@ VARIANTS = {
               ("AdamW on the side stream under the next forward", lambda: setattr(step, "overlap_optimizer", True))],
     "fcs": [("FFN-up bias gradient: column-sum kernel over dz", lambda: setattr(model.engine, "fused_colsum", False)),
             ("FFN-up bias gradient: partial sums from the dz GEMM", lambda: setattr(model.engine, "fused_colsum", True))],
+    "planes": [("attention-dropout mask generator: 16 bits per uniform", lambda: mv.hip_ops.set_attn_planes(16)),
+               ("12 bits", lambda: mv.hip_ops.set_attn_planes(12)), ("8 bits", lambda: mv.hip_ops.set_attn_planes(8))],
+    "drop": [("dropout off (eval-mode forward inside the training step)", lambda: model.eval()), ("dropout 0.1", lambda: model.train())],
     "tail": [("last layer on all rows", lambda: setattr(step, "tail_rows", False)), ("last layer on consumed rows", lambda: setattr(step, "tail_rows", True))],
 }
 which = sys.argv[1] if len(sys.argv) > 1 else "pack"

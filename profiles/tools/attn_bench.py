@@ -51,10 +51,17 @@ for (N, S, fam) in ((36, 473, "full"), (36, 473, "s2s"), (36, 473, "noncross"), 
     delta = torch.empty(B, A, L, device=dev)
     fl = 4.0 * A * dh * float((vl * vl).sum())          # forward FLOPs on the rows that exist (dense within them)
     for p in (0.0, 0.1):
-        tf = bench(lambda: ops.attn_fwd(qkv_f, bits, ti, ctx, lse, B, L, A, dh, p_drop=p, drop_key=12345, cu=cu, total_rows=M, ctx_bf16=ctx_b))
+        db = None
+        extra = ""
+        if p > 0:
+            db = torch.empty(ops.dropbits_numel(B, L, A), dtype=torch.int32, device=dev)
+            tgs = []
+            for pl in (8, 12, 16):
+                ops.set_attn_planes(pl)
+                tgs.append(bench(lambda: ops.attn_dropmask(p, 12345, B, L, A, db, cu=cu)))
+            extra = f"  | keep-bits generator, 8 / 12 / 16 bits per uniform: {tgs[0]:5.1f} / {tgs[1]:5.1f} / {tgs[2]:5.1f} us"
+        tf = bench(lambda: ops.attn_fwd(qkv_f, bits, ti, ctx, lse, B, L, A, dh, p_drop=p, cu=cu, total_rows=M, ctx_bf16=ctx_b, dropbits=db))
         cb = ctx_b if ctx_b is not None else ctx
-        tb = bench(lambda: ops.attn_bwd(qkv, cb, dctx, lse, bits, ti, dqkv, delta, B, L, A, dh, p_drop=p, drop_key=12345, cu=cu, total_rows=M))
-        gb = torch.zeros(3 * H, device=dev)
-        tcs = bench(lambda: ops.colsum(dqkv, 3 * H, M, 3 * H, gb))
+        tb = bench(lambda: ops.attn_bwd(qkv, cb, dctx, lse, bits, ti, dqkv, delta, B, L, A, dh, p_drop=p, cu=cu, total_rows=M, dropbits=db))
         print(f"L={L} {fam:9s} rows {M:6d} p={p}: fwd {tf:7.1f} us ({fl / tf / 1e6:6.0f} TF/s)  bwd {tb:7.1f} us ({2.5 * fl / tb / 1e6:6.0f} TF/s)"
-              f"  | colsum(dqkv) {tcs:5.1f} us", flush=True)
+              + extra, flush=True)

@@ -26,7 +26,7 @@ lse = torch.empty(B, A, L, device=dev)
 dqkv = torch.empty_like(qkv)
 delta = torch.empty(B, A, L, device=dev)
 for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 3):
-    ops.attn_fwd(qkv_f, bits, ti, ctx, lse, B, L, A, dh, p_drop=0.1, drop_key=12345, cu=cu, total_rows=M, ctx_bf16=ctx_b)
-    ops.attn_bwd(qkv, ctx_b, dctx, lse, bits, ti, dqkv, delta, B, L, A, dh, p_drop=0.1, drop_key=12345, cu=cu, total_rows=M)
+    ops.attn_fwd(qkv_f, bits, ti, ctx, lse, B, L, A, dh, p_drop=0.0, cu=cu, total_rows=M, ctx_bf16=ctx_b)
+    ops.attn_bwd(qkv, ctx_b, dctx, lse, bits, ti, dqkv, delta, B, L, A, dh, p_drop=0.0, cu=cu, total_rows=M)
 torch.cuda.synchronize()
 print("rows", M)

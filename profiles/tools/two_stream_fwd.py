@@ -45,7 +45,7 @@ class Part:
     def layer(self, l):
         M = self.M
         ops.gemm(self.x, Wq, self.qkv, M=M, N=3 * H, K=H, bias=bq, epi=EPI_BIAS, c3=self.qkvb)
-        ops.attn_fwd(self.qkv, self.bits, self.ti, self.ctx, self.lse, self.B, L, A, dh, p_drop=0.1, drop_key=77 + l, cu=self.cu, total_rows=M,
+        ops.attn_fwd(self.qkv, self.bits, self.ti, self.ctx, self.lse, self.B, L, A, dh, p_drop=0.0, cu=self.cu, total_rows=M,
                      ctx_bf16=self.ctxb)
         ops.gemm(self.ctx, Wo, self.pre, M=M, N=H, K=H, bias=bo, epi=EPI_BIAS_RES, r=self.x, p_drop=0.1, drop_key=5 + l)
         ops.layernorm_fwd(self.pre, g, be, self.a, self.mean, self.rstd, M, H, 1e-12, y_bf16=self.ab)

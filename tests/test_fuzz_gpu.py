@@ -136,12 +136,13 @@ def test_attention_random_configurations(seed):
     dctx = _rnd(g, (M, H), torch.bfloat16, 1.0)
     ctx = torch.full((M, H), float("nan"), dtype=torch.bfloat16, device=DEV)
     lse = torch.zeros((B, A, Lq), dtype=torch.float32, device=DEV)
-    ops.attn_fwd(qkv, bits, tinfo, ctx, lse, B, Lq, A, dh, p_drop=p_drop, drop_key=key, cu=cu, total_rows=M)
-    keep = None
+    keep, db = None, None
     if p_drop > 0:
-        Lp = (Lq + 3) // 4 * 4
-        k8, sc = ops.dropout_mask(p_drop, key, B * A * Lq * Lp, DEV)
-        keep = k8.view(B, A, Lq, Lp)[..., :Lq].double() * sc
+        db = torch.zeros(ops.dropbits_numel(B, Lq, A), dtype=torch.int32, device=DEV)
+        ops.attn_dropmask(p_drop, key, B, Lq, A, db, cu=cu)
+        thr = round(p_drop * 65536)
+        keep = ops.attn_keep_mask(db, B, Lq, A).double() * (65536.0 / (65536.0 - thr))
+    ops.attn_fwd(qkv, bits, tinfo, ctx, lse, B, Lq, A, dh, p_drop=p_drop, cu=cu, total_rows=M, dropbits=db)
     qd = qkv.double().requires_grad_(True)
     rctx = _attn_ref(qd, cu.cpu(), B, A, Lq, mask, keep)
     cfg = dict(seed=seed, fam=fam, B=B, A=A, N=N, S=S, p=p_drop, n_ids=n_ids.tolist())
@@ -149,7 +150,7 @@ def test_attention_random_configurations(seed):
     assert _relerr(ctx, rctx) < 2e-2, cfg
     dqkv = torch.full((M, 3 * H), float("nan"), dtype=torch.bfloat16, device=DEV)
     delta = torch.zeros((B, A, Lq), dtype=torch.float32, device=DEV)
-    ops.attn_bwd(qkv, ctx, dctx, lse, bits, tinfo, dqkv, delta, B, Lq, A, dh, p_drop=p_drop, drop_key=key, cu=cu, total_rows=M)
+    ops.attn_bwd(qkv, ctx, dctx, lse, bits, tinfo, dqkv, delta, B, Lq, A, dh, p_drop=p_drop, cu=cu, total_rows=M, dropbits=db)
     (rctx * dctx.double()).sum().backward()
     assert torch.isfinite(dqkv.float()).all(), cfg
     assert _relerr(dqkv, qd.grad) < 2.5e-2, cfg

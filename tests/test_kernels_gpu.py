@@ -320,8 +320,9 @@ def test_attention_fwd_bwd(impl, fam, B, A, N, S):
 @pytest.mark.parametrize("impl", ["mfma", "mfma_f16", "simple_bf16", "f32"])
 @pytest.mark.parametrize("fam,B,A,N,S", [("full", 2, 2, 16, 45), ("s2s", 2, 3, 36, 150), ("bar", 2, 2, 36, 221), ("full", 1, 12, 100, 409)])
 def test_attention_dropout_follows_the_mask_function(impl, fam, B, A, N, S):
-    """Attention-probability dropout (HF BertSelfAttention.dropout): forward and both backward kernels regenerate the mask that
-    mv_dropout_mask defines for this site -- checked by applying that mask in an fp64 restatement and differentiating it."""
+    """Attention-probability dropout (HF BertSelfAttention.dropout): the mask is the keep-bit tensor of mv_attn_dropmask; the forward
+    and both backward kernels (MFMA: select masks / per-key dwords; plain VALU: bit look-ups) must all apply exactly it -- checked by
+    decoding the bits, applying them in an fp64 restatement and differentiating that.  P(drop) = 6554 / 65536."""
     dt = torch.float32 if impl == "f32" else (torch.float16 if impl.endswith("f16") else torch.bfloat16)
     ops.set_impl(1 if impl.startswith("simple") else 0)
     try:
@@ -333,14 +334,22 @@ def test_attention_dropout_follows_the_mask_function(impl, fam, B, A, N, S):
         bits = torch.zeros((B, Lq, (Lq + 31) // 32), dtype=torch.int32, device=DEV)
         tinfo = torch.zeros((B, (Lq + 63) // 64, (Lq + 63) // 64), dtype=torch.uint8, device=DEV)
         ops.mask_pack(mask, bits, tinfo)
-        Lp = (Lq + 3) // 4 * 4                     # mask index ((b*A + h)*L + q)*Lp + k (include/medvill.h, mv_attn_fwd)
-        keep, sc = ops.dropout_mask(p, key, B * A * Lq * Lp, DEV)
-        keep = keep.view(B, A, Lq, Lp)[..., :Lq].double()
+        db = torch.zeros(ops.dropbits_numel(B, Lq, A), dtype=torch.int32, device=DEV)
+        ops.attn_dropmask(p, key, B, Lq, A, db)
+        keep = ops.attn_keep_mask(db, B, Lq, A).double()
+        sc = 65536.0 / (65536.0 - 6554.0)
         frac = float(keep.mean())
-        assert abs(frac - (1 - 26 / 256)) < 4 * math.sqrt(0.1 * 0.9 / keep.numel()) + 1e-3 and sc == pytest.approx(256 / 230)
+        assert abs(frac - (1 - 6554 / 65536)) < 4 * math.sqrt(0.1 * 0.9 / keep.numel()) + 1e-4
+        db2 = torch.zeros_like(db)
+        ops.attn_dropmask(p, key + 1, B, Lq, A, db2)
+        assert not torch.equal(db, db2)                                            # another key, another mask
+        k2 = ops.attn_keep_mask(db2, B, Lq, A).double()
+        assert abs(float((keep * k2).mean()) - frac * float(k2.mean())) < 5 * math.sqrt(0.09 / keep.numel()) + 1e-4   # and an independent one
         ctx = torch.zeros((B, Lq, H), dtype=dt, device=DEV)
         lse = torch.zeros((B, A, Lq), dtype=torch.float32, device=DEV)
-        ops.attn_fwd(qkv.view(B * Lq, 3 * H), bits, tinfo, ctx, lse, B, Lq, A, dh, p_drop=p, drop_key=key)
+        ops.attn_fwd(qkv.view(B * Lq, 3 * H), bits, tinfo, ctx, lse, B, Lq, A, dh, p_drop=p, dropbits=db)
+        with pytest.raises(RuntimeError, match="MV_E_ARG"):                        # no mask tensor, no dropout: never a silent p = 0
+            ops.attn_fwd(qkv.view(B * Lq, 3 * H), bits, tinfo, ctx.clone(), lse.clone(), B, Lq, A, dh, p_drop=p)
         qd = qkv.double().requires_grad_(True)
         q, k, v = [t.view(B, Lq, A, dh).permute(0, 2, 1, 3) for t in qd.split(H, dim=-1)]
         add = (1.0 - (mask if mask.dim() == 3 else mask[:, None, :].expand(B, Lq, Lq)).double()) * -10000.0
@@ -350,7 +359,7 @@ def test_attention_dropout_follows_the_mask_function(impl, fam, B, A, N, S):
         assert relerr(ctx, rctx) < tol
         dqkv = torch.zeros((B, Lq, 3 * H), dtype=dt, device=DEV)
         delta = torch.zeros((B, A, Lq), dtype=torch.float32, device=DEV)
-        ops.attn_bwd(qkv.view(B * Lq, 3 * H), ctx, dctx, lse, bits, tinfo, dqkv, delta, B, Lq, A, dh, p_drop=p, drop_key=key)
+        ops.attn_bwd(qkv.view(B * Lq, 3 * H), ctx, dctx, lse, bits, tinfo, dqkv, delta, B, Lq, A, dh, p_drop=p, dropbits=db)
         (rctx * dctx.double()).sum().backward()
         assert relerr(dqkv, qd.grad) < (1e-5 if impl == "f32" else 2.5e-2)
     finally:
@@ -895,3 +904,59 @@ def test_gemm_writes_partial_column_sums(dt, epi, M, N, K):
             ops.gemm(a, b, c, M=M, N=N, K=K, colsum_part=part)
         finally:
             ops.set_gemm_variant(0, 0)
+
+
+# ------------------------------------------------------------------------------------------ attention dropout: keep-bits
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("fam,B,A,N,S,packed", [("full", 2, 2, 16, 45, False), ("s2s", 3, 4, 36, 473, False), ("bar", 2, 2, 36, 221, False),
+                                                 ("full", 4, 3, 36, 300, True), ("mixed", 4, 2, 36, 150, True), ("full", 1, 12, 100, 665, True)])
+def test_attention_dropout_keep_bits_every_tile_class_and_packed_rows(dt, fam, B, A, N, S, packed):
+    """The MFMA kernels' dropout (select masks from scalar loads in the forward / dQ kernels, per-key dwords through the LDS-DMA ring
+    in the dK/dV kernel) on every tile class -- fully visible, mixed, ragged tail, skipped -- over padded and packed rows, against an
+    fp64 restatement that applies the decoded keep-bits; blocks beyond a sample's packed length are never written."""
+    dh, Lq, p, key = 64, N + S + 3, 0.1, 0xABCDEF12345
+    H = A * dh
+    g = torch.Generator().manual_seed(9)
+    n_ids = torch.randint(2, S + 2, (B,), generator=g)
+    fams = [("s2s" if i % 2 else "full") for i in range(B)] if fam == "mixed" else fam
+    desc = D.MaskDesc.make(fams, N, S, n_ids, DEV)
+    mask = (D.mixed_mask(N, S, n_ids, torch.arange(B) % 2 == 1) if fam == "mixed" else D.build_mask(fam, N, S, n_ids)).to(DEV)
+    bits = torch.zeros((B, Lq, (Lq + 31) // 32), dtype=torch.int32, device=DEV)
+    tinfo = torch.zeros((B, (Lq + 63) // 64, (Lq + 63) // 64), dtype=torch.uint8, device=DEV)
+    ops.mask_build(desc.desc, B, Lq, bits, tinfo)
+    cu, M, lens = None, B * Lq, [Lq] * B
+    if packed:
+        cu, rowmap, inv = ops.pack_plan(desc.desc, B, Lq)
+        M = int(cu[-1])
+        lens = (cu[1:] - cu[:-1]).tolist()
+    db = torch.full((ops.dropbits_numel(B, Lq, A),), 0x5A5A5A5A, dtype=torch.int32, device=DEV)
+    ops.attn_dropmask(p, key, B, Lq, A, db, cu=cu)
+    w = db.view(B, A, (Lq + 31) // 32, (Lq + 63) // 64, 64)
+    for b in range(B):                                       # unwritten exactly where no query or no key exists
+        for qb in range(w.shape[2]):
+            for kt in range(w.shape[3]):
+                untouched = bool((w[b, :, qb, kt] == 0x5A5A5A5A).all())
+                assert untouched == (qb * 32 >= lens[b] or kt * 64 >= lens[b]), (b, qb, kt)
+    keep = ops.attn_keep_mask(db, B, Lq, A).double() * (65536.0 / (65536.0 - 6554.0))
+    qkv, dctx = rnd((M, 3 * H), dt, 51), rnd((M, H), dt, 52)
+    ctx = torch.zeros((M, H), dtype=dt, device=DEV)
+    lse = torch.zeros((B, A, Lq), dtype=torch.float32, device=DEV)
+    ops.attn_fwd(qkv, bits, tinfo, ctx, lse, B, Lq, A, dh, p_drop=p, cu=cu, total_rows=M, dropbits=db)
+    dq = torch.zeros((M, 3 * H), dtype=dt, device=DEV)
+    delta = torch.zeros((B, A, Lq), dtype=torch.float32, device=DEV)
+    ops.attn_bwd(qkv, ctx, dctx, lse, bits, tinfo, dq, delta, B, Lq, A, dh, p_drop=p, cu=cu, total_rows=M, dropbits=db)
+    # fp64 restatement sample by sample on the rows that exist
+    qd = qkv.double().requires_grad_(True)
+    outs, row0 = [], 0
+    for b in range(B):
+        n = lens[b]
+        x = qd[row0:row0 + n]
+        q, k, v = [t.view(n, A, dh).permute(1, 0, 2) for t in x.split(H, dim=-1)]
+        add = (1.0 - mask[b, :n, :n].double()) * -10000.0
+        pr = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(dh) + add[None], -1) * keep[b, :, :n, :n]
+        outs.append((pr @ v).permute(1, 0, 2).reshape(n, H))
+        row0 += n
+    rctx = torch.cat(outs)
+    assert relerr(ctx, rctx) < (4e-3 if dt == torch.float16 else 2e-2)
+    (rctx * dctx.double()).sum().backward()
+    assert relerr(dq, qd.grad) < (6e-3 if dt == torch.float16 else 2.5e-2)
