@@ -83,11 +83,15 @@ def cpu_baseline(cfgname, steps=3):
                        f"same shape ({c['name']}); host CPU: {model}")
 
 
-def pmc_traffic():
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/, written by
-    profiles/tools/pmc_traffic.py from separate FETCH_SIZE / WRITE_SIZE runs): an offline measurement of the same
-    kernel on the same shape, not of this run.  None when the file is absent."""
-    p = os.path.join(ROOT, "profiles", "r02_dominant_kernel_pmc.json")
+HBM_PEAK_GBS = 8000.0           # MI355X HBM3E (MI355X_MICROARCH.md)
+RIDGE_FLOP_PER_BYTE = PEAK_BF16_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)      # 312.5: below it a kernel is HBM-bound by the roofline
+
+
+def pmc_traffic(case):
+    """HBM bytes per launch of a kernel from the committed rocprofv3 PMC passes (profiles/r03_<case>_pmc.json, written by
+    profiles/tools/r03_condense.py from separate FETCH_SIZE / WRITE_SIZE runs of profiles/tools/dominant.py <case>): an offline
+    measurement of the same kernel on the same operands, not of this run.  None when the file is absent."""
+    p = os.path.join(ROOT, "profiles", f"r03_{case}_pmc.json")
     try:
         with open(p) as f:
             d = json.load(f)
@@ -96,41 +100,77 @@ def pmc_traffic():
         return None, "no committed PMC pass for this build"
 
 
-def time_dominant_kernel(eng, B, L):
-    """The FFN-up projection of one layer ([B*L,768] x [3072,768]^T + bias, GELU and GELU' epilogue, all the outputs the
-    training step writes) alone: HIP events around 20 launches on the stream it is launched on."""
-    import torch
-    import medvill_amd.hip_ops as ops
-    from medvill_amd._lib import EPI_BIAS_GELU_D
-    M, H, I = B * L, eng.cfg.hidden, eng.cfg.intermediate
-    p = "enc.encoder.layer.0."
-    x = eng._buf("a0", (M, H), eng.fadt)
-    out, out_b = eng._pair("i0", (M, I))
-    dg = eng._buf("dgelu0", (M, I), eng.fadt)
-    w, bias = eng.wf[p + "intermediate.dense.weight"], eng.p[p + "intermediate.dense.bias"]
-    c3 = out_b if eng.dual else None
-    st = torch.cuda.current_stream()
-    reps = 20
+def time_kernel_case(case):
+    """One of the step's heaviest kernels alone: HIP events around 20 launches on the stream it is launched on, on the seeded
+    operands of profiles/tools/dominant.py -- the SAME definition the committed rocprofv3 summaries (profiles/r03_<case>_kernel_stats.txt)
+    were taken with, so `achieved` can be recomputed from that file's average duration."""
+    sys.path.insert(0, os.path.join(ROOT, "profiles", "tools"))
+    import dominant
+    m = dominant.time_case(case, reps=20)
+    traffic, note = pmc_traffic(case)
+    tfl = m["flop"] / m["ms"] / 1e9
+    gbs = m["bytes"] / m["ms"] / 1e6
+    ai = m["flop"] / m["bytes"]
+    bound = "mfma" if ai >= RIDGE_FLOP_PER_BYTE else "hbm"
+    return dict(kernel=m["kernel"], ms=m["ms"], tflops=tfl, algorithmic_flop=m["flop"], algorithmic_bytes=m["bytes"],
+                arithmetic_intensity_flop_per_byte=ai, bound=bound, mfma_frac=tfl / PEAK_BF16_TFLOPS, hbm_frac=gbs / HBM_PEAK_GBS,
+                algorithmic_gb_per_s=gbs, hbm_traffic_pmc_bytes=traffic, traffic_note=note,
+                profile=f"profiles/r03_{case}_kernel_stats.txt")
 
-    def launch():
-        ops.gemm(x, w, out, M=M, N=I, K=H, bias=bias, epi=EPI_BIAS_GELU_D, c2=dg, c3=c3)
-    for _ in range(3):
-        launch()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record(st)
-    for _ in range(reps):
-        launch()
-    e1.record(st)
-    e1.synchronize()
-    ms = e0.elapsed_time(e1) / reps
-    fl = 2.0 * M * H * I
-    nout = 3 if eng.dual else 2
-    enc = "f16" if eng.fadt == torch.float16 else "bf16"
-    traffic, note = pmc_traffic()
-    return dict(kernel=f"gemm_ring_kernel<NT, 256x256x64, {enc} operands> {M}x{I}x{H} +bias+GELU (writes gelu(z) and gelu'(z)"
-                       + (" in f16 and gelu(z) again in bf16 for the weight-gradient product)" if eng.dual else ")"),
-                ms=ms, tflops=fl / ms / 1e9, algorithmic_flop=fl, algorithmic_bytes=2.0 * (M * H + I * H + nout * M * I),
-                hbm_traffic_pmc_bytes=traffic, traffic_note=note)
+
+def drop_in_user_timings(mv, model, step, cfg, dev, B, N, S, n):
+    """(i) CXRBERT_Trainer._run_epoch over a host-side loader of the reference's 9-tuples (dataset_origin.py:181: CPU tensors, int64
+    [B,L,L] masks of 134 MB per batch) -- H2D copies, mask recognition and its sampled verification included, per step;
+    (ii) the literal model API: CXRBERT.forward() -> [B,L,V] f32 logits -> torch CrossEntropyLoss -> backward() -> fused AdamW, B = 16."""
+    import contextlib
+    import time
+    from types import SimpleNamespace
+    import torch
+    out = {}
+    with contextlib.redirect_stdout(sys.stderr):       # the trainer prints like the reference's; stdout carries the ONE JSON line only
+        _drop_in_user_timings(mv, model, step, cfg, dev, B, N, S, n, out, time, SimpleNamespace, torch)
+    return out
+
+
+def _drop_in_user_timings(mv, model, step, cfg, dev, B, N, S, n, out, time, SimpleNamespace, torch):
+    args_t = SimpleNamespace(with_cuda=True, weight_load=False, bert_model="bert-base-scratch", lr=1e-5, log_freq=10, mlm_task=True,
+                             itm_task=True, cuda_devices=None, dropout_prob=0.1)
+    tr = None
+    for fam in ("full", "bar"):
+        host = []
+        for i in range(2):
+            b = mv.data.synthetic_batch(cfg.vocab_size, B, N, S, fam, seed=4321 + i, device="cpu")
+            host.append((b["cls_tok"], b["input_txt"], b["txt_labels"], b["attn_mask"], (b["img_feats"], b["img_pos"]), b["segment"],
+                         b["is_aligned"], b["sep_tok"], torch.zeros(B)))
+        if tr is None:
+            torch.manual_seed(1234)
+            tr = mv.CXRBERT_Trainer(args_t, host * 2, None, config=cfg)
+            tr.model.train()
+        tr._run_epoch(host * 2, 0, True)                # warm-up: workspaces, the first batches' every-entry mask checks
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        tr._run_epoch(host * (n + 1), 0, True)
+        torch.cuda.synchronize()
+        out[f"trainer_hostloader_{fam}_ms_per_step"] = (time.perf_counter() - t0) / (2 * (n + 1)) * 1e3
+    del tr
+    b16 = mv.data.synthetic_batch(cfg.vocab_size, 16, N, S, "full", seed=999, device=dev)
+    ce_m, ce_i = torch.nn.CrossEntropyLoss(ignore_index=-100), torch.nn.CrossEntropyLoss()
+    eng = model.engine
+
+    def one(t):
+        mlm, itm = model(b16["cls_tok"], b16["input_txt"], b16["attn_mask"], b16["segment"], (b16["img_feats"], b16["img_pos"]), b16["sep_tok"])
+        loss = ce_m(mlm.transpose(1, 2), b16["txt_labels"]) + ce_i(itm, b16["is_aligned"])
+        loss.backward()
+        eng.adamw_step(t, lr=1e-5)
+    step.sync()
+    one(1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for t in range(n):
+        one(t + 2)
+    torch.cuda.synchronize()
+    out["dropin_forward_backward_b16_ms"] = (time.perf_counter() - t0) / n * 1e3
+    return out
 
 
 def spawn_ranks(args):
@@ -256,6 +296,19 @@ def main():
             # both, so they always run the padded layout
             extras["bar_ms_per_step"], _ = timed(step, make_batches("bar", n=2), 2, n2)
             extras["noncross_ms_per_step"], _ = timed(step, make_batches("noncross", n=2), 2, n2)
+            # BASELINE.json configs 3 and 5 on this build, so that they are witnessed by the driver's run too
+            extras["c3_ms_per_step"], _ = timed(step, make_batches("mixed", n=2), 2, n2)
+            if world == 1:
+                extras.update(drop_in_user_timings(mv, model, step, cfg, dev, B, N, S, n2))
+                c5 = CONFIGS["c5"]
+                cfg5 = mv.ModelConfig(max_pos=c5["max_pos"])
+                torch.manual_seed(1234)
+                m5 = mv.CXRBERT(cfg5, None, dtype=torch.bfloat16, device=dev, fwd_operand=args.fwd_operand, grad_operand=args.grad_operand)
+                m5.train()
+                st5 = mv.TrainStep(m5, lr=1e-5, overlap_optimizer=True)
+                b5 = [mv.data.synthetic_batch(cfg5.vocab_size, B, c5["N"], c5["S"], c5["family"], seed=77 + i, device=dev) for i in range(2)]
+                extras["c5_ms_per_step"], _ = timed(st5, b5, 2, n2)
+                del m5, st5, b5
     if rank == 0:
         f_fwd = flops_fwd_per_sample(cfg.hidden, cfg.intermediate, cfg.vocab_size, cfg.img_hidden, cfg.layers, L, N)
         f_step = 3.0 * f_fwd
@@ -273,7 +326,11 @@ def main():
             f_enc -= (rows_mean - (n_lab + 1.0)) * (2.0 * Hh * Hh + 4.0 * Hh * Ii)
         f_exec = 3.0 * (2.0 * N * cfg.img_hidden * Hh + f_enc + 2.0 * Hh * Hh + n_lab * (2.0 * Hh * Hh + 2.0 * Hh * Vv) + 4.0 * Hh)
         executed = value / world * f_exec / 1e12
-        kern = time_dominant_kernel(model.engine, B, L)
+        # dominant kernel: the FFN-up GEMM with its fused epilogue (largest single launch of the step; its symbol, the 256x256 ring
+        # kernel, and the persistent weight-gradient kernel each take ~20 % of the step's kernel time: profiles/r03_bench_kernel_stats.txt).
+        # The weight-gradient GEMM is reported beside it: its call is two kernels (split-K partials + reduction), timed together.
+        kern = time_kernel_case("ffn1")
+        kern_dw = time_kernel_case("dw")
         eng = model.engine
         pps = lambda ms: (world * B / (ms / 1e3)) if ms else None
         out = {
@@ -284,6 +341,7 @@ def main():
             "config": {"workload": c["name"], "per_gpu_batch": B, "global_batch": B * world, "seq_len": L, "regions": N,
                        "mask": c["family"], "layers": cfg.layers, "hidden": cfg.hidden, "vocab": cfg.vocab_size,
                        "parallelism": f"dp{world}", "optimizer": "HF AdamW fused", "dropout": cfg.dropout,
+                       "dropout_realised": {"hidden_state_sites": 6554 / 65536, "attention_probabilities": mv.hip_ops.attn_drop_prob(cfg.dropout)},
                        "precision": ("16-bit MFMA operands, fp32 accumulate / statistics / master weights / optimizer; forward operands "
                                      "f16-encoded, gradient-product operands " + ("bf16-encoded (every stored activation in both encodings)" if eng.dual
                                                                                  else "f16-encoded under a dynamic loss scale (device-side overflow check, "
@@ -306,14 +364,26 @@ def main():
                        "bar_mask_ms_per_step": extras.get("bar_ms_per_step"), "bar_mask_pairs_per_s": pps(extras.get("bar_ms_per_step")),
                        "noncross_mask_ms_per_step": extras.get("noncross_ms_per_step"),
                        "noncross_mask_pairs_per_s": pps(extras.get("noncross_ms_per_step")),
+                       "c3_mixed_mask_ms_per_step": extras.get("c3_ms_per_step"), "c3_pairs_per_s": pps(extras.get("c3_ms_per_step")),
+                       "c5_L768_s2s_ms_per_step": extras.get("c5_ms_per_step"), "c5_pairs_per_s": pps(extras.get("c5_ms_per_step")),
+                       # what a user of the reference's own interfaces gets (host-resident 9-tuples with int64 [B,L,L] masks through
+                       # CXRBERT_Trainer; CXRBERT.forward + torch cross-entropy + backward at B = 16): see drop_in_user_timings
+                       "trainer_hostloader_full_ms_per_step": extras.get("trainer_hostloader_full_ms_per_step"),
+                       "trainer_hostloader_bar_ms_per_step": extras.get("trainer_hostloader_bar_ms_per_step"),
+                       "dropin_forward_backward_b16_ms": extras.get("dropin_forward_backward_b16_ms"),
                        "rccl_ranks": rccl_ranks, "dist_backend": backend, "allreduce_exposed_ms": exposed_ms,
                        "mlm_loss": float(st[0] / max(float(st[1]), 1.0)), "itm_loss": float(st[3] / max(float(st[4]), 1.0))},
             # dominant kernel (the FFN-up GEMM, largest single share of the step): algorithmic FLOPs per launch / its
             # average duration, HIP events around 20 launches on its own stream (time_dominant_kernel); traffic = HBM bytes
             # per launch from the committed rocprofv3 PMC passes of the same kernel and shape (profiles/), not of this run
-            "roofline": {"bound": "mfma", "achieved": kern["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": kern["tflops"] / PEAK_BF16_TFLOPS, "traffic": kern["hbm_traffic_pmc_bytes"],
-                         "kernel": kern,
+            "roofline": {"bound": kern["bound"],
+                         "achieved": kern["tflops"] if kern["bound"] == "mfma" else kern["algorithmic_gb_per_s"],
+                         "peak": PEAK_BF16_TFLOPS if kern["bound"] == "mfma" else HBM_PEAK_GBS,
+                         "unit": "TFLOP/s" if kern["bound"] == "mfma" else "GB/s",
+                         "frac": kern["mfma_frac"] if kern["bound"] == "mfma" else kern["hbm_frac"],
+                         "traffic": kern["hbm_traffic_pmc_bytes"],
+                         "ridge_flop_per_byte": RIDGE_FLOP_PER_BYTE,
+                         "kernel": kern, "weight_gradient_gemm": kern_dw,
                          "step": {"achieved": executed, "frac": executed / PEAK_BF16_TFLOPS,
                                   "convention": "EXECUTED FLOPs of the whole step (valid rows, labelled rows) / dense 16-bit MFMA peak",
                                   "dense_tflops": dense, "dense_frac": dense / PEAK_BF16_TFLOPS, "flop_per_sample_dense": f_step,

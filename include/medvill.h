@@ -344,7 +344,9 @@ int mv_maxpool3x3s2(int dtype, const void* x, void* y, int B, int H, int W, int 
 /* ---- dropout mask (inspection / tests) -----------------------------------------------------------
  * The kernels above never store dropout masks: they regenerate them from a counter-based hash of
  * (drop_key, linear element index).  keep[i] = 1 if element i survives; an element is dropped with
- * probability round(p_drop*256)/256 and survivors are scaled by *scale_out (HOST pointer, nullable). */
+ * probability round(p_drop*65536)/65536 and survivors are scaled by *scale_out (HOST pointer, nullable).
+ * These are the masks of the hidden-state sites (embeddings, both projections); the attention-probability site's mask is
+ * the keep-bit tensor of mv_attn_dropmask. */
 int mv_dropout_mask(float p_drop, unsigned long long drop_key, size_t n, uint8_t* keep, float* scale_out,
                     void* stream);
 

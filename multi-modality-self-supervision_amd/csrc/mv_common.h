@@ -133,10 +133,11 @@ __device__ __forceinline__ void gelu_erf_and_grad(float z, float& g, float& d) {
   d = fmaf(z * 0.39894228040143267794f, e, cdf);
 }
 
-// ---- dropout: counter-based mask, regenerated (never stored) in the backward kernels --------------------------
-// One 32-bit hash per group of 4 consecutive elements (linear index >> 2), one byte per element; an element is
-// dropped when its byte < thr, i.e. with probability thr/256 (p = 0.1 -> thr = 26 -> 0.1016; survivors are scaled by
-// 1/(1 - thr/256) so the expectation is preserved exactly).  Keys are derived on the host per (step, site, layer).
+// ---- dropout of the hidden-state sites: counter-based mask, regenerated (never stored) in the backward kernels -----------
+// One 32-bit hash per PAIR of consecutive elements (linear index >> 1), 16 bits per element; an element is dropped when its
+// half-word < thr, i.e. with probability thr/65536 (p = 0.1 -> thr = 6554 -> 0.100006; survivors are scaled by 1/(1 - thr/65536),
+// so the expectation is preserved exactly).  Keys are derived on the host per (step, site, layer).  (The attention-probability
+// site uses a stored keep-bit tensor instead: mv_attn_dropmask.)
 struct DropCfg {
   unsigned k0, k1, thr;   // thr == 0: dropout off
   float inv_keep;
@@ -149,27 +150,30 @@ __device__ __forceinline__ unsigned mv_hash32(unsigned x, unsigned k0, unsigned 
   x ^= x >> 16;
   return x;
 }
-__device__ __forceinline__ bool mv_keep(unsigned h, int e, unsigned thr) { return ((h >> (8 * e)) & 0xffu) >= thr; }
+__device__ __forceinline__ bool mv_keep(unsigned h, int e, unsigned thr) { return ((h >> (16 * e)) & 0xffffu) >= thr; }    // e = 0, 1
 // 4 consecutive elements starting at linear index idx (idx % 4 == 0)
 __device__ __forceinline__ f32x4 mv_drop4(f32x4 v, size_t idx, const DropCfg& d) {
-  const unsigned h = mv_hash32((unsigned)(idx >> 2), d.k0, d.k1);
-#pragma unroll
-  for (int e = 0; e < 4; ++e) v[e] = mv_keep(h, e, d.thr) ? v[e] * d.inv_keep : 0.f;
+  const unsigned c = (unsigned)(idx >> 1);
+  const unsigned h0 = mv_hash32(c, d.k0, d.k1), h1 = mv_hash32(c + 1u, d.k0, d.k1);
+  v[0] = mv_keep(h0, 0, d.thr) ? v[0] * d.inv_keep : 0.f;
+  v[1] = mv_keep(h0, 1, d.thr) ? v[1] * d.inv_keep : 0.f;
+  v[2] = mv_keep(h1, 0, d.thr) ? v[2] * d.inv_keep : 0.f;
+  v[3] = mv_keep(h1, 1, d.thr) ? v[3] * d.inv_keep : 0.f;
   return v;
 }
 __device__ __forceinline__ float mv_drop1(float v, size_t idx, const DropCfg& d) {
-  const unsigned h = mv_hash32((unsigned)(idx >> 2), d.k0, d.k1);
-  return mv_keep(h, (int)(idx & 3), d.thr) ? v * d.inv_keep : 0.f;
+  const unsigned h = mv_hash32((unsigned)(idx >> 1), d.k0, d.k1);
+  return mv_keep(h, (int)(idx & 1), d.thr) ? v * d.inv_keep : 0.f;
 }
 static inline DropCfg mv_make_drop(float p, unsigned long long key) {
   DropCfg d;
-  int thr = (int)(p * 256.0f + 0.5f);
+  int thr = (int)(p * 65536.0f + 0.5f);
   if (p <= 0.f) thr = 0;
-  if (thr > 255) thr = 255;
+  if (thr > 65535) thr = 65535;
   d.thr = (unsigned)thr;
   d.k0 = (unsigned)(key & 0xffffffffULL);
   d.k1 = (unsigned)(key >> 32);
-  d.inv_keep = 1.0f / (1.0f - (float)thr / 256.0f);
+  d.inv_keep = 65536.0f / (65536.0f - (float)thr);
   return d;
 }
 

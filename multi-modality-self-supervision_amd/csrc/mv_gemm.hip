@@ -365,6 +365,11 @@ extern "C" int mv_gemm(int dtype, int ta, int tb, int M, int N, int K, const voi
   p.vec8_ok = mv_is16(c_dtype) && ((ldc & 7) == 0) && aligned_to(C, 16) && (!need_bias || aligned_to(bias, 16)) &&
               (!C3 || (((ldc3 & 7) == 0) && aligned_to(C3, 16))) &&
               ((epi != MV_EPI_BIAS_GELU && epi != MV_EPI_BIAS_GELU_D) || (((ldc2 & 7) == 0) && aligned_to(C2, 16))) && ((N & 3) == 0);
+  {   // the 16-byte-store epilogue addresses its outputs through buffer descriptors: sizes below 2 GiB, else the 8-byte path
+    const size_t bC = (size_t)M * ldc * 2, bC2 = C2 ? (size_t)M * ldc2 * 2 : 0, bC3 = C3 ? (size_t)M * ldc3 * 2 : 0;
+    if (bC >= 0x7fffffffULL || bC2 >= 0x7fffffffULL || bC3 >= 0x7fffffffULL) p.vec8_ok = 0;
+    p.bytesC = (unsigned)bC; p.bytesC2 = (unsigned)bC2; p.bytesC3 = (unsigned)bC3;
+  }
   const bool mfma = mv_is16(dtype) && (g_mv_impl == 0);
   const bool f16 = dtype == MV_F16;
   if (mfma && f16 && ta && !tb) return MV_E_DTYPE;    // f16 operands: y = x.W^T, dx = dy.W and dW = dy^T.x

@@ -15,6 +15,7 @@ struct GemmArgs {
   int kchunk, splitk;
   float* ws;
   unsigned bytesA, bytesB;
+  unsigned bytesC, bytesC2, bytesC3;   // 16-bit outputs of the 16-byte-store epilogue, as buffer sizes (that path needs them < 2 GiB)
   const float* alpha;   // nullable, MV_EPI_NONE with an f32 C only: C = *alpha * (A.B) (+ C when accumulating) -- 1 / loss scale of the
                         // f16-gradient path, applied where a weight gradient is written (mv_gemm's alpha_dev)
   float* csum;    // nullable (256x256 ring kernel, 16-bit C, N % 256 == 0): f32 [2 * ceil(M/256)][N] -- row 2*tm + half receives the sums over
@@ -137,18 +138,23 @@ __device__ __forceinline__ void epilogue4v(const GemmArgs& p, int m, int n, f32x
 // 8 consecutive columns of one row of a 16-bit output: ONE 16-byte store per output tensor instead of two 8-byte ones (the
 // epilogue of a 16-bit tile is bound by the number of store instructions it issues, not by their bytes).  Epilogues without
 // a residual operand only: bias, bias + GELU (+ derivative), plain.
-__device__ __forceinline__ void st8_16(void* base, size_t i, int dtype, const float (&o)[8]) {
+// 8 consecutive 16-bit outputs as ONE 16-byte buffer store.  (Write-through `sc1` stores -- outputs that do not stay in the XCD's L2,
+// where they evict the operand panels the XCD's other tiles re-read: the FFN-up kernel fetches its x panels ~4 times,
+// profiles/r03_ffn1_kernel_stats.txt -- were measured slower on every shape: profiles/r03_notes.txt.)
+__device__ __forceinline__ void st8_16(__amdgpu_buffer_rsrc_t rs, unsigned byte_off, int dtype, const float (&o)[8]) {
+  u32x4 bits;
   if (dtype == MV_BF16) {
     bf16x8 r;
 #pragma unroll
     for (int e = 0; e < 8; ++e) r[e] = (bf16_t)o[e];
-    *(bf16x8*)((bf16_t*)base + i) = r;
+    bits = __builtin_bit_cast(u32x4, r);
   } else {
     f16x8 r;
 #pragma unroll
     for (int e = 0; e < 8; ++e) r[e] = (f16_t)o[e];
-    *(f16x8*)((f16_t*)base + i) = r;
+    bits = __builtin_bit_cast(u32x4, r);
   }
+  __builtin_amdgcn_raw_buffer_store_b128(bits, rs, byte_off, 0, 0);
 }
 // 8 consecutive 16-bit elements of the elementwise operand, as raw bits (zeros past the last row); decoded at the point of use
 __device__ __forceinline__ u32x4 ld8_raw(const GemmArgs& p, int m, int n) {
@@ -166,9 +172,10 @@ __device__ __forceinline__ void dec8_16(u32x4 raw, int dtype, float (&r)[8]) {
     for (int e = 0; e < 8; ++e) r[e] = (float)v[e];
   }
 }
+struct OutRsrc { __amdgpu_buffer_rsrc_t c, c2, c3; };
 template <int E>
-__device__ __forceinline__ void epilogue8_16(const GemmArgs& p, int m, int n, f32x4 v0, f32x4 v1, f32x4 b0, f32x4 b1, float (&cs)[8], bool do_cs,
-                                             u32x4 rraw = (u32x4){0u, 0u, 0u, 0u}) {
+__device__ __forceinline__ void epilogue8_16(const GemmArgs& p, const OutRsrc& rs, int m, int n, f32x4 v0, f32x4 v1, f32x4 b0, f32x4 b1, float (&cs)[8],
+                                             bool do_cs, u32x4 rraw = (u32x4){0u, 0u, 0u, 0u}) {
   if (m >= p.M) return;
   float o[8] = {v0[0] + b0[0], v0[1] + b0[1], v0[2] + b0[2], v0[3] + b0[3], v1[0] + b1[0], v1[1] + b1[1], v1[2] + b1[2], v1[3] + b1[3]};
   if (E == MV_EPI_MUL || E == MV_EPI_RES) {
@@ -181,10 +188,10 @@ __device__ __forceinline__ void epilogue8_16(const GemmArgs& p, int m, int n, f3
     float dd[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { float g_, d_; gelu_erf_and_grad(o[e], g_, d_); o[e] = g_; dd[e] = d_; }
-    st8_16(p.C2, (size_t)m * p.ldc2 + n, p.c_dtype, dd);
+    st8_16(rs.c2, ((unsigned)m * (unsigned)p.ldc2 + (unsigned)n) * 2u, p.c_dtype, dd);
   }
-  st8_16(p.C, (size_t)m * p.ldc + n, p.c_dtype, o);
-  if (p.C3) st8_16(p.C3, (size_t)m * p.ldc3 + n, p.c3_dtype, o);
+  st8_16(rs.c, ((unsigned)m * (unsigned)p.ldc + (unsigned)n) * 2u, p.c_dtype, o);
+  if (p.C3) st8_16(rs.c3, ((unsigned)m * (unsigned)p.ldc3 + (unsigned)n) * 2u, p.c3_dtype, o);
   if (do_cs) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) cs[e] += o[e];
@@ -326,6 +333,10 @@ __device__ __forceinline__ bf16x8 g2_frag(const char* tile, int base, int l15, i
       /* the elementwise operand's rows are requested two 16-row groups ahead of their use (4 x 16 bytes per lane in flight) */ \
       u32x4 rq[2][2];                                                                                          \
       float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};                                                  \
+      OutRsrc ors;                                                                                             \
+      ors.c = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, p.bytesC, 0x00020000);                                 \
+      ors.c2 = __builtin_amdgcn_make_buffer_rsrc(p.C2, 0, p.bytesC2, 0x00020000);                              \
+      ors.c3 = __builtin_amdgcn_make_buffer_rsrc(p.C3, 0, p.bytesC3, 0x00020000);                              \
       const bool do_cs = p.csum != nullptr;                                                                    \
       if (WIDE_R) {                                                                                            \
         _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                          \
@@ -340,9 +351,9 @@ __device__ __forceinline__ bf16x8 g2_frag(const char* tile, int base, int l15, i
           if (WIDE_R) {                                                                                        \
             const u32x4 rcur = rq[i & 1][rr];                                                                  \
             if (i + 2 < 8) rq[i & 1][rr] = ld8_raw(p, m0 + wm + (i + 2) * 16 + row, ncol8);                    \
-            epilogue8_16<EE>(p, m0 + wm + i * 16 + row, ncol8, v0, v1, b0, b1, cs, do_cs, rcur);               \
+            epilogue8_16<EE>(p, ors, m0 + wm + i * 16 + row, ncol8, v0, v1, b0, b1, cs, do_cs, rcur);          \
           } else {                                                                                             \
-            epilogue8_16<EE>(p, m0 + wm + i * 16 + row, ncol8, v0, v1, b0, b1, cs, do_cs);                     \
+            epilogue8_16<EE>(p, ors, m0 + wm + i * 16 + row, ncol8, v0, v1, b0, b1, cs, do_cs);                \
           }                                                                                                    \
         }                                                                                                      \
       }                                                                                                        \
@@ -415,7 +426,9 @@ int mv_launch_ring_nt(const GemmArgs& p, bool f16, int variant, int tiles, int s
 int mv_launch_ring_nn(const GemmArgs& p, bool f16, int variant, int tiles, int splitk, int n_cu, hipStream_t stream);    // dx = dy.W
 int mv_launch_ring_tn(const GemmArgs& p, bool f16, int variant, int tiles, int splitk, int n_cu, hipStream_t stream);    // dW = dy^T.x
 int mv_launch_ring_tnn(const GemmArgs& p, bool f16, int variant, int tiles, int splitk, int n_cu, hipStream_t stream);   // A^T.B^T (bf16 only)
+int mv_launch_ring_tn4(const GemmArgs& p, bool f16, int tiles, int splitk, hipStream_t stream);                           // dW, 32-deep stages x4
 static inline int mv_launch_ring(const GemmArgs& p, int ta, int tb, bool f16, int variant, int tiles, int splitk, int n_cu, hipStream_t stream) {
+  if (variant == 4 && ta && tb) return mv_launch_ring_tn4(p, f16, tiles, splitk, stream);
   if (!ta && !tb) return mv_launch_ring_nt(p, f16, variant, tiles, splitk, n_cu, stream);
   if (!ta && tb) return mv_launch_ring_nn(p, f16, variant, tiles, splitk, n_cu, stream);
   if (ta && tb) return mv_launch_ring_tn(p, f16, variant, tiles, splitk, n_cu, stream);

@@ -758,15 +758,15 @@ extern "C" int mv_colsum_partials(const float* part, int P, int ld, int N, float
 // keep-mask of the counter-based dropout for linear indices 0..n-1 (test / inspection utility)
 __global__ void dropout_mask_kernel(uint8_t* __restrict__ out, size_t n, DropCfg d) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-    const unsigned h = mv_hash32((unsigned)(i >> 2), d.k0, d.k1);
-    out[i] = (d.thr == 0 || mv_keep(h, (int)(i & 3), d.thr)) ? 1 : 0;
+    const unsigned h = mv_hash32((unsigned)(i >> 1), d.k0, d.k1);
+    out[i] = (d.thr == 0 || mv_keep(h, (int)(i & 1), d.thr)) ? 1 : 0;
   }
 }
 extern "C" int mv_dropout_mask(float p_drop, unsigned long long drop_key, size_t n, uint8_t* keep, float* scale_out, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!keep || n == 0) return MV_E_ARG;
   const DropCfg d = mv_make_drop(p_drop, drop_key);
-  if (scale_out) *scale_out = d.inv_keep;     // host pointer: 1 / (1 - thr/256)
+  if (scale_out) *scale_out = d.inv_keep;     // host pointer: 1 / (1 - thr/65536)
   int blocks = (int)((n + 255) / 256);
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(dropout_mask_kernel, dim3(blocks), dim3(256), 0, stream, keep, n, d);

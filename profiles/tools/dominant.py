@@ -1,0 +1,95 @@
+"""The step's heaviest kernels ALONE, on seeded operands -- ONE definition shared by bench.py (HIP-event timing inside the bench
+line's `roofline`) and by the rocprofv3 passes (profiles/tools/r03_profile_all.sh), so that the line's numbers can be recomputed
+from the committed profile summaries: both time the same kernel on the same data.
+
+cases
+  dw     the weight-gradient GEMM (persistent 256x256 kernel, TN form, split-K + reduction): dW1 = dz^T . a, [3072 x 768] over 25,483
+         packed rows, f16 operands, f32 result un-scaled by 1/S -- the kernel symbol with the largest share of the step (46 launches)
+  ffn1   the FFN-up projection (256x256 ring kernel, NT form): [32768, 768] x [3072, 768]^T + bias, GELU and GELU' epilogue, two f16 outputs
+  attn   attention forward + backward (dQ, dK/dV) at B = 64, A = 12, L = 512, ragged packed rows, dropout 0.1 from keep-bits
+usage: python3 profiles/tools/dominant.py <case> [reps]"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+
+H, I = 768, 3072
+ROWS_PACKED, ROWS_PADDED = 25483, 32768
+
+
+def _rnd(shape, std, seed, dev, dtype=torch.float16):
+    g = torch.Generator(device=dev).manual_seed(seed)
+    return (torch.randn(shape, generator=g, device=dev) * std).to(dtype)
+
+
+def make_case(name, dev="cuda"):
+    """-> (launch callable, dict(kernel, flop, bytes, launches_per_call))"""
+    from medvill_amd import hip_ops as ops
+    from medvill_amd._lib import EPI_BIAS_GELU_D
+    if name == "dw":
+        M = ROWS_PACKED
+        dz, a = _rnd((M, I), 0.1, 11, dev), _rnd((M, H), 1.0, 12, dev)          # loss-scaled dz, LayerNorm output
+        g = torch.zeros((I, H), device=dev)
+        ws = torch.empty(16 * I * H, device=dev)
+        alpha = torch.tensor([1.0 / 32768.0], device=dev)
+        fn = lambda: ops.gemm(dz, a, g, ta=True, tb=True, M=I, N=H, K=M, lda=I, ldb=H, splitk=0, ws=ws, alpha=alpha)
+        return fn, dict(kernel=f"gemm_pring_kernel<TN, 256x256x64, f16 operands> dW1 = dz^T.a: {I}x{H} over {M} rows, 7 split-K slabs (+ splitk_reduce_kernel)",
+                        symbol="gemm_pring_kernel", flop=2.0 * M * I * H, bytes=2.0 * M * (I + H) + 4.0 * I * H)
+    if name == "ffn1":
+        M = ROWS_PADDED
+        x, w, b = _rnd((M, H), 1.0, 21, dev), _rnd((I, H), 0.02, 22, dev), _rnd((I,), 0.02, 23, dev, torch.float32)
+        o, d = torch.empty((M, I), device=dev, dtype=torch.float16), torch.empty((M, I), device=dev, dtype=torch.float16)
+        fn = lambda: ops.gemm(x, w, o, M=M, N=I, K=H, bias=b, epi=EPI_BIAS_GELU_D, c2=d)
+        return fn, dict(kernel=f"gemm_ring_kernel<NT, 256x256x64, f16 operands> {M}x{I}x{H} +bias+GELU (writes gelu(z) and gelu'(z), f16)",
+                        symbol="gemm_ring_kernel", flop=2.0 * M * I * H, bytes=2.0 * (M * H + I * H + 2 * M * I))
+    if name == "attn":
+        import medvill_amd as mv
+        B, A, dh, N, S = 64, 12, 64, 36, 473
+        L = N + S + 3
+        g = torch.Generator().manual_seed(1)
+        n_ids = torch.randint((S + 1) // 2 + 1, S + 2, (B,), generator=g)
+        desc = mv.data.MaskDesc.make("full", N, S, n_ids, dev)
+        bits = torch.zeros((B, L, (L + 31) // 32), dtype=torch.int32, device=dev)
+        ti = torch.zeros((B, (L + 63) // 64, (L + 63) // 64), dtype=torch.uint8, device=dev)
+        ops.mask_build(desc.desc, B, L, bits, ti)
+        cu, _, _ = ops.pack_plan(desc.desc, B, L)
+        M = int(cu[-1])
+        vl = (N + 2 + n_ids).double()
+        qkv, dctx = _rnd((M, 3 * H), 1.0, 31, dev), _rnd((M, H), 1.0, 32, dev)
+        ctx = torch.empty((M, H), device=dev, dtype=torch.float16)
+        lse, delta = torch.empty((B, A, L), device=dev), torch.empty((B, A, L), device=dev)
+        dqkv = torch.empty_like(qkv)
+        db = torch.empty(ops.dropbits_numel(B, L, A), dtype=torch.int32, device=dev)
+
+        def fn():
+            ops.attn_dropmask(0.1, 12345, B, L, A, db, cu=cu)
+            ops.attn_fwd(qkv, bits, ti, ctx, lse, B, L, A, dh, p_drop=0.1, cu=cu, total_rows=M, dropbits=db)
+            ops.attn_bwd(qkv, ctx, dctx, lse, bits, ti, dqkv, delta, B, L, A, dh, p_drop=0.1, cu=cu, total_rows=M, dropbits=db)
+        fwd = 4.0 * A * dh * float((vl * vl).sum())
+        return fn, dict(kernel=f"attn_dropmask + attn_fwd_mfma + attn_bwd_dq_mfma + attn_bwd_dkv_mfma, B={B} A={A} L={L} rows {M}, dropout 0.1",
+                        symbol="attn_", flop=3.5 * fwd, bytes=2.0 * M * (3 * H + H) * 3)
+    raise ValueError(name)
+
+
+def time_case(name, reps=20, warm=3, dev="cuda"):
+    """HIP events on the stream the kernel is launched on; ms per call of the case's launch callable."""
+    fn, meta = make_case(name, dev)
+    st = torch.cuda.current_stream()
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(st)
+    for _ in range(reps):
+        fn()
+    e1.record(st)
+    e1.synchronize()
+    meta["ms"] = e0.elapsed_time(e1) / reps
+    return meta
+
+
+if __name__ == "__main__":
+    case = sys.argv[1] if len(sys.argv) > 1 else "dw"
+    reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+    m = time_case(case, reps=reps)
+    print(f"{case}: {m['ms'] * 1e3:.1f} us per call (HIP events) = {m['flop'] / m['ms'] / 1e9:.0f} TFLOP/s algorithmic; {m['kernel']}")

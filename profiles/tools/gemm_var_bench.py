@@ -40,7 +40,7 @@ CASES = [
     ("TN dWqkv 2304x768", lambda: ops.gemm(x3, x, gWq, ta=True, tb=True, M=3 * H, N=H, K=M, lda=3 * H, ldb=H, splitk=0, ws=ws, alpha=alpha), 2.0 * M * 3 * H * H),
     ("TN dWo  768x768", lambda: ops.gemm(x, x, gWo, ta=True, tb=True, M=H, N=H, K=M, lda=H, ldb=H, splitk=0, ws=ws, alpha=alpha), 2.0 * M * H * H),
 ]
-VARS = [("auto", (0, 0)), ("ring256x256", (2, 14)), ("pring", (2, 24)), ("256x128 2/CU", (2, 2)), ("128x128", (1, 0))]
+VARS = [("auto", (0, 0)), ("ring256x256", (2, 14)), ("pring", (2, 24)), ("ring 32-deep x4", (2, 4)), ("256x128 2/CU", (2, 2)), ("128x128", (1, 0))]
 
 
 def t_of(fn, reps=10):

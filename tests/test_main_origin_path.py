@@ -129,3 +129,20 @@ def test_main_origin_loop_through_the_models_import_path(tmp_path):
     assert os.path.exists(os.path.join(args.output_path, "1", "pytorch_model.bin"))
     assert os.path.exists(os.path.join(args.output_path, "1", "config.json"))
     assert trainer.n_recognised > 0                     # the BAR matrices were recognised (descriptors, no per-step 4 MB upload)
+
+
+def test_launcher_resolves_models_to_the_build_even_from_a_checkout_with_its_own_models(tmp_path):
+    """run_main_origin.py: executed from a directory that has its OWN `models` package and a main_origin.py whose first statement is
+    the reference's import line, the import must land on this repo's `models/` (a script's directory otherwise shadows PYTHONPATH)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    (tmp_path / "models").mkdir()
+    (tmp_path / "models" / "__init__.py").write_text("")
+    (tmp_path / "models" / "train_origin.py").write_text("class CXRBERT_Trainer:\n    ORIGIN = 'the checkout'\n")
+    (tmp_path / "main_origin.py").write_text(
+        "from models.train_origin import CXRBERT_Trainer  # CXR-BERT\n"
+        "import sys\nprint('RESOLVED', CXRBERT_Trainer.__module__, sys.argv[1:])\n")
+    r = subprocess.run([sys.executable, os.path.join(root, "run_main_origin.py"), "--epochs", "1"], cwd=str(tmp_path), capture_output=True, text=True,
+                       env={**os.environ, "CUDA_VISIBLE_DEVICES": "", "HIP_VISIBLE_DEVICES": ""})
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "RESOLVED medvill_amd.trainer ['--epochs', '1']" in r.stdout, r.stdout

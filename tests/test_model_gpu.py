@@ -270,7 +270,7 @@ def test_dropout_training_step_against_oracle_with_the_same_masks(golden_dir):
                 full[sel] = (keep.view(-1, H)[:sel.numel()].float() * sc)
             masks[name] = full.view(B, Lq, H).cpu()
         fracs.append(float(keep.float().mean()))
-        assert sc == pytest.approx(1.0 / (1.0 - 26.0 / 256.0))          # the hidden-state sites: 8-bit thresholds
+        assert sc == pytest.approx(65536.0 / (65536.0 - 6554.0))        # P(drop) = 6554 / 65536 at every site
     assert all(abs(f - 0.9) < 0.012 for f in fracs), fracs
     assert len({float(m.sum()) for m in masks.values()}) == len(masks)        # every site / layer draws its own mask
     Po = {k: v.clone().requires_grad_(True) for k, v in P.items()}
