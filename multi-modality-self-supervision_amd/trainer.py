@@ -218,59 +218,65 @@ class CXRBERT_Trainer:
         n2 = N + 2
         if S < 1 or input_ids.shape[1] != S + 1:
             return None, None
-        ids = input_ids.cpu()
+        # numpy views of the host tensors: the probes touch a few KB of the 134 MB matrix, and torch's CPU operators would hand each of
+        # these tiny jobs to its OpenMP pool (measured on the 16-core share of a GPU box: 3 ms .. 90 ms per batch, and the kernel
+        # launches of the step that follows slowed down 3-5x by the spinning workers)
+        import numpy as np
+        mn = m.numpy()
+        ids = input_ids.cpu().numpy()
         # valid length from the LAST non-zero id (the text [SEP] is never 0): random_word (dataset_origin.py:183-209) may put
         # id 0 at a labelled in-text position, and a tokenizer may use id 0 for a real token
         nz = ids != 0
         T = ids.shape[1]
-        last = torch.where(nz.any(1), T - 1 - nz.flip(1).to(torch.int64).argmax(1), torch.full((B,), -1, dtype=torch.int64))
+        last = np.where(nz.any(1), T - 1 - np.argmax(nz[:, ::-1], axis=1), -1).astype(np.int64)
         n_ids = last + 1
         vl = n2 + n_ids
+        j = np.arange(L).reshape(1, L)
         if txt_labels is not None and torch.is_tensor(txt_labels):
-            lab = txt_labels.cpu() != -100
-            if lab.shape == (B, L) and bool((lab & (torch.arange(L).view(1, L) >= vl.view(B, 1))).any()):
+            lab = txt_labels.cpu().numpy() != -100
+            if lab.shape == (B, L) and bool((lab & (j >= vl.reshape(B, 1))).any()):
                 return None, None          # a label after the derived valid length: the packed rows would drop it
-        j = torch.arange(L).view(1, L)
-        full_row = (j < vl.view(B, 1)).to(torch.int64)
+        full_row = (j < vl.reshape(B, 1)).astype(np.int64)
         if m.dim() == 2:
-            if not torch.equal(m, full_row):
+            if not np.array_equal(mn, full_row):
                 return None, None
-            fam_id = torch.full((B,), D.FAMILY_ID["1d"], dtype=torch.int32)
+            fam_id = np.full((B,), D.FAMILY_ID["1d"], dtype=np.int32)
         else:
-            r0, rl, cl = m[:, 0, :], m[:, L - 1, :], m[:, :, L - 1]
-            img_row = (j < n2).to(torch.int64).expand(B, L)
-            txt_row = (j >= n2).to(torch.int64).expand(B, L)
-            bar_col = ((j < n2) | (j == L - 1)).to(torch.int64).expand(B, L)
-            ones = torch.ones((B, L), dtype=torch.int64)
-            eq = lambda a, b_: (a == b_).all(1)
+            r0, rl, cl = mn[:, 0, :], mn[:, L - 1, :], mn[:, :, L - 1]
+            img_row = np.broadcast_to((j < n2).astype(np.int64), (B, L))
+            txt_row = np.broadcast_to((j >= n2).astype(np.int64), (B, L))
+            bar_col = np.broadcast_to(((j < n2) | (j == L - 1)).astype(np.int64), (B, L))
+            eq = lambda a_, b_: (a_ == b_).all(1)
+            one = lambda a_: (a_ == 1).all(1)
             is_full = eq(r0, full_row) & eq(rl, full_row)
-            is_s2s = eq(r0, img_row) & eq(rl, ones)
-            is_bar = eq(r0, ones) & eq(rl, ones) & eq(cl, bar_col)
+            is_s2s = eq(r0, img_row) & one(rl)
+            is_bar = one(r0) & one(rl) & eq(cl, bar_col)
             is_non = eq(r0, img_row) & eq(rl, txt_row)
-            fam_id = torch.full((B,), -1, dtype=torch.int32)
+            fam_id = np.full((B,), -1, dtype=np.int32)
             # same precedence as a per-sample if / elif chain over (full, s2s, bar, noncross)
             for cond, name in ((is_non, "noncross"), (is_bar, "bar"), (is_s2s, "s2s"), (is_full, "full")):
-                fam_id = torch.where(cond, torch.full_like(fam_id, D.FAMILY_ID[name]), fam_id)
+                fam_id = np.where(cond, np.int32(D.FAMILY_ID[name]), fam_id).astype(np.int32)
             if bool((fam_id < 0).any()):
                 return None, None
-        d = torch.empty((B, 3), dtype=torch.int32)
-        d[:, 0], d[:, 1], d[:, 2] = fam_id, n2, vl.to(torch.int32)
+        dn = np.empty((B, 3), dtype=np.int32)
+        dn[:, 0], dn[:, 1], dn[:, 2] = fam_id, n2, vl.astype(np.int32)
+        d = torch.from_numpy(dn)
         desc = D.MaskDesc(d, L, host=d)          # uploaded with the batch's other integer fields (_upload_small)
         if self.verify_masks == "off":
             return desc, None
         if not self._full_check:
             # host-side spot check of `verify_probes` random rows per sample against the closed forms
             if m.dim() == 3 and self.verify_probes > 0:
-                g = torch.Generator().manual_seed(self._mask_batches)
-                rows = torch.randint(0, L, (B, self.verify_probes), generator=g)
-                got = m[torch.arange(B).view(B, 1), rows]                       # [B, P, L]
-                i_ = rows.view(B, -1, 1)
-                jj = torch.arange(L).view(1, 1, L)
-                f = fam_id.view(B, 1, 1)
-                want = torch.where(f == 1, (jj < n2) | ((i_ >= n2) & (jj >= n2) & (jj <= i_)),
-                       torch.where(f == 2, (i_ < n2) | (jj < n2) | (jj <= i_),
-                       torch.where(f == 3, (i_ < n2) == (jj < n2), jj < vl.view(B, 1, 1))))
-                if not torch.equal(got, want.to(torch.int64)):
+                rng = np.random.default_rng(self._mask_batches)
+                rows = rng.integers(0, L, size=(B, self.verify_probes))
+                got = mn[np.arange(B).reshape(B, 1), rows]                      # [B, P, L]
+                i_ = rows.reshape(B, -1, 1)
+                jj = np.arange(L).reshape(1, 1, L)
+                f = fam_id.reshape(B, 1, 1)
+                want = np.where(f == 1, (jj < n2) | ((i_ >= n2) & (jj >= n2) & (jj <= i_)),
+                       np.where(f == 2, (i_ < n2) | (jj < n2) | (jj <= i_),
+                       np.where(f == 3, (i_ < n2) == (jj < n2), jj < vl.reshape(B, 1, 1))))
+                if not np.array_equal(got != 0, want):
                     return None, None
             return desc, None
         state = {}
@@ -295,23 +301,26 @@ class CXRBERT_Trainer:
             return state["ok"]
         return desc, verify
 
-    def _upload(self, t):
-        """Host tensor -> device through a reused pinned staging buffer (asynchronous copy on the current stream)."""
-        n = t.numel()
-        key = (t.dtype, t.dim() > 1)
+    def _stage(self, key, n, dtype):
+        """One of two reused pinned staging buffers of >= n elements (the copy that last used it has finished)."""
         slot = self._pinned.get(key)
         if slot is None or slot[0][0].numel() < n:
             cap = n + n // 4
-            slot = self._pinned[key] = [[torch.empty(cap, dtype=t.dtype).pin_memory() for _ in range(2)], 0, [None, None]]
+            slot = self._pinned[key] = [[torch.empty(cap, dtype=dtype).pin_memory() for _ in range(2)], 0, [None, None]]
         bufs, i, evs = slot
         if evs[i] is not None:
-            evs[i].synchronize()         # the copy that last used this staging buffer has finished
-        stage = bufs[i][:n].view(t.shape)
-        stage.copy_(t)
-        d = stage.to(self.device, non_blocking=True)
-        evs[i] = torch.cuda.Event()
-        evs[i].record(torch.cuda.current_stream())
+            evs[i].synchronize()
         slot[1] = i ^ 1
+        return bufs[i][:n], slot, i
+
+    def _upload(self, t):
+        """Host tensor -> device through a reused pinned staging buffer (asynchronous copy on the current stream)."""
+        import numpy as np
+        stage, slot, i = self._stage((t.dtype, "one"), t.numel(), t.dtype)
+        np.copyto(stage.numpy(), t.contiguous().view(-1).numpy())          # plain memcpy, no OpenMP pool
+        d = stage.view(t.shape).to(self.device, non_blocking=True)
+        slot[2][i] = torch.cuda.Event()
+        slot[2][i].record(torch.cuda.current_stream())
         return d
 
     def _to_batch(self, data):
@@ -348,19 +357,27 @@ class CXRBERT_Trainer:
                  if torch.is_tensor(batch.get(k)) and not batch[k].is_cuda and batch[k].dtype == torch.int64]
         if len(names) < 7:
             return
-        parts = {k: batch[k].contiguous() for k in names}
-        rows, ids = D.label_index(batch["txt_labels"])              # host-side nonzero: R is needed on the host anyway
-        parts["label_rows"], parts["label_ids"] = rows.to(torch.int64), ids.to(torch.int64)
+        import numpy as np
+        parts = {k: batch[k].contiguous().numpy() for k in names}
+        flat_lab = parts["txt_labels"].reshape(-1)
+        rows = np.flatnonzero(flat_lab != -100)                     # the labelled-row index: R is needed on the host anyway
+        parts["label_rows"], parts["label_ids"] = rows.astype(np.int64), flat_lab[rows]
         desc = batch.get("attn_desc")
         if desc is not None and desc._host is not None:
-            parts["_desc"] = desc._host.to(torch.int64).contiguous()
-        flat = torch.cat([v.reshape(-1) for v in parts.values()])
-        dflat = self._upload(flat)
+            parts["_desc"] = desc._host.numpy().astype(np.int64)
+        n = sum(v.size for v in parts.values())
+        stage, slot, i = self._stage((torch.int64, "ints"), n, torch.int64)
+        sn, off = stage.numpy(), 0
+        for v in parts.values():
+            sn[off:off + v.size] = v.reshape(-1)
+            off += v.size
+        dflat = stage.to(self.device, non_blocking=True)
+        slot[2][i] = torch.cuda.Event()
+        slot[2][i].record(torch.cuda.current_stream())
         off = 0
         for k, v in parts.items():
-            n = v.numel()
-            t = dflat[off:off + n].view(v.shape)
-            off += n
+            t = dflat[off:off + v.size].view(v.shape)
+            off += v.size
             if k in ("label_rows", "label_ids"):
                 batch[k] = t.to(torch.int32)
             elif k == "_desc":

@@ -54,5 +54,18 @@ with contextlib.redirect_stdout(sys.stderr):
     tr._run_epoch(host * (n // 2), 0, True)
     torch.cuda.synchronize()
     tot = (time.perf_counter() - t0) / n * 1e3
+# the same process, device-resident batches straight into the step (what bench.py's headline times)
+res = [mv.data.synthetic_batch(cfg.vocab_size, B, N, S, fam, seed=4321 + i, device=dev) for i in range(2)]
+for i in range(4):
+    o_step(res[i % 2])
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+th = 0.0
+for i in range(n):
+    t1 = time.perf_counter()
+    o_step(res[i % 2])
+    th += time.perf_counter() - t1
+torch.cuda.synchronize()
+print(f"resident batches, same process: {(time.perf_counter() - t0) / n * 1e3:.1f} ms per step, host wall in the step call {th / n * 1e3:.1f} ms")
 print(f"{fam}: {tot:.1f} ms per step over host batches; host wall per step: batch preparation {acc['to_batch'] / n * 1e3:.1f} ms "
       f"(of it mask recognition {acc['recognise'] / n * 1e3:.1f}), step call (launches) {acc['step'] / n * 1e3:.1f} ms")
