@@ -252,19 +252,7 @@ __device__ __forceinline__ void tile_store(const u32x4 (&reg)[2], char* tile, in
 // write and, having no alias information for `ds_read_b64_tr_b16`, puts `s_waitcnt vmcnt(0)` in front of the first transposed
 // fragment read of every tile -- the whole ring drained once per tile, so only the transfer issued last was ever ahead.  The
 // kernels below order the ring themselves (counted vmcnt + s_barrier before a stage is read, see att_wait_stage).
-typedef int dma_rsrc_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ dma_rsrc_t dma_rsrc(const void* p, unsigned bytes) {      // raw buffer, stride 0, `bytes` records
-  const unsigned long long v = (unsigned long long)(uintptr_t)p;
-  return (dma_rsrc_t){(int)(unsigned)v, (int)((unsigned)(v >> 32) & 0xffffu), (int)bytes, 0x00020000};
-}
-// (M0 is compiler-reserved: it is written inside the SAME statement that reads it, as the CDNA guide prescribes; an "m0" clobber would
-// only draw "clobber list contains reserved registers" from hipcc -- ROCm 7.2 -- on every instantiation)
-__device__ __forceinline__ void lds_dma16(dma_rsrc_t rs, MV_LDS void* dst, unsigned voff) {   // dst: wave-uniform, lane i lands at +16 i
-  asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"((unsigned)(uintptr_t)dst), "v"(voff), "s"(rs) : "memory");
-}
-__device__ __forceinline__ void lds_dma4(dma_rsrc_t rs, MV_LDS void* dst, unsigned voff) {
-  asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dword %1, %2, 0 offen lds" ::"s"((unsigned)(uintptr_t)dst), "v"(voff), "s"(rs) : "memory");
-}
+// (dma_rsrc_t, dma_rsrc, lds_dma16, lds_dma4: mv_common.h)
 template <int NW>
 __device__ __forceinline__ void tile_dma(dma_rsrc_t rs, unsigned bytes, size_t rowbase, int row0, int nrows, int ld,
                                          int col0, char* tile, int wid, int lane) {

@@ -177,6 +177,24 @@ static inline DropCfg mv_make_drop(float p, unsigned long long key) {
   return d;
 }
 
+// ---- LDS-DMA (global -> LDS without registers) issued from inline assembly.  Through the builtin the compiler tracks the transfer as
+// a pending LDS write and, having no alias information for `ds_read_b64_tr_b16`, puts `s_waitcnt vmcnt(0)` in front of the first
+// transposed fragment read that follows -- which drains the transfer just issued for the NEXT stage before the current stage's MFMAs
+// start.  Kernels that use these order their rings themselves (counted `s_waitcnt vmcnt(N)` + `s_barrier` before a stage is read).
+typedef int dma_rsrc_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ dma_rsrc_t dma_rsrc(const void* p, unsigned bytes) {      // raw buffer, stride 0, `bytes` records
+  const unsigned long long v = (unsigned long long)(uintptr_t)p;
+  return (dma_rsrc_t){(int)(unsigned)v, (int)((unsigned)(v >> 32) & 0xffffu), (int)bytes, 0x00020000};
+}
+// (M0 is compiler-reserved: it is written inside the SAME statement that reads it, as the CDNA guide prescribes; an "m0" clobber would
+// only draw "clobber list contains reserved registers" from hipcc -- ROCm 7.2 -- on every instantiation)
+__device__ __forceinline__ void lds_dma16(dma_rsrc_t rs, MV_LDS void* dst, unsigned voff) {   // dst: wave-uniform, lane i lands at +16 i
+  asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"((unsigned)(uintptr_t)dst), "v"(voff), "s"(rs) : "memory");
+}
+__device__ __forceinline__ void lds_dma4(dma_rsrc_t rs, MV_LDS void* dst, unsigned voff) {
+  asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dword %1, %2, 0 offen lds" ::"s"((unsigned)(uintptr_t)dst), "v"(voff), "s"(rs) : "memory");
+}
+
 __device__ __forceinline__ float fexp2(float x) { return __builtin_amdgcn_exp2f(x); }   // bare v_exp_f32
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -262,7 +262,7 @@ __device__ __forceinline__ int t2_off(int kr, int ch) { return kr * 512 + ((ch ^
 
 // PITCH512: contraction-major image with 512-B rows (tile width 192/256) or 256-B rows (tile width 128)
 template <bool TR, bool PITCH512, int NPIECE, int NW, int KS>
-__device__ __forceinline__ void g2_issue(__amdgpu_buffer_rsrc_t rs, unsigned bytes, int ld, int row0, int rows_total,
+__device__ __forceinline__ void g2_issue(dma_rsrc_t rs, unsigned bytes, int ld, int row0, int rows_total,
                                          int tile_rows, int k0, int kend, char* region, int wid, int lane, int dbg = 0) {
 #pragma unroll
   for (int q = 0; q < NPIECE / NW; ++q) {
@@ -291,7 +291,7 @@ __device__ __forceinline__ void g2_issue(__amdgpu_buffer_rsrc_t rs, unsigned byt
       ok = (c * 8 < tile_rows) && (gk < kend) && (gc < rows_total);
       off = ((unsigned)gk * (unsigned)ld + (unsigned)gc) * 2u;
     }
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (MV_LDS void*)(region + pc * 1024), 16, ok ? off : bytes, 0, 0, 0);
+    lds_dma16(rs, (MV_LDS void*)(region + pc * 1024), ok ? off : bytes);     // asm: see mv_common.h (no compiler-inserted ring drain)
   }
 }
 

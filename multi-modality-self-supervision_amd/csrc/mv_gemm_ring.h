@@ -3,6 +3,31 @@
 #pragma once
 #include "mv_gemm_common.h"
 
+// One ring stage's MFMAs for the layouts with a contraction-major operand (fragments through `ds_read_b64_tr_b16`).  hipcc reads each
+// A fragment right before the MFMAs that consume it (register pressure), so every group of NJ MFMAs starts with a full LDS round
+// trip that the second wave of the SIMD only partly covers (the loop alone ran at 57-64 % of the MFMA rate, profiles/r03_notes.txt).
+// Here the next A fragment is requested BEFORE the current group's MFMAs (4 more registers); the scheduling fences pin that order.
+template <bool TA, bool TB, bool BP512, int NJ, int KS, bool F16>
+__device__ __forceinline__ void g2_stage_mma_tr(const char* tA, const char* tB, int wm, int wn, int l15, int lq, f32x4 (&acc)[8][NJ]) {
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    bf16x8 fb[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) fb[j] = g2_frag<TB, BP512, KS>(tB, wn + j * 16, l15, lq, ks);
+    bf16x8 cur = g2_frag<TA, true, KS>(tA, wm, l15, lq, ks);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      bf16x8 nxt = cur;
+      if (i + 1 < 8) nxt = g2_frag<TA, true, KS>(tA, wm + (i + 1) * 16, l15, lq, ks);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) acc[i][j] = mma16<F16>(fb[j], cur, acc[i][j]);
+      __builtin_amdgcn_sched_barrier(0);
+      cur = nxt;
+    }
+  }
+}
+
 template <bool TA, bool TB, int NJ, int WN, int NSTAGE, int KS, bool F16 = false>
 __global__ __launch_bounds__(128 * WN, 2) void gemm_ring_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -42,8 +67,8 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_ring_kernel(GemmArgs p) {
   const int kend = min(p.K, kbeg + p.kchunk);
   const int nst = (kend - kbeg + BKS - 1) / BKS;
 
-  __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, p.bytesA, 0x00020000);
-  __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, p.bytesB, 0x00020000);
+  const dma_rsrc_t rsA = dma_rsrc(p.A, p.bytesA);
+  const dma_rsrc_t rsB = dma_rsrc(p.B, p.bytesB);
 
   f32x4 acc[8][NJ];
 #pragma unroll
@@ -109,7 +134,7 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_ring_kernel(GemmArgs p) {
         __builtin_amdgcn_sched_barrier(0);
         G2_MMA(fa0, fb0);
         G2_MMA(fa1, fb1);
-      } else {
+      } else {       // (g2_stage_mma_tr spills in this kernel -- 3-4x slower, measured; the persistent form below takes it)
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
           bf16x8 fa[8], fb[NJ];
@@ -195,8 +220,8 @@ __global__ __launch_bounds__(128 * WN, 1) void gemm_pring_kernel(GemmArgs p, int
     kend = min(p.K, kbeg + p.kchunk);
   };
 
-  __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, p.bytesA, 0x00020000);
-  __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, p.bytesB, 0x00020000);
+  const dma_rsrc_t rsA = dma_rsrc(p.A, p.bytesA);
+  const dma_rsrc_t rsB = dma_rsrc(p.B, p.bytesB);
 
   // issue cursor: runs NSTAGE-1 stages ahead of the compute cursor, across unit boundaries
   int iu = blockIdx.x, is = 0, im0 = 0, in0 = 0, ikbeg = 0, ikend = 0, isplit = 0, inst = 0;
@@ -245,17 +270,21 @@ __global__ __launch_bounds__(128 * WN, 1) void gemm_pring_kernel(GemmArgs p, int
       issue_one();                                // refills the slot everyone finished reading (or used as scratch)
       const char* tA = smem + (cfs % NSTAGE) * STAGE;
       const char* tB = tA + A_BYTES;
+      if constexpr (TA && TB) {      // (the NN / TNN forms spill with the extra fragment: measured 2.3x slower)
+        g2_stage_mma_tr<TA, TB, BP512, NJ, KS, F16>(tA, tB, wm, wn, l15, lq, acc);
+      } else {
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        bf16x8 fa[8], fb[NJ];
+        for (int ks = 0; ks < KS; ++ks) {
+          bf16x8 fa[8], fb[NJ];
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) fb[j] = g2_frag<TB, BP512, KS>(tB, wn + j * 16, l15, lq, ks);
+          for (int j = 0; j < NJ; ++j) fb[j] = g2_frag<TB, BP512, KS>(tB, wn + j * 16, l15, lq, ks);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) fa[i] = g2_frag<TA, true, KS>(tA, wm + i * 16, l15, lq, ks);
+          for (int i = 0; i < 8; ++i) fa[i] = g2_frag<TA, true, KS>(tA, wm + i * 16, l15, lq, ks);
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+          for (int i = 0; i < 8; ++i)
 #pragma unroll
-          for (int j = 0; j < NJ; ++j) acc[i][j] = mma16<F16>(fb[j], fa[i], acc[i][j]);
+            for (int j = 0; j < NJ; ++j) acc[i][j] = mma16<F16>(fb[j], fa[i], acc[i][j]);
+        }
       }
       ++cfs;
     }
@@ -279,7 +308,8 @@ __global__ __launch_bounds__(128 * WN, 1) void gemm_pring_kernel(GemmArgs p, int
     else { MV_EPI_SWITCH(p.epi, G2_EPI_BODY) }
     // whole tile inside the matrix and vector stores: every one of the 32 row-group stores above was issued
     const bool full = (m0 + G2_BM <= p.M) && (n0 + BN <= p.N) && ((p.N & 3) == 0) && (p.splitk > 1 || p.vec_ok);
-    epi_ops = full ? EPI_OPS : 0;
+    // (16-bit outputs leave in 16-byte pieces, 16 stores per output: below the bound, so the next unit's first wait drains them)
+    epi_ops = (full && (p.splitk > 1 || p.c_dtype == MV_F32)) ? EPI_OPS : 0;
   }
 }
 

@@ -27,6 +27,7 @@ ws = torch.empty(32 * I * H, device=dev)
 alpha = torch.tensor([1.0 / 32768], device=dev)
 cpart = torch.empty(2 * ((M + 255) // 256), I, device=dev)
 gb1 = torch.zeros(I, device=dev)
+oH, Wo = torch.empty(M, H, device=dev, dtype=f16), rnd(H, H, sc=0.02)
 CASES = [
     ("NT ffn1 +bias+gelu+gelu'", lambda: ops.gemm(x, W1, oI, M=M, N=I, K=H, bias=b1, epi=EPI_BIAS_GELU_D, c2=oI2), 2.0 * M * I * H),
     ("NT ffn1 +bias", lambda: ops.gemm(x, W1, oI, M=M, N=I, K=H, bias=b1, epi=EPI_BIAS), 2.0 * M * I * H),
@@ -38,6 +39,9 @@ CASES = [
     ("TN dW1  3072x768", lambda: ops.gemm(xi, x, gW1, ta=True, tb=True, M=I, N=H, K=M, lda=I, ldb=H, splitk=0, ws=ws, alpha=alpha), 2.0 * M * I * H),
     ("TN dW2  768x3072", lambda: ops.gemm(x, xi, gW2, ta=True, tb=True, M=H, N=I, K=M, lda=H, ldb=I, splitk=0, ws=ws, alpha=alpha), 2.0 * M * I * H),
     ("TN dWqkv 2304x768", lambda: ops.gemm(x3, x, gWq, ta=True, tb=True, M=3 * H, N=H, K=M, lda=3 * H, ldb=H, splitk=0, ws=ws, alpha=alpha), 2.0 * M * 3 * H * H),
+    ("NN dx(qkv) K=2304", lambda: ops.gemm(x3, Wq, oH, tb=True, M=M, N=H, K=3 * H, ldb=H), 2.0 * M * 3 * H * H),
+    ("NN dx(ffn1) K=3072", lambda: ops.gemm(xi, W1, oH, tb=True, M=M, N=H, K=I, ldb=H), 2.0 * M * I * H),
+    ("NN dx(Wo) K=768", lambda: ops.gemm(x, Wo, oH, tb=True, M=M, N=H, K=H, ldb=H), 2.0 * M * H * H),
     ("TN dWo  768x768", lambda: ops.gemm(x, x, gWo, ta=True, tb=True, M=H, N=H, K=M, lda=H, ldb=H, splitk=0, ws=ws, alpha=alpha), 2.0 * M * H * H),
 ]
 VARS = [("auto", (0, 0)), ("ring256x256", (2, 14)), ("pring", (2, 24)), ("ring 32-deep x4", (2, 4)), ("256x128 2/CU", (2, 2)), ("128x128", (1, 0))]
