@@ -81,6 +81,8 @@ const char* mv_build_info(void);
 /* test hook for mv_gemm's MFMA tile choice: force = 0 auto / 1 the 128x128x64 kernel / 2 the 256-row
  * LDS-DMA kernel; nj = 0 auto / 3 (256x192 tile) / 4 (256x256 tile). */
 void mv_set_gemm_variant(int force, int nj);
+/* test / experiment hook for mv_layernorm_bwd: low byte 0 = prefetching kernel, 8 waves per block (default) / 1 = one row at a time, 4 waves / 2, 3 = prefetching, 4 / 16 waves; bits 8.. = grid cap (0 = default) */
+void mv_set_rowops_variant(int v);
 /* bits per uniform of the attention-dropout mask generator (mv_attn_dropmask): 16 (default), 12 or 8.  P(drop) = round(p * 2^n) / 2^n;
  * the generator's time is proportional to n.  Process-wide: set before the masks of a forward are generated. */
 void mv_set_attn_planes(int planes);

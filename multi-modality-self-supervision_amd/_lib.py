@@ -29,6 +29,7 @@ PROTOTYPES = {
     "mv_build_info": [],
     "mv_set_gemm_variant": [i32, i32],
     "mv_set_attn_planes": [i32],
+    "mv_set_rowops_variant": [i32],
     "mv_get_attn_planes": [],
     "mv_gemm": [i32, i32, i32, i32, i32, i32, vp, i32, vp, i32, vp, i32, i32, vp, i32, vp, i32, i32, vp, i32, vp, i32, i32,
                 i32, vp, sz, i32, f32, u64, vp, vp, vp],
@@ -68,7 +69,7 @@ PROTOTYPES = {
     "mv_count_nonfinite": [vp, sz, vp, vp],
     "mv_scaler_update": [vp, i32, f32, f32, f32, f32, vp],
 }
-_RESTYPE = {"mv_set_impl": None, "mv_set_gemm_variant": None, "mv_set_attn_planes": None, "mv_build_info": C.c_char_p}
+_RESTYPE = {"mv_set_impl": None, "mv_set_gemm_variant": None, "mv_set_attn_planes": None, "mv_set_rowops_variant": None, "mv_build_info": C.c_char_p}
 
 _lib = None
 

@@ -138,6 +138,125 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TD* __restrict__ dy, 
   }
 }
 
+// The same with the NEXT row's dy / x requested before the current row's arithmetic (raw 16-bit registers, 4 NC more): a wave keeps two
+// rows of loads in flight instead of one load -> reduce -> store round trip at a time (measured: profiles/r03_notes.txt).
+template <typename T> struct raw4;
+template <> struct raw4<float> { typedef f32x4 type; };
+template <> struct raw4<bf16_t> { typedef bf16x4 type; };
+template <> struct raw4<f16_t> { typedef f16x4 type; };
+template <typename T> __device__ __forceinline__ f32x4 cvt_raw4(typename raw4<T>::type r) {
+  return (f32x4){(float)r[0], (float)r[1], (float)r[2], (float)r[3]};
+}
+template <typename TX, typename TD, int NC, int WPB>
+__global__ __launch_bounds__(64 * WPB) void ln_bwd_pf_kernel(const TD* __restrict__ dy, const TX* __restrict__ x,
+                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                        const float* __restrict__ g, TD* __restrict__ dx, float* __restrict__ dgamma,
+                                                        float* __restrict__ dbeta, float* __restrict__ colsum, int M, int H,
+                                                        TD* __restrict__ dx_drop, DropCfg drop, const float* __restrict__ gscale) {
+  typedef typename raw4<TD>::type RD;
+  typedef typename raw4<TX>::type RX;
+  __shared__ float red[3][WPB][260];
+  const int lane = threadIdx.x & 63, wl = threadIdx.x >> 6;
+  f32x4 ag[NC], ab[NC], ac[NC], gg[NC];
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    ag[i] = (f32x4){0, 0, 0, 0}; ab[i] = ag[i]; ac[i] = ag[i];
+    const int c = lane * 4 + 256 * i;
+    gg[i] = c < H ? *(const f32x4*)(g + c) : ag[i];
+  }
+  const int stride = gridDim.x * WPB;
+  int row = blockIdx.x * WPB + wl;
+  RD rd[NC]; RX rx[NC];
+  float mu = 0.f, rs = 0.f;
+  if (row < M) {
+#pragma unroll
+    for (int n = 0; n < NC; ++n) {
+      const int c = lane * 4 + 256 * n;
+      if (c < H) { rd[n] = *(const RD*)(dy + (size_t)row * H + c); rx[n] = *(const RX*)(x + (size_t)row * H + c); }
+    }
+    mu = mean[row]; rs = rstd[row];
+  }
+  for (; row < M; row += stride) {
+    const int nrow = row + stride;
+    RD nd[NC]; RX nx[NC];
+    float nmu = 0.f, nrs = 0.f;
+    if (nrow < M) {
+#pragma unroll
+      for (int n = 0; n < NC; ++n) {
+        const int c = lane * 4 + 256 * n;
+        if (c < H) { nd[n] = *(const RD*)(dy + (size_t)nrow * H + c); nx[n] = *(const RX*)(x + (size_t)nrow * H + c); }
+      }
+      nmu = mean[nrow]; nrs = rstd[nrow];
+    }
+    f32x4 xh[NC], gd[NC];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int n = 0; n < NC; ++n) {
+      const int c = lane * 4 + 256 * n;
+      xh[n] = (f32x4){0, 0, 0, 0}; gd[n] = xh[n];
+      if (c < H) {
+        const f32x4 d = cvt_raw4<TD>(rd[n]), xv = cvt_raw4<TX>(rx[n]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float h_ = (xv[e] - mu) * rs;
+          const float gde = gg[n][e] * d[e];
+          xh[n][e] = h_; gd[n][e] = gde;
+          s1 += gde; s2 += gde * h_;
+          ag[n][e] += d[e] * h_;
+          ab[n][e] += d[e];
+        }
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+    s1 /= (float)H; s2 /= (float)H;
+    TD* dxr = dx + (size_t)row * H;
+#pragma unroll
+    for (int n = 0; n < NC; ++n) {
+      const int c = lane * 4 + 256 * n;
+      if (c < H) {
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = rs * (gd[n][e] - s1 - xh[n][e] * s2);
+        st4<TD>(dxr + c, o);
+        if (dx_drop) {
+          o = mv_drop4(o, (size_t)row * H + c, drop);
+          st4<TD>(dx_drop + (size_t)row * H + c, o);
+        }
+        ac[n] += o;
+      }
+    }
+#pragma unroll
+    for (int n = 0; n < NC; ++n) { rd[n] = nd[n]; rx[n] = nx[n]; }
+    mu = nmu; rs = nrs;
+  }
+#pragma unroll
+  for (int n = 0; n < NC; ++n) {
+    const int c0 = 256 * n;
+    if (c0 >= H) break;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { red[0][wl][lane * 4 + e] = ag[n][e]; red[1][wl][lane * 4 + e] = ab[n][e]; red[2][wl][lane * 4 + e] = ac[n][e]; }
+    __syncthreads();
+    // the atomics on one address serialise at the memory side (about 20 ns each, measured: 1024 -> 2048 blocks costs +20 us), hence
+    // few, large blocks: thread t < 768 sums column t % 256 of accumulator t / 256 over the block's waves and adds it once
+    const int t = threadIdx.x & 255;
+    const int col = c0 + t;
+    for (int which = threadIdx.x >> 8; which < 3; which += WPB / 4) {
+      if (col < H && (which < 2 || colsum)) {
+        const float gs = gscale ? *gscale : 1.0f;
+        float a = 0.f;
+#pragma unroll
+        for (int w = 0; w < WPB; ++w) a += red[which][w][t];
+        atomicAdd((which == 0 ? dgamma : which == 1 ? dbeta : colsum) + col, gs * a);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+int g_mv_ln_bwd_variant = 0;     // test / experiment hook, see mv_layernorm_bwd; grid cap in bits 8..
+extern "C" void mv_set_rowops_variant(int v) { g_mv_ln_bwd_variant = v; }
+
 extern "C" int mv_layernorm_fwd(int dtype, const void* x, int x_dtype, const float* gamma, const float* beta, void* y, void* y_bf16,
                                 float* mean, float* rstd, int M, int H, float eps, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
@@ -163,12 +282,27 @@ extern "C" int mv_layernorm_bwd(int dtype, const void* dy, const void* x, int x_
   hipStream_t stream = (hipStream_t)stream_;
   if (!dy || !x || !mean || !rstd || !gamma || !dx || !dgamma || !dbeta || M <= 0 || H <= 0) return MV_E_ARG;
   if ((H & 3) || H > MV_MAX_H) return MV_E_SHAPE;
-  int blocks = (M + 3) / 4;
-  if (blocks > 1024) blocks = 1024;
-  dim3 grid(blocks), block(256);
+  int var = g_mv_ln_bwd_variant & 0xff;                 // 0: 8 waves per block x 512 blocks (default) | 1: old kernel | 2: prefetch, 4 waves | 3: 16 waves x 256
+  // (the 8- and 16-wave blocks have 128 registers per lane: enough for rows of up to 768 16-bit elements, beyond that they would spill)
+  if ((var == 0 || var == 3) && !(H <= 768 && x_dtype != MV_F32)) var = 2;
+  const int wpb = var == 0 ? 8 : var == 3 ? 16 : 4;
+  int blocks = (M + wpb - 1) / wpb;
+  const int cap = (g_mv_ln_bwd_variant >> 8) > 0 ? (g_mv_ln_bwd_variant >> 8) : (var == 0 ? 512 : var == 3 ? 256 : 1024);
+  if (blocks > cap) blocks = cap;
+  dim3 grid(blocks), block(64 * wpb);
   const DropCfg drop = mv_make_drop(dx_drop ? p_drop : 0.f, drop_key);
   if (dx_drop && drop.thr == 0) dx_drop = nullptr;
-#define LNB(NC_) hipLaunchKernelGGL((ln_bwd_kernel<TX_, TD_, NC_>), grid, block, 0, stream, (const TD_*)dy, (const TX_*)x, mean, rstd, gamma, (TD_*)dx, dgamma, dbeta, colsum, M, H, (TD_*)dx_drop, drop, grad_unscale_dev)
+#define LNB_ARGS (const TD_*)dy, (const TX_*)x, mean, rstd, gamma, (TD_*)dx, dgamma, dbeta, colsum, M, H, (TD_*)dx_drop, drop, grad_unscale_dev
+#define LNB(NC_)                                                                                                                  \
+  do {                                                                                                                            \
+    constexpr bool wide_ok__ = (NC_) <= 3 && sizeof(TX_) == 2;                                                                    \
+    if constexpr (wide_ok__) {                                                                                                    \
+      if (var == 3) { hipLaunchKernelGGL((ln_bwd_pf_kernel<TX_, TD_, NC_, 16>), grid, block, 0, stream, LNB_ARGS); break; }       \
+      if (var == 0) { hipLaunchKernelGGL((ln_bwd_pf_kernel<TX_, TD_, NC_, 8>), grid, block, 0, stream, LNB_ARGS); break; }        \
+    }                                                                                                                             \
+    if (var != 1) hipLaunchKernelGGL((ln_bwd_pf_kernel<TX_, TD_, NC_, 4>), grid, block, 0, stream, LNB_ARGS);                \
+    else hipLaunchKernelGGL((ln_bwd_kernel<TX_, TD_, NC_>), grid, block, 0, stream, (const TD_*)dy, (const TX_*)x, mean, rstd, gamma, (TD_*)dx, dgamma, dbeta, colsum, M, H, (TD_*)dx_drop, drop, grad_unscale_dev); \
+  } while (0)
   if (dtype == MV_F32 && x_dtype == MV_F32) { typedef float TX_; typedef float TD_; NC_DISPATCH(H, LNB); }
   else if (dtype == MV_BF16 && x_dtype == MV_F32) { typedef float TX_; typedef bf16_t TD_; NC_DISPATCH(H, LNB); }
   else if (dtype == MV_BF16 && x_dtype == MV_BF16) { typedef bf16_t TX_; typedef bf16_t TD_; NC_DISPATCH(H, LNB); }

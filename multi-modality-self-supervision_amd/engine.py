@@ -909,6 +909,7 @@ class Engine:
         synchronisation; under data parallelism every rank sees the same all-reduced gradient and decides alike."""
         if self.scaler is None:
             return
+        # (counting everything but the embeddings bucket on the side stream under the embedding backward was measured: no change)
         ops.count_nonfinite(self.flat_g, self.scaler[6:7])
         ops.scaler_update(self.scaler, growth_interval=self.scale_growth_interval)
 

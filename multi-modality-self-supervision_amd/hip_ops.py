@@ -361,5 +361,10 @@ def attn_drop_prob(p_drop: float) -> float:
     return round(p_drop * (1 << n)) / float(1 << n)
 
 
+def set_rowops_variant(v: int = 0):
+    """Experiment hook of mv_layernorm_bwd (see include/medvill.h)."""
+    _lib().mv_set_rowops_variant(int(v))
+
+
 def set_gemm_variant(force: int = 0, nj: int = 0):
     _lib().mv_set_gemm_variant(int(force), int(nj))

@@ -50,6 +50,10 @@ VARIANTS = {
     "planes": [("attention-dropout mask generator: 16 bits per uniform", lambda: mv.hip_ops.set_attn_planes(16)),
                ("12 bits", lambda: mv.hip_ops.set_attn_planes(12)), ("8 bits", lambda: mv.hip_ops.set_attn_planes(8))],
     "drop": [("dropout off (eval-mode forward inside the training step)", lambda: model.eval()), ("dropout 0.1", lambda: model.train())],
+    "ln": [("LayerNorm backward: one row at a time, 4 waves x 1024 blocks", lambda: mv.hip_ops.set_rowops_variant(1)),
+           ("prefetch, 8 waves x 512 blocks", lambda: mv.hip_ops.set_rowops_variant(0)),
+           ("prefetch, 16 waves x 256 blocks", lambda: mv.hip_ops.set_rowops_variant(3)),
+           ("prefetch, 4 waves x 512 blocks", lambda: mv.hip_ops.set_rowops_variant(2 | (512 << 8)))],
     "tail": [("last layer on all rows", lambda: setattr(step, "tail_rows", False)), ("last layer on consumed rows", lambda: setattr(step, "tail_rows", True))],
 }
 which = sys.argv[1] if len(sys.argv) > 1 else "pack"

@@ -520,6 +520,38 @@ def test_layernorm_fwd_bwd(dt, M, H):
     assert relerr(cs, dx.double().sum(0)) < (1e-4 if dt == torch.float32 else 2e-2)
 
 
+@pytest.mark.parametrize("variant", [0, 2, 3])
+@pytest.mark.parametrize("M,H", [(5000, 768), (37, 256), (700, 512), (3000, 1024)])
+def test_layernorm_bwd_kernel_variants(variant, M, H):
+    """The prefetching LayerNorm backward (16 / 4 / 8 waves per block; 16-bit rows of up to 768 elements take the wide blocks, others
+    fall back) against the one-row-at-a-time kernel: dx and the dropped copy bit for bit, the column sums to f32 summation order."""
+    f16 = torch.float16
+    x = (rnd((M, H), torch.float32, 31, 2.0) + 0.5).to(f16)
+    g = rnd((H,), torch.float32, 32) * 0.1 + 1.0
+    dy = rnd((M, H), f16, 34)
+    mean, rstd = x.float().mean(1), 1.0 / torch.sqrt(x.float().var(1, unbiased=False) + 1e-12)
+    us = torch.tensor([0.25], device=DEV)
+    out = {}
+    try:
+        for v in (1, variant):
+            ops.set_rowops_variant(v)
+            dx, dxd = torch.zeros((M, H), dtype=f16, device=DEV), torch.zeros((M, H), dtype=f16, device=DEV)
+            dg, db, cs = torch.zeros(H, device=DEV), torch.zeros(H, device=DEV), torch.zeros(H, device=DEV)
+            ops.layernorm_bwd(dy, x, mean, rstd, g, dx, dg, db, cs, M, H, dx_drop=dxd, p_drop=0.1, drop_key=77, unscale=us)
+            out[v] = (dx, dxd, dg, db, cs)
+    finally:
+        ops.set_rowops_variant(0)
+    a, b = out[1], out[variant]
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    for i in (2, 3, 4):
+        assert relerr(b[i], a[i]) < 1e-5
+    xd = x.double().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(xd, (H,), g.double(), None, 1e-12)
+    (ref * dy.double()).sum().backward()
+    assert relerr(b[0], xd.grad) < 2e-3
+    assert relerr(b[4], 0.25 * b[1].double().sum(0)) < 1e-3
+
+
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 def test_embed_fwd_bwd(dt):
     B, N, T, H, V, maxpos = 3, 5, 30, 128, 1024, 512
