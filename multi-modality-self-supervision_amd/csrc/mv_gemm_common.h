@@ -177,6 +177,7 @@ template <int E>
 __device__ __forceinline__ void epilogue8_16(const GemmArgs& p, const OutRsrc& rs, int m, int n, f32x4 v0, f32x4 v1, f32x4 b0, f32x4 b1, float (&cs)[8],
                                              bool do_cs, u32x4 rraw = (u32x4){0u, 0u, 0u, 0u}) {
   if (m >= p.M) return;
+  if (p.dbg & 16) m &= 255;       // experiment: every tile stores into the same 256 rows (they stay in L2): what the epilogue costs without HBM writes
   float o[8] = {v0[0] + b0[0], v0[1] + b0[1], v0[2] + b0[2], v0[3] + b0[3], v1[0] + b1[0], v1[1] + b1[1], v1[2] + b1[2], v1[3] + b1[3]};
   if (E == MV_EPI_MUL || E == MV_EPI_RES) {
     float r[8];

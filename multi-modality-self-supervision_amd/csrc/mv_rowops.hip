@@ -610,19 +610,24 @@ __global__ __launch_bounds__(256) void ce_kernel(const TL* __restrict__ logits, 
 
 // Vector form: every lane owns 4 consecutive columns per step (16-byte logit loads, 8/16-byte gradient stores).
 // Used when ld, ldd are multiples of 4 and the bases are 16-byte aligned (the MLM head's padded [R, Vp] buffers).
-template <typename TL, typename TD, int MAXV>
-__global__ __launch_bounds__(256) void ce_vec_kernel(const TL* __restrict__ logits, int ld, const int32_t* __restrict__ labels,
+template <typename TL, typename TD, int MAXV, int NT>
+__global__ __launch_bounds__(NT) void ce_vec_kernel(const TL* __restrict__ logits, int ld, const int32_t* __restrict__ labels,
                                                      int R, int V, float* __restrict__ out, TD* __restrict__ dlogits, int ldd,
                                                      const float* __restrict__ gs_dev, float gs_host, const float* __restrict__ ls_dev) {
-  __shared__ float smax[4];
-  __shared__ int sarg[4];
-  __shared__ float ssum[4];
-  const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wl = tid >> 6;
+  constexpr int NWV = NT / 64;
+  __shared__ float smax[NWV];
+  __shared__ int sarg[NWV];
+  __shared__ float ssum[NWV];
+  const int tid = threadIdx.x, lane = tid & 63, wl = tid >> 6;
+  // a block walks rows blockIdx.x, + gridDim.x, ... and adds its three sums once at the end: the adds of all blocks land on the same
+  // three addresses and serialise at the memory side (about 20 ns each, profiles/r03_notes.txt) -- one set per ROW cost ~70 us here
+  float t_nll = 0.f, t_cnt = 0.f, t_ok = 0.f;
+  for (int row = blockIdx.x; row < R; row += gridDim.x) {
   const int label = labels[row];
   TD* drow = dlogits ? dlogits + (size_t)row * ldd : nullptr;
   if (label < 0 || label >= V) {
-    if (drow) for (int c = tid * 4; c < ldd; c += 1024) st4<TD>(drow + c, (f32x4){0.f, 0.f, 0.f, 0.f});
-    return;
+    if (drow) for (int c = tid * 4; c < ldd; c += NT * 4) st4<TD>(drow + c, (f32x4){0.f, 0.f, 0.f, 0.f});
+    continue;
   }
   const TL* lr = logits + (size_t)row * ld;
   f32x4 v[MAXV];
@@ -630,7 +635,7 @@ __global__ __launch_bounds__(256) void ce_vec_kernel(const TL* __restrict__ logi
   int am = 0x7fffffff;
 #pragma unroll
   for (int n = 0; n < MAXV; ++n) {
-    const int c = (tid + 256 * n) * 4;
+    const int c = (tid + NT * n) * 4;
     v[n] = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
     if (c < V) {
       f32x4 x = ld4<TL>(lr + c);
@@ -651,7 +656,7 @@ __global__ __launch_bounds__(256) void ce_vec_kernel(const TL* __restrict__ logi
   if (lane == 0) { smax[wl] = mx; sarg[wl] = am; }
   __syncthreads();
   mx = smax[0]; am = sarg[0];
-  for (int w = 1; w < 4; ++w) if (smax[w] > mx || (smax[w] == mx && sarg[w] < am)) { mx = smax[w]; am = sarg[w]; }
+  for (int w = 1; w < NWV; ++w) if (smax[w] > mx || (smax[w] == mx && sarg[w] < am)) { mx = smax[w]; am = sarg[w]; }
   float s = 0.f;
   const float mxl = mx * 1.4426950408889634f;
 #pragma unroll
@@ -662,19 +667,21 @@ __global__ __launch_bounds__(256) void ce_vec_kernel(const TL* __restrict__ logi
   s = wave_sum(s);
   if (lane == 0) ssum[wl] = s;
   __syncthreads();
-  s = ssum[0] + ssum[1] + ssum[2] + ssum[3];
+  s = 0.f;
+#pragma unroll
+  for (int w = 0; w < NWV; ++w) s += ssum[w];
   if (tid == 0) {
     const float xl = ldf<TL>(lr + label);
-    atomicAdd(out + 0, (mx + logf(s)) - xl);
-    atomicAdd(out + 1, 1.0f);
-    if (am == label) atomicAdd(out + 2, 1.0f);
+    t_nll += (mx + logf(s)) - xl;
+    t_cnt += 1.0f;
+    if (am == label) t_ok += 1.0f;
   }
   if (drow) {
     const float gs = (gs_dev ? *gs_dev : gs_host) * (ls_dev ? *ls_dev : 1.0f);   // x loss scale (16-bit gradients)
     const float inv = gs / s;
 #pragma unroll
     for (int n = 0; n < MAXV; ++n) {
-      const int c = (tid + 256 * n) * 4;
+      const int c = (tid + NT * n) * 4;
       if (c < ldd) {
         f32x4 o;
 #pragma unroll
@@ -682,6 +689,13 @@ __global__ __launch_bounds__(256) void ce_vec_kernel(const TL* __restrict__ logi
         st4<TD>(drow + c, o);
       }
     }
+  }
+  __syncthreads();       // smax / sarg / ssum are reused by the next row
+  }
+  if (tid == 0 && t_cnt > 0.f) {
+    atomicAdd(out + 0, t_nll);
+    atomicAdd(out + 1, t_cnt);
+    if (t_ok > 0.f) atomicAdd(out + 2, t_ok);
   }
 }
 
@@ -696,7 +710,10 @@ extern "C" int mv_ce_fwd_bwd(const void* logits, int l_dtype, int ld, const int3
   const bool vec_ok = ((ld & 3) == 0) && (!dlogits || (ldd & 3) == 0) && ((((uintptr_t)logits) & 15) == 0) &&
                       (!dlogits || (((uintptr_t)dlogits) & 15) == 0) && V > 2048 && ldd <= 1024 * 32 && V <= 1024 * 32;
   if (vec_ok) {
-#define CEV_LAUNCH(TL, TD) hipLaunchKernelGGL((ce_vec_kernel<TL, TD, 32>), grid, block, 0, stream, (const TL*)logits, ld, labels, R, V, out, (TD*)dlogits, ldd, grad_scale_dev, grad_scale_host, loss_scale_dev)
+    // 1024-thread blocks (32 logits per thread in registers, two blocks per CU) walking rows: more than twice the waves in flight of the
+    // 256-thread form of rounds 1-2 (128 logits per thread, three blocks per CU; 373 -> 179 us alone), one set of result atomics per block
+    const dim3 vgrid(R < 512 ? R : 512), vblock(1024);
+#define CEV_LAUNCH(TL, TD) hipLaunchKernelGGL((ce_vec_kernel<TL, TD, 8, 1024>), vgrid, vblock, 0, stream, (const TL*)logits, ld, labels, R, V, out, (TD*)dlogits, ldd, grad_scale_dev, grad_scale_host, loss_scale_dev)
     if (l_dtype == MV_F32 && d_dtype == MV_F32) CEV_LAUNCH(float, float);
     else if (l_dtype == MV_F32 && d_dtype == MV_F16) CEV_LAUNCH(float, f16_t);
     else if (l_dtype == MV_F32 && d_dtype == MV_BF16) CEV_LAUNCH(float, bf16_t);

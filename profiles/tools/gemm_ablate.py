@@ -6,7 +6,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from medvill_amd import hip_ops as ops
-from medvill_amd._lib import EPI_BIAS
+from medvill_amd._lib import EPI_BIAS, EPI_BIAS_GELU_D
 dev = "cuda"
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 25483
 H, I = 768, 3072
@@ -17,12 +17,14 @@ b1 = torch.randn(I, device=dev)
 oI, oH = torch.empty(M, I, device=dev, dtype=f16), torch.empty(M, H, device=dev, dtype=f16)
 gW1 = torch.empty(I, H, device=dev)
 ws = torch.empty(32 * I * H, device=dev)
+oI2 = torch.empty(M, I, device=dev, dtype=f16)
 CASES = [
+    ("NT ffn1 +bias+gelu+gelu' (K=768)", lambda: ops.gemm(x, W1, oI, M=M, N=I, K=H, bias=b1, epi=EPI_BIAS_GELU_D, c2=oI2)),
     ("NT ffn1 +bias (K=768)", lambda: ops.gemm(x, W1, oI, M=M, N=I, K=H, bias=b1, epi=EPI_BIAS)),
     ("TN dW1 3072x768 (K=rows, 7 slabs)", lambda: ops.gemm(xi, x, gW1, ta=True, tb=True, M=I, N=H, K=M, lda=I, ldb=H, splitk=0, ws=ws)),
     ("NN dx(ffn1) (K=3072)", lambda: ops.gemm(xi, W1, oH, tb=True, M=M, N=H, K=I, ldb=H)),
 ]
-ARMS = [("whole kernel", 0), ("no epilogue", 1), ("no epilogue, no loads", 3), ("no epilogue, no MFMA", 5), ("no epilogue, neither", 7)]
+ARMS = [("whole kernel", 0), ("stores folded onto 256 rows (no HBM writes)", 16), ("no epilogue", 1), ("no epilogue, no loads", 3), ("no epilogue, no MFMA", 5), ("no epilogue, neither", 7)]
 
 
 def t_of(fn, reps=10):
