@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MV_ABI_VERSION 3
+#define MV_ABI_VERSION 4
 
 /* MV_F16 is the encoding of the 16-bit path (weights' f16 shadow, stored activations, gradients): 11 significand bits
  * instead of bf16's 8 at the same MFMA rate.  At BERT-base depth bf16-encoded forward operands cannot meet the 1e-2 logit
@@ -182,6 +182,17 @@ int mv_mlm_corrupt(const int64_t* ids, const int32_t* lengths, const float* u, c
  * logical [B, L] indexing (so a packed run draws the same attention-dropout masks as the padded one).  All four accept
  * NULL for the dense [B*L] layout.  Packed attention exists for the bf16 MFMA kernels only.                      */
 int mv_pack_plan(const int32_t* desc, int B, int L, int32_t* cu, int32_t* rowmap, int32_t* inv, void* stream);
+/* Row order of the LAST encoder layer (round 3): attention is equivariant under a reordering of a sample's rows, and in the full / 1-D
+ * mask families the mask of a packed sample does not depend on the order either (every row sees every row).  Only the rows the heads
+ * consume (`sel`, packed row indices: labelled rows and each sample's first row) are needed as QUERIES of the last layer, so that layer
+ * runs on rows reordered with those first and its attention kernels stop after them (qlim of mv_attn_fwd / mv_attn_bwd):
+ *   perm    int32 [cu[B]]  packed row (old order) held by row i of the new order
+ *   newpos  int32 [cu[B]]  its inverse
+ *   qlim    int32 [B]      number of consumed rows of sample b (they are rows cu[b] .. cu[b]+qlim[b]-1 of the new order, ascending old order)
+ *   sel_new int32 [n_sel]  newpos[sel[i]]
+ * L: the logical sequence length (an upper bound of every sample's row count, <= 2048).  */
+int mv_tail_perm(const int32_t* cu, int B, int L, const int32_t* sel, int n_sel, int32_t* perm, int32_t* newpos, int32_t* qlim,
+                 int32_t* sel_new, void* stream);
 
 /* ---- fused-mask multi-head attention --------------------------------------------------------
  * Replaces HF BertSelfAttention's scores/softmax/context (spec:
@@ -195,10 +206,12 @@ int mv_pack_plan(const int32_t* desc, int B, int L, int32_t* cu, int32_t* rowmap
  * P(drop) of that generator: the forward and both backward kernels spend one select per score element (they are bound by vector-instruction
  * issue, not by MFMA, so nothing is hashed inside them).
  * dtype MV_F16: qkv and ctx in the f16 encoding; ctx_bf16 (nullable, MV_F16 only) receives the bf16 copy of ctx that
- * the backward pairs with bf16 gradients.  */
+ * the backward pairs with bf16 gradients.
+ * qlim (nullable, int32 [B]): only the first qlim[b] rows of sample b are queries (every row is a key); the context / lse of the other
+ * rows are left untouched.  MFMA kernels only.  */
 int mv_attn_fwd(int dtype, const void* qkv, const uint32_t* bits, const uint8_t* tileinfo,
                 void* ctx, void* ctx_bf16, float* lse, int B, int L, int A, int dh,
-                float p_drop, const uint32_t* dropbits, const int32_t* cu, int total_rows, void* stream);
+                float p_drop, const uint32_t* dropbits, const int32_t* cu, int total_rows, const int32_t* qlim, void* stream);
 
 /* The attention-probability dropout mask of one layer as keep-bits, laid out as the kernels' select masks:
  * dropbits uint32 [B*A][ceil(L/32)][ceil(L/64)][64] (64-byte aligned), i.e. per (head, 32-query block, 64-key tile) 32 x uint64;
@@ -211,11 +224,12 @@ int mv_attn_dropmask(float p_drop, unsigned long long drop_key, int B, int L, in
                      void* stream);
 
 /* dqkv [B*L,3H] from dctx [B*L,H]; `delta` is a [B,A,L] f32 scratch (rowsum(dctx*ctx)).  dtype (MV_F32, MV_BF16 or
- * MV_F16) is the encoding of qkv, ctx, dctx and dqkv alike. */
+ * MV_F16) is the encoding of qkv, ctx, dctx and dqkv alike.  qlim (nullable): as in mv_attn_fwd; the dctx rows past a sample's
+ * limit are ignored (taken as zero) and their dQ rows are written as zeros. */
 int mv_attn_bwd(int dtype, const void* qkv, const void* ctx, const void* dctx, const float* lse,
                 const uint32_t* bits, const uint8_t* tileinfo,
                 void* dqkv, float* delta, int B, int L, int A, int dh,
-                float p_drop, const uint32_t* dropbits, const int32_t* cu, int total_rows, void* stream);
+                float p_drop, const uint32_t* dropbits, const int32_t* cu, int total_rows, const int32_t* qlim, void* stream);
 
 /* ---- LayerNorm ------------------------------------------------------------------------------
  * y = (x-mean)/sqrt(var+eps)*gamma+beta over the last dim (HF LayerNorm eps=1e-12 in the

@@ -38,9 +38,10 @@ PROTOTYPES = {
     "mv_mlm_draws": [u64, i32, i32, i32, vp, vp, vp],
     "mv_mlm_corrupt": [vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "mv_pack_plan": [vp, i32, i32, vp, vp, vp, vp],
-    "mv_attn_fwd": [i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp, vp, i32, vp],
+    "mv_tail_perm": [vp, i32, i32, vp, i32, vp, vp, vp, vp, vp],
+    "mv_attn_fwd": [i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp, vp, i32, vp, vp],
     "mv_attn_dropmask": [f32, u64, i32, i32, i32, vp, vp, vp],
-    "mv_attn_bwd": [i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp, vp, i32, vp],
+    "mv_attn_bwd": [i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp, vp, i32, vp, vp],
     "mv_layernorm_fwd": [i32, vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, f32, vp],
     "mv_layernorm_bwd": [i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, f32, u64, vp, vp],
     "mv_embed_fwd": [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, f32,
@@ -92,7 +93,7 @@ def load(build_if_missing: bool = False):
         fn = getattr(lib, name)          # AttributeError if an exported symbol is missing
         fn.argtypes = args
         fn.restype = _RESTYPE.get(name, C.c_int)
-    if lib.mv_abi_version() != 3:
+    if lib.mv_abi_version() != 4:
         raise RuntimeError("libmedvill_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -157,6 +157,10 @@ struct AttnArgs {
   // packed rows (nullable): sample b owns rows cu[b] .. cu[b+1]-1 of qkv / ctx / dctx / out / dqkv, i.e. only its first
   // cu[b+1]-cu[b] positions exist; mask words, lse, delta and the dropout counter keep their logical [B, L] indexing
   const int32_t* cu;
+  // query limit (nullable): only the first qlim[b] rows of sample b are QUERIES (every row is a key).  The forward leaves the context /
+  // lse of the other rows untouched, the backward writes zero dQ rows for them and ignores their dctx rows.  Used for the last encoder
+  // layer, whose rows are reordered so that the rows the heads consume come first (mv_tail_perm).
+  const int32_t* qlim;
 };
 // ---- precomputed dropout keep-bits -------------------------------------------------------------------------------------------
 typedef unsigned long long u64x8 __attribute__((ext_vector_type(8)));
@@ -374,18 +378,34 @@ __device__ __forceinline__ int next_tile(unsigned long long need, int after, int
 }
 
 // ---- forward --------------------------------------------------------------------------------
+// Block -> (128-row block xb, head, sample).  Workgroups go to the 8 XCDs round-robin in dispatch order (x fastest).  With
+// (x, y, z) = (row block, head, sample) read off blockIdx directly, XCD k only ever saw row block k % 4 -- and in a packed or ragged batch
+// the LAST row block of most samples is nearly empty (390 of 512 rows on average): two XCDs idled while six did the work (found with the
+// query-limit sweep of profiles/tools/tailq_bench.py: a launch with one row block per head ran on 2 XCDs).  Here the row block is the SLOWEST
+// index of the dispatch order: every XCD gets every row block of its (head, sample) pairs -- which also share their K / V tiles in that
+// XCD's L2 -- and the nearly empty blocks come last.
+__device__ __forceinline__ void att_block(int& xb, int& head, int& b) {
+  const int flat = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+  const int nhb = gridDim.y * gridDim.z;
+  xb = flat / nhb;
+  const int rem = flat - xb * nhb;
+  b = rem / gridDim.y;
+  head = rem - b * gridDim.y;
+}
 #define FWD_NS 3      // 48 KiB of LDS per block: three blocks per CU
 template <bool F16>
 __global__ __launch_bounds__(256, 3) void attn_fwd_mfma_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // FWD_NS stages x (K 8 KiB + V 8 KiB)
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int head = blockIdx.y, b = blockIdx.z;
+  int xb, head, b;
+  att_block(xb, head, b);
   const int L = a.L, H = a.H, ld = 3 * a.H, T = a.T;
-  const int qb0 = blockIdx.x * 128, q0 = qb0 + wid * 32, q = q0 + l31;
+  const int qb0 = xb * 128, q0 = qb0 + wid * 32, q = q0 + l31;
   const int Lv = a.cu ? a.cu[b + 1] - a.cu[b] : L;             // positions of this sample that exist as rows
-  if (qb0 >= Lv) return;
-  const bool wave_on = q0 < Lv, q_ok = q < Lv;
+  const int Lq = a.qlim ? min(Lv, a.qlim[b]) : Lv;             // ... and those that are queries
+  if (qb0 >= Lq) return;
+  const bool wave_on = q0 < Lq, q_ok = q < Lq;
   const size_t rowbase = a.cu ? (size_t)a.cu[b] : (size_t)b * L;
   const size_t lrow = (size_t)b * L;                            // logical row base (mask words)
   __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.qkv, 0, a.bytes_qkv, 0x00020000);
@@ -588,13 +608,24 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_mfma_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int head = blockIdx.y, b = blockIdx.z;
+  int xb, head, b;
+  att_block(xb, head, b);
   const int L = a.L, H = a.H, ld = 3 * a.H, T = a.T;
-  const int qb0 = blockIdx.x * 128, q0 = qb0 + wid * 32, q = q0 + l31;
+  const int qb0 = xb * 128, q0 = qb0 + wid * 32, q = q0 + l31;
   const int Lv = a.cu ? a.cu[b + 1] - a.cu[b] : L;
+  const int Lq = a.qlim ? min(Lv, a.qlim[b]) : Lv;
   if (qb0 >= Lv) return;
-  const bool wave_on = q0 < Lv, q_ok = q < Lv;
   const size_t rowbase = a.cu ? (size_t)a.cu[b] : (size_t)b * L;
+  if (qb0 >= Lq) {        // rows that are keys only: their dQ is zero (thread t: row t / 2, 32 of the head's 64 columns)
+    const int r = qb0 + (tid >> 1);
+    if (r < Lv) {
+      bf16_t* z = a.dqkv + (rowbase + r) * (size_t)ld + head * 64 + 32 * (tid & 1);
+#pragma unroll
+      for (int c = 0; c < 32; c += 4) store4_16<F16>(z + c, 0.f, 0.f, 0.f, 0.f);
+    }
+    return;
+  }
+  const bool wave_on = q0 < Lq, q_ok = q < Lq;
   const size_t lrow = (size_t)b * L;
   __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.qkv, 0, a.bytes_qkv, 0x00020000);
   const dma_rsrc_t rsq = dma_rsrc(a.qkv, a.bytes_qkv);
@@ -672,13 +703,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_mfma_kernel(AttnArgs a) {
     cur = next_tile(tmk.need, cur, nkt);
     ++done;
   }
-  if (!q_ok) return;
+  if (q >= Lv) return;
   bf16_t* orow = a.dqkv + (rowbase + q) * (size_t)ld + head * 64;
 #pragma unroll
   for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      store4_16<F16>(orow + 32 * dt + 8 * g + 4 * h, dq[dt][4 * g], dq[dt][4 * g + 1], dq[dt][4 * g + 2], dq[dt][4 * g + 3]);
+      if (q_ok) store4_16<F16>(orow + 32 * dt + 8 * g + 4 * h, dq[dt][4 * g], dq[dt][4 * g + 1], dq[dt][4 * g + 2], dq[dt][4 * g + 3]);
+      else store4_16<F16>(orow + 32 * dt + 8 * g + 4 * h, 0.f, 0.f, 0.f, 0.f);       // a key-only row inside a query tile (a.qlim)
     }
 }
 
@@ -752,9 +784,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_mfma_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int head = blockIdx.y, b = blockIdx.z;
+  int xb, head, b;
+  att_block(xb, head, b);
   const int L = a.L, H = a.H, ld = 3 * a.H, T = a.T;
-  const int kb0 = blockIdx.x * 128, k0w = kb0 + wid * 32, key = k0w + l31;
+  const int kb0 = xb * 128, k0w = kb0 + wid * 32, key = k0w + l31;
   const int Lv = a.cu ? a.cu[b + 1] - a.cu[b] : L;
   if (kb0 >= Lv) return;
   const bool wave_on = k0w < Lv, k_ok = key < Lv;
@@ -775,7 +808,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_mfma_kernel(AttnArgs a) {
 #pragma unroll
   for (int i = 0; i < 16; ++i) { dk[0][i] = 0.f; dk[1][i] = 0.f; dv[0][i] = 0.f; dv[1][i] = 0.f; }
 
-  const int nqt = (Lv + 63) / 64;
+  const int Lq = a.qlim ? min(Lv, a.qlim[b]) : Lv;        // rows that are queries: the others arrive as zero rows with zero statistics
+  const int nqt = (Lq + 63) / 64;
   const int ka = kb0 >> 6;
   const int kw0 = kb0 >> 5;           // first of the block's 4 mask words
   const size_t sbase = ((size_t)b * a.A + head) * L;
@@ -794,24 +828,24 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_mfma_kernel(AttnArgs a) {
   int iss = cur, issued = 0, done = 0;
   auto issue = [&]() {
     char* st_ = smem + (issued % DKV_NS) * KV_STAGE;
-    tile_dma<4>(rsq, a.bytes_qkv, rowbase, iss * 64, Lv, ld, head * 64, st_, wid, lane);
-    tile_dma<4>(rsdo, a.bytes_ctx, rowbase, iss * 64, Lv, H, head * 64, st_ + 8192, wid, lane);
+    tile_dma<4>(rsq, a.bytes_qkv, rowbase, iss * 64, Lq, ld, head * 64, st_, wid, lane);
+    tile_dma<4>(rsdo, a.bytes_ctx, rowbase, iss * 64, Lq, H, head * 64, st_ + 8192, wid, lane);
     {   // 64 rows x 4 mask words: 256 dwords, 64 per wave
       const int idx = wid * 64 + lane, qq = iss * 64 + (idx >> 2), wi = kw0 + (idx & 3);
-      const bool ok = qq < Lv && wi < a.W;
+      const bool ok = qq < Lq && wi < a.W;
       const unsigned off = (unsigned)(((lrow + qq) * (size_t)a.W + wi) * 4);
       lds_dma4(rsw, (MV_LDS void*)(st_ + 16384 + 512 + wid * 256), ok ? off : a.bytes_bits);
     }
     {   // lse (even waves) / delta (odd waves) of the 64 query rows; issued by every wave so that the counted waits are uniform
       const int qi = iss * 64 + lane;
       const unsigned off = (unsigned)((sbase + qi) * 4);
-      if (wid & 1) lds_dma4(rsdl, (MV_LDS void*)(st_ + 16384 + 256), qi < Lv ? off : a.bytes_stat);
-      else lds_dma4(rsl, (MV_LDS void*)(st_ + 16384), qi < Lv ? off : a.bytes_stat);
+      if (wid & 1) lds_dma4(rsdl, (MV_LDS void*)(st_ + 16384 + 256), qi < Lq ? off : a.bytes_stat);
+      else lds_dma4(rsl, (MV_LDS void*)(st_ + 16384), qi < Lq ? off : a.bytes_stat);
     }
     if (use_db) {   // keep-bit dwords of this wave's 32 keys for the tile's two 32-query halves (lane >> 5)
       const size_t blk = dbits_block(a, (size_t)b * a.A + head, 2 * iss + (lane >> 5), k0w >> 6);
       const unsigned off = (unsigned)((blk * 2 + db_in_block) * 4);
-      lds_dma4(rsdb, (MV_LDS void*)(st_ + 16384 + 512 + 1024 + wid * 256), (k0w < Lv && (2 * iss + (lane >> 5)) * 32 < Lv) ? off : a.bytes_dbits);
+      lds_dma4(rsdb, (MV_LDS void*)(st_ + 16384 + 512 + 1024 + wid * 256), (k0w < Lv && (2 * iss + (lane >> 5)) * 32 < Lq) ? off : a.bytes_dbits);
     }
     ++issued;
     iss = next_tile(tmk.need, iss, nqt);
@@ -1103,7 +1137,7 @@ static int launch_simple_fwd(const void* qkv, const uint32_t* bits, void* ctx, f
 
 extern "C" int mv_attn_fwd(int dtype, const void* qkv, const uint32_t* bits, const uint8_t* tileinfo, void* ctx, void* ctx_bf16,
                            float* lse, int B, int L, int A, int dh, float p_drop, const uint32_t* dropbits,
-                           const int32_t* cu, int total_rows, void* stream_) {
+                           const int32_t* cu, int total_rows, const int32_t* qlim, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!qkv || !bits || !tileinfo || !ctx || !lse || B <= 0 || L <= 0 || A <= 0 || dh <= 0) return MV_E_ARG;
   if (!mv_dtype_ok(dtype)) return MV_E_DTYPE;
@@ -1118,7 +1152,7 @@ extern "C" int mv_attn_fwd(int dtype, const void* qkv, const uint32_t* bits, con
     const size_t bq = nrow * 3 * H * 2;
     if (bq >= 0x7fffffffULL || (((uintptr_t)qkv) & 15) || (((uintptr_t)ctx) & 7) || (((uintptr_t)ctx_bf16) & 7)) return MV_E_SHAPE;
     AttnArgs a{};
-    a.cu = cu;
+    a.cu = cu; a.qlim = qlim;
     a.qkv = (const bf16_t*)qkv; a.out = (bf16_t*)ctx; a.out2 = (bf16_t*)ctx_bf16; a.bits = bits; a.info = tileinfo; a.lse = lse;
     a.B = B; a.L = L; a.A = A; a.H = H; a.W = (L + 31) / 32; a.T = (L + 63) / 64;
     a.scale = 1.0f / sqrtf((float)dh);
@@ -1137,7 +1171,7 @@ extern "C" int mv_attn_fwd(int dtype, const void* qkv, const uint32_t* bits, con
     MV_CHECK_LAUNCH();
     return MV_OK;
   }
-  if (dh > 128 || cu) return MV_E_SHAPE;       // packed rows: MFMA kernels only
+  if (dh > 128 || cu || qlim) return MV_E_SHAPE;       // packed rows / query limits: MFMA kernels only
   if (dtype == MV_F16) {                         // VALU cross-check of the f16 forward (mv_set_impl(1))
     int rc = launch_simple_fwd<f16_t>(qkv, bits, ctx, lse, B, L, A, dh, p_drop, dropbits, stream);
     if (rc == MV_OK && ctx_bf16) rc = mv_cast(ctx, MV_F16, ctx_bf16, MV_BF16, (size_t)B * L * H, stream_);
@@ -1169,7 +1203,7 @@ static int launch_simple_bwd(const void* qkv, const void* ctx, const void* dctx,
 
 extern "C" int mv_attn_bwd(int dtype, const void* qkv, const void* ctx, const void* dctx, const float* lse, const uint32_t* bits,
                            const uint8_t* tileinfo, void* dqkv, float* delta, int B, int L, int A, int dh, float p_drop,
-                           const uint32_t* dropbits, const int32_t* cu, int total_rows, void* stream_) {
+                           const uint32_t* dropbits, const int32_t* cu, int total_rows, const int32_t* qlim, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!qkv || !ctx || !dctx || !lse || !bits || !tileinfo || !dqkv || !delta || B <= 0 || L <= 0 || A <= 0 || dh <= 0)
     return MV_E_ARG;
@@ -1184,7 +1218,7 @@ extern "C" int mv_attn_bwd(int dtype, const void* qkv, const void* ctx, const vo
     const size_t bq = nrow * 3 * H * 2, bc = nrow * H * 2;
     if (bq >= 0x7fffffffULL || (((uintptr_t)qkv) & 15) || (((uintptr_t)dctx) & 15) || (((uintptr_t)dqkv) & 7)) return MV_E_SHAPE;
     AttnArgs a{};
-    a.cu = cu;
+    a.cu = cu; a.qlim = qlim;
     a.qkv = (const bf16_t*)qkv; a.ctx = (const bf16_t*)ctx; a.dctx = (const bf16_t*)dctx; a.dqkv = (bf16_t*)dqkv;
     a.bits = bits; a.info = tileinfo; a.lse_in = lse; a.delta = delta; a.delta_out = delta;
     a.B = B; a.L = L; a.A = A; a.H = H; a.W = (L + 31) / 32; a.T = (L + 63) / 64;
@@ -1211,7 +1245,7 @@ extern "C" int mv_attn_bwd(int dtype, const void* qkv, const void* ctx, const vo
     MV_CHECK_LAUNCH();
     return MV_OK;
   }
-  if (dh > 128 || cu) return MV_E_SHAPE;
+  if (dh > 128 || cu || qlim) return MV_E_SHAPE;
   if (dtype == MV_F16) return launch_simple_bwd<f16_t>(qkv, ctx, dctx, lse, bits, dqkv, delta, B, L, A, dh, p_drop, dropbits, stream);
   return dtype == MV_F32 ? launch_simple_bwd<float>(qkv, ctx, dctx, lse, bits, dqkv, delta, B, L, A, dh, p_drop, dropbits, stream)
                          : launch_simple_bwd<bf16_t>(qkv, ctx, dctx, lse, bits, dqkv, delta, B, L, A, dh, p_drop, dropbits, stream);

@@ -147,6 +147,46 @@ __global__ __launch_bounds__(NT) void pack_plan_kernel(const int32_t* __restrict
   }
 }
 
+// Row order of the last encoder layer: within every sample the rows the heads consume (`sel`: labelled rows + first rows) come first,
+// in ascending order, then the others.  One block per sample; wave 0 assigns positions with ballots (stable partition).
+#define TP_MAXL 2048
+__global__ __launch_bounds__(NT) void tail_perm_kernel(const int32_t* __restrict__ cu, const int32_t* __restrict__ sel, int n_sel,
+                                                       int32_t* __restrict__ perm, int32_t* __restrict__ newpos,
+                                                       int32_t* __restrict__ qlim, int32_t* __restrict__ sel_new) {
+  __shared__ unsigned char flag[TP_MAXL];
+  const int b = blockIdx.x, lo = cu[b], n = cu[b + 1] - lo, lane = threadIdx.x & 63;
+  for (int i = threadIdx.x; i < n; i += NT) flag[i] = 0;
+  __syncthreads();
+  for (int i = threadIdx.x; i < n_sel; i += NT) {
+    const int r = sel[i] - lo;
+    if (r >= 0 && r < n) flag[r] = 1;
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    int pos = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+      for (int c = 0; c < n; c += 64) {
+        const int r = c + lane;
+        const bool f = r < n && (flag[r] != 0) == (pass == 0);
+        const unsigned long long m = __ballot(f);
+        if (f) {
+          const int p = pos + __popcll(m & ((1ull << lane) - 1ull));
+          perm[lo + p] = lo + r;
+          newpos[lo + r] = lo + p;
+        }
+        pos += __popcll(m);
+      }
+      if (pass == 0 && lane == 0) qlim[b] = pos;
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
+  for (int i = threadIdx.x; i < n_sel; i += NT) {
+    const int r = sel[i] - lo;
+    if (r >= 0 && r < n) sel_new[i] = newpos[lo + r];
+  }
+}
+
 }  // namespace
 
 extern "C" int mv_pack_plan(const int32_t* desc, int B, int L, int32_t* cu, int32_t* rowmap, int32_t* inv, void* stream_) {
@@ -154,6 +194,16 @@ extern "C" int mv_pack_plan(const int32_t* desc, int B, int L, int32_t* cu, int3
   if (!desc || !cu || !rowmap || !inv || B <= 0 || L <= 0) return MV_E_ARG;
   if ((long long)B * L > 0x7fffffffLL) return MV_E_SHAPE;
   pack_plan_kernel<<<B, NT, 0, stream>>>(desc, B, L, cu, rowmap, inv);
+  MV_CHECK_LAUNCH();
+  return MV_OK;
+}
+
+extern "C" int mv_tail_perm(const int32_t* cu, int B, int L, const int32_t* sel, int n_sel, int32_t* perm, int32_t* newpos,
+                           int32_t* qlim, int32_t* sel_new, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!cu || !sel || !perm || !newpos || !qlim || !sel_new || B <= 0 || L <= 0 || n_sel <= 0) return MV_E_ARG;
+  if (L > TP_MAXL) return MV_E_SHAPE;
+  tail_perm_kernel<<<B, NT, 0, stream>>>(cu, sel, n_sel, perm, newpos, qlim, sel_new);
   MV_CHECK_LAUNCH();
   return MV_OK;
 }

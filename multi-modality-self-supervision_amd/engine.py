@@ -181,6 +181,7 @@ class Engine:
         self._w2t, self._w2t_ev, self._w2t_stale = None, None, True
         self.head_on_side = True  # the tied decoder's weight gradient on the side stream (see _mlm_backward)
         self.fused_colsum = os.environ.get("MV_FUSED_COLSUM", "1") != "0"   # bias gradients from partial sums of the producing kernels
+        self.tail_queries = os.environ.get("MV_TAIL_QUERIES", "1") != "0"    # last layer's attention: consumed rows only as queries (see encoder_forward)
         self._mask_stream = None      # third stream: the attention-dropout keep-bits of every layer are generated at the start of a forward
         self._dE_ev = None
         self._opt_ev = None       # overlapped AdamW: parameter range -> event (see adamw_step)
@@ -410,7 +411,7 @@ class Engine:
             self.sync_shadow()
         self._wait_opt("embeddings")
         f32 = torch.float32
-        S = self.S = dict(B=B, T=T, N=N, L=Lq, M=M, cu=None, rowmap=None, inv=None, sel=None, n_lab=0)
+        S = self.S = dict(B=B, T=T, N=N, L=Lq, M=M, cu=None, rowmap=None, inv=None, sel=None, n_lab=0, tq=None)
         if pack:
             if not isinstance(attn_mask, MaskDesc) or not self.is16:
                 raise ValueError("pack=True needs mask descriptors (data.MaskDesc) and the bf16 path")
@@ -429,6 +430,14 @@ class Engine:
             first = cu[:B] if cu is not None else torch.arange(B, device=dev, dtype=torch.int32) * Lq
             S["sel"] = torch.cat([lab.to(torch.int32), first.to(torch.int32)]).contiguous()
             S["n_lab"] = int(tail_rows.numel())
+            # The consumed rows are also the only QUERIES the last layer's attention needs (its keys / values are all rows).  In the full /
+            # 1-D families a packed sample's mask is "every row sees every row" whatever the order of the rows, so the last layer runs on
+            # rows reordered with the consumed ones first and its attention kernels stop after them (mv_tail_perm, qlim): exact, and
+            # about 70 % of that layer's attention forward and backward is not computed.
+            S["tq"] = None
+            if pack and self.tail_queries and cfg.layers >= 1 and ops.get_impl() == 0 and Lq <= 2048 and \
+                    bool(((hd[:, 0] == 0) | (hd[:, 0] == 4)).all()):
+                S["tq"] = ops.tail_perm(cu, B, Lq, S["sel"], M)          # (perm, newpos, qlim, sel_new)
         pd = S["p_drop"] = float(cfg.dropout) if self.training else 0.0
         self.drop_counter += 1
         dk = S["drop_keys"] = self._drop_keys(cfg.layers)
@@ -504,6 +513,14 @@ class Engine:
             p = f"enc.encoder.layer.{l}."
             Wqkv, bqkv, _, _ = self.qkv_views(l, fwd=True)
             a_ = {}
+            tq = S["tq"] if l == cfg.layers - 1 else None
+            if tq is not None:
+                # last layer on the reordered rows (consumed rows first within each sample); its output only exists on the consumed rows
+                xp, xp_b = self._pair("tail_xperm", (M, H))
+                ops.gather_rows(x, H, tq[0], M, H, xp, H)
+                if dual:
+                    ops.gather_rows(x_b, H, tq[0], M, H, xp_b, H)
+                x, x_b = xp, xp_b
             a_["x"] = x_b
             qkv, qkv_b = self._pair(f"qkv{l}", (M, 3 * H))
             a_["qkv"] = qkv_b
@@ -516,11 +533,11 @@ class Engine:
                 a_["dropbits"] = db_ev[l][0]
                 torch.cuda.current_stream().wait_event(db_ev[l][1])
             ops.attn_fwd(qkv, bits, tinfo, ctx, lse, B, Lq, A, dh, p_drop=pd, cu=cu,
-                         total_rows=M, ctx_bf16=xb2(ctx, ctx_b), dropbits=a_["dropbits"])
+                         total_rows=M, ctx_bf16=xb2(ctx, ctx_b), dropbits=a_["dropbits"], qlim=tq[2] if tq is not None else None)
             Mr = M                  # rows the rest of this layer runs on
             if l == cfg.layers - 1 and S["sel"] is not None:
                 # last layer: only the labelled rows and the first row of every sample are consumed downstream
-                sel = S["sel"]
+                sel = S["sel"] if tq is None else tq[3]
                 Mr = int(sel.numel())
                 ctx_s, ctx_sb = self._pair("tail_ctx", (Mr, H))
                 x_s = self._buf("tail_x", (Mr, H), fadt)
@@ -863,12 +880,13 @@ class Engine:
                 dctx_s = self._buf("bw_dctx_tail", (M, H), adt)
                 ops.gemm(dproj1, self.w[p + "attention.output.dense.weight"], dctx_s, tb=True, M=M, N=H, K=H)
                 dctx.zero_()
-                ops.scatter_rows(dctx_s, H, S["sel"], M, H, dctx, H, accumulate=False)
+                ops.scatter_rows(dctx_s, H, S["sel"] if S["tq"] is None else S["tq"][3], M, H, dctx, H, accumulate=False)
             else:
                 ops.gemm(dproj1, self.w[p + "attention.output.dense.weight"], dctx, tb=True, M=M, N=H, K=H)
             M = M_all
+            tq = S["tq"] if tail else None
             ops.attn_bwd(a_["qkv"], a_["ctx"], dctx, a_["lse"], S["bits"], S["tinfo"], dqkv, delta, B, Lq, A, dh, cu=S["cu"],
-                         total_rows=M, p_drop=pd, dropbits=a_["dropbits"])
+                         total_rows=M, p_drop=pd, dropbits=a_["dropbits"], qlim=tq[2] if tq is not None else None)
             fork()
             with torch.cuda.stream(side):
                 ops.colsum(dqkv, 3 * H, M, 3 * H, gbqkv, accumulate=True, unscale=us)
@@ -878,7 +896,11 @@ class Engine:
             if tail:
                 # the residual branch's gradient (dpre1) also lives on the consumed rows only
                 ops.gemm(dqkv, Wqkv, dx, tb=True, M=M, N=H, K=3 * H)
-                ops.scatter_rows(dpre1, H, S["sel"], a_["rows"], H, dx, H, accumulate=True)
+                ops.scatter_rows(dpre1, H, S["sel"] if tq is None else tq[3], a_["rows"], H, dx, H, accumulate=True)
+                if tq is not None:         # back to the row order of the layers below
+                    dxu = self._buf("bw_dx_unperm", (M, H), adt)
+                    ops.scatter_rows(dx, H, tq[0], M, H, dxu, H, accumulate=False)
+                    dx = dxu
             else:
                 ops.gemm(dqkv, Wqkv, dx, tb=True, M=M, N=H, K=3 * H, epi=EPI_RES, r=dpre1)
             dy = dx

@@ -114,6 +114,22 @@ def pack_plan(desc, B, Lq):
     return cu, rowmap, inv
 
 
+def tail_perm(cu, B, Lq, sel, total_rows):
+    """(perm, newpos, qlim, sel_new) of mv_tail_perm: the last layer's row order with the consumed rows `sel` (packed row indices) first."""
+    L.require_cuda(cu, sel)
+    if cu.dtype != torch.int32 or sel.dtype != torch.int32:
+        raise TypeError("tail_perm: int32 tensors")
+    dev = cu.device
+    perm = torch.empty((total_rows,), dtype=torch.int32, device=dev)
+    newpos = torch.empty((total_rows,), dtype=torch.int32, device=dev)
+    qlim = torch.empty((B,), dtype=torch.int32, device=dev)
+    sel_new = torch.empty((sel.numel(),), dtype=torch.int32, device=dev)
+    rc = _lib().mv_tail_perm(L.ptr(cu), B, Lq, L.ptr(sel.contiguous()), int(sel.numel()), L.ptr(perm), L.ptr(newpos), L.ptr(qlim), L.ptr(sel_new),
+                             L.stream_ptr())
+    L.check(rc, "mv_tail_perm")
+    return perm, newpos, qlim, sel_new
+
+
 def dropbits_numel(B, Lq, A):
     """uint32 elements of one layer's attention-dropout keep-bits (mv_attn_dropmask)."""
     return B * A * ((Lq + 31) // 32) * ((Lq + 63) // 64) * 64
@@ -145,21 +161,21 @@ def attn_keep_mask(dropbits, B, Lq, A):
     return out[:, :, :Lq, :Lq]
 
 
-def attn_fwd(qkv, bits, tileinfo, ctx, lse, B, Lq, A, dh, p_drop=0.0, cu=None, total_rows=0, ctx_bf16=None, dropbits=None):
-    """p_drop > 0 needs `dropbits` (attn_dropmask)."""
+def attn_fwd(qkv, bits, tileinfo, ctx, lse, B, Lq, A, dh, p_drop=0.0, cu=None, total_rows=0, ctx_bf16=None, dropbits=None, qlim=None):
+    """p_drop > 0 needs `dropbits` (attn_dropmask).  qlim (int32 [B], optional): only the first qlim[b] rows of a sample are queries."""
     if ctx.dtype != qkv.dtype or (ctx_bf16 is not None and ctx_bf16.dtype != torch.bfloat16):
         raise TypeError("attn_fwd: ctx shares qkv's encoding; the second output is bf16")
     L.require_cuda(dropbits)
     rc = _lib().mv_attn_fwd(L.dt_of(qkv), L.ptr(qkv), L.ptr(bits), L.ptr(tileinfo), L.ptr(ctx), L.ptr(ctx_bf16), L.ptr(lse), B, Lq, A, dh,
-                            float(p_drop), L.ptr(dropbits), L.ptr(cu), int(total_rows), L.stream_ptr())
+                            float(p_drop), L.ptr(dropbits), L.ptr(cu), int(total_rows), L.ptr(qlim), L.stream_ptr())
     L.check(rc, "mv_attn_fwd")
 
 
-def attn_bwd(qkv, ctx, dctx, lse, bits, tileinfo, dqkv, delta, B, Lq, A, dh, p_drop=0.0, cu=None, total_rows=0, dropbits=None):
-    L.require_cuda(dropbits)
+def attn_bwd(qkv, ctx, dctx, lse, bits, tileinfo, dqkv, delta, B, Lq, A, dh, p_drop=0.0, cu=None, total_rows=0, dropbits=None, qlim=None):
+    L.require_cuda(dropbits, qlim)
     rc = _lib().mv_attn_bwd(L.dt_of(qkv), L.ptr(qkv), L.ptr(ctx), L.ptr(dctx), L.ptr(lse), L.ptr(bits), L.ptr(tileinfo),
                             L.ptr(dqkv), L.ptr(delta), B, Lq, A, dh, float(p_drop), L.ptr(dropbits), L.ptr(cu), int(total_rows),
-                            L.stream_ptr())
+                            L.ptr(qlim), L.stream_ptr())
     L.check(rc, "mv_attn_bwd")
 
 

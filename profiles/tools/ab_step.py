@@ -54,6 +54,8 @@ VARIANTS = {
            ("prefetch, 8 waves x 512 blocks", lambda: mv.hip_ops.set_rowops_variant(0)),
            ("prefetch, 16 waves x 256 blocks", lambda: mv.hip_ops.set_rowops_variant(3)),
            ("prefetch, 4 waves x 512 blocks", lambda: mv.hip_ops.set_rowops_variant(2 | (512 << 8)))],
+    "tq": [("last layer's attention: every row a query", lambda: setattr(model.engine, "tail_queries", False)),
+           ("consumed rows only as queries (reordered rows, qlim)", lambda: setattr(model.engine, "tail_queries", True))],
     "tail": [("last layer on all rows", lambda: setattr(step, "tail_rows", False)), ("last layer on consumed rows", lambda: setattr(step, "tail_rows", True))],
 }
 which = sys.argv[1] if len(sys.argv) > 1 else "pack"

@@ -7,7 +7,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from medvill_amd import hip_ops as ops
-from medvill_amd._lib import EPI_BIAS, EPI_BIAS_GELU_D, EPI_MUL, EPI_NONE
+from medvill_amd._lib import EPI_BIAS, EPI_BIAS_GELU_D, EPI_BIAS_RES, EPI_MUL, EPI_NONE
 dev = "cuda"
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 25483
 H, I = 768, 3072
@@ -28,6 +28,7 @@ alpha = torch.tensor([1.0 / 32768], device=dev)
 cpart = torch.empty(2 * ((M + 255) // 256), I, device=dev)
 gb1 = torch.zeros(I, device=dev)
 oH, Wo = torch.empty(M, H, device=dev, dtype=f16), rnd(H, H, sc=0.02)
+W2, bH = rnd(H, I, sc=0.02), torch.randn(H, device=dev)
 CASES = [
     ("NT ffn1 +bias+gelu+gelu'", lambda: ops.gemm(x, W1, oI, M=M, N=I, K=H, bias=b1, epi=EPI_BIAS_GELU_D, c2=oI2), 2.0 * M * I * H),
     ("NT ffn1 +bias", lambda: ops.gemm(x, W1, oI, M=M, N=I, K=H, bias=b1, epi=EPI_BIAS), 2.0 * M * I * H),
@@ -39,6 +40,8 @@ CASES = [
     ("TN dW1  3072x768", lambda: ops.gemm(xi, x, gW1, ta=True, tb=True, M=I, N=H, K=M, lda=I, ldb=H, splitk=0, ws=ws, alpha=alpha), 2.0 * M * I * H),
     ("TN dW2  768x3072", lambda: ops.gemm(x, xi, gW2, ta=True, tb=True, M=H, N=I, K=M, lda=H, ldb=I, splitk=0, ws=ws, alpha=alpha), 2.0 * M * I * H),
     ("TN dWqkv 2304x768", lambda: ops.gemm(x3, x, gWq, ta=True, tb=True, M=3 * H, N=H, K=M, lda=3 * H, ldb=H, splitk=0, ws=ws, alpha=alpha), 2.0 * M * 3 * H * H),
+    ("NT ffn2 +bias+res K=3072 N=768", lambda: ops.gemm(xi, W2, oH, M=M, N=H, K=I, bias=bH, epi=EPI_BIAS_RES, r=x, p_drop=0.1, drop_key=7), 2.0 * M * I * H),
+    ("NT Wo +bias+res K=768 N=768", lambda: ops.gemm(x, Wo, oH, M=M, N=H, K=H, bias=bH, epi=EPI_BIAS_RES, r=x, p_drop=0.1, drop_key=7), 2.0 * M * H * H),
     ("NN dx(qkv) K=2304", lambda: ops.gemm(x3, Wq, oH, tb=True, M=M, N=H, K=3 * H, ldb=H), 2.0 * M * 3 * H * H),
     ("NN dx(ffn1) K=3072", lambda: ops.gemm(xi, W1, oH, tb=True, M=M, N=H, K=I, ldb=H), 2.0 * M * I * H),
     ("NN dx(Wo) K=768", lambda: ops.gemm(x, Wo, oH, tb=True, M=M, N=H, K=H, ldb=H), 2.0 * M * H * H),

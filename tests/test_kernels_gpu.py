@@ -992,3 +992,81 @@ def test_attention_dropout_keep_bits_every_tile_class_and_packed_rows(dt, fam, B
     assert relerr(ctx, rctx) < (4e-3 if dt == torch.float16 else 2e-2)
     (rctx * dctx.double()).sum().backward()
     assert relerr(dq, qd.grad) < (6e-3 if dt == torch.float16 else 2.5e-2)
+
+
+# ------------------------------------------------------------------------------------------ last layer: consumed rows first, query limits
+def test_tail_perm_orders_the_consumed_rows_first():
+    g = torch.Generator().manual_seed(3)
+    B, Lq = 7, 515
+    lens = torch.randint(40, Lq + 1, (B,), generator=g)
+    lens[3] = Lq
+    cu = torch.cat([torch.zeros(1, dtype=torch.int64), lens.cumsum(0)]).to(torch.int32)
+    M = int(cu[-1])
+    sel = []
+    for b in range(B):
+        n = int(lens[b])
+        k = int(torch.randint(1, min(n, 90), (1,), generator=g))
+        sel.append(int(cu[b]) + torch.randperm(n, generator=g)[:k])
+    sel = torch.cat(sel)
+    sel = sel[torch.randperm(sel.numel(), generator=g)].to(torch.int32)          # any order: the heads' order is not the row order
+    perm, newpos, qlim, sel_new = ops.tail_perm(cu.to(DEV), B, Lq, sel.to(DEV), M)
+    perm, newpos, qlim, sel_new = perm.cpu().long(), newpos.cpu().long(), qlim.cpu(), sel_new.cpu().long()
+    assert torch.equal(newpos[perm], torch.arange(M)) and torch.equal(perm[newpos], torch.arange(M))
+    flag = torch.zeros(M, dtype=torch.bool)
+    flag[sel.long()] = True
+    for b in range(B):
+        lo, hi = int(cu[b]), int(cu[b + 1])
+        nq = int(flag[lo:hi].sum())
+        assert int(qlim[b]) == nq
+        old = perm[lo:hi]
+        assert bool((old >= lo).all()) and bool((old < hi).all())
+        assert bool(flag[old[:nq]].all()) and not bool(flag[old[nq:]].any())
+        assert torch.equal(old[:nq], old[:nq].sort().values) and torch.equal(old[nq:], old[nq:].sort().values)
+    assert torch.equal(sel_new, newpos[sel.long()])
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("p", [0.0, 0.1])
+def test_attention_query_limits_equal_the_full_run_on_the_limited_rows(dt, p):
+    """qlim: only the first qlim[b] rows of a sample are queries.  The context of those rows, and dqkv when the other rows' dctx is
+    zero, must be what the unrestricted kernels give (the skipped work contributes exact zeros)."""
+    B, A, N, S, dh = 5, 3, 36, 473, 64
+    Lq, H = N + S + 3, A * dh
+    g = torch.Generator().manual_seed(21)
+    n_ids = torch.randint(2, S + 2, (B,), generator=g)
+    n_ids[0] = S + 1
+    desc = D.MaskDesc.make("full", N, S, n_ids, DEV)
+    bits = torch.zeros((B, Lq, (Lq + 31) // 32), dtype=torch.int32, device=DEV)
+    tinfo = torch.zeros((B, (Lq + 63) // 64, (Lq + 63) // 64), dtype=torch.uint8, device=DEV)
+    ops.mask_build(desc.desc, B, Lq, bits, tinfo)
+    cu, rowmap, inv = ops.pack_plan(desc.desc, B, Lq)
+    M = int(cu[-1])
+    lens = (cu[1:] - cu[:-1]).cpu()
+    qlim = torch.tensor([1, 54, 64, 131, 0], dtype=torch.int32)
+    qlim = torch.minimum(qlim, lens.to(torch.int32))
+    qlim[0] = lens[0]                                      # one sample unrestricted, one with no query at all
+    db = None
+    if p > 0:
+        db = torch.zeros((ops.dropbits_numel(B, Lq, A),), dtype=torch.int32, device=DEV)
+        ops.attn_dropmask(p, 99, B, Lq, A, db, cu=cu)
+    qkv, dctx = rnd((M, 3 * H), dt, 51), rnd((M, H), dt, 52)
+    isq = torch.zeros(M, dtype=torch.bool)
+    for b in range(B):
+        isq[int(cu[b]):int(cu[b]) + int(qlim[b])] = True
+    dctx[~isq.to(DEV)] = 0
+    res = []
+    for ql in (None, qlim.to(DEV)):
+        ctx = torch.full((M, H), 7.0, dtype=dt, device=DEV)
+        lse = torch.zeros((B, A, Lq), dtype=torch.float32, device=DEV)
+        ops.attn_fwd(qkv, bits, tinfo, ctx, lse, B, Lq, A, dh, p_drop=p, cu=cu, total_rows=M, dropbits=db, qlim=ql)
+        dq = torch.full((M, 3 * H), 3.0, dtype=dt, device=DEV)
+        delta = torch.zeros((B, A, Lq), dtype=torch.float32, device=DEV)
+        ops.attn_bwd(qkv, ctx, dctx, lse, bits, tinfo, dq, delta, B, Lq, A, dh, p_drop=p, cu=cu, total_rows=M, dropbits=db, qlim=ql)
+        res.append((ctx, dq))
+    (c0, d0), (c1, d1) = res
+    m = isq.to(DEV)
+    assert torch.equal(c0[m], c1[m])
+    assert bool((c1[~m] == 7.0).all())                     # rows that are keys only: context untouched
+    assert bool(torch.isfinite(d1.float()).all())
+    assert float((d1.float() - d0.float()).abs().max()) <= 1e-6 * float(d0.float().abs().max()) + 0.0
+    assert bool((d1[~m][:, :H] == 0).all())                # their dQ rows are zeros

@@ -272,7 +272,11 @@ def test_dropout_training_step_against_oracle_with_the_same_masks(golden_dir):
         fracs.append(float(keep.float().mean()))
         assert sc == pytest.approx(65536.0 / (65536.0 - 6554.0))        # P(drop) = 6554 / 65536 at every site
     assert all(abs(f - 0.9) < 0.012 for f in fracs), fracs
-    assert len({float(m.sum()) for m in masks.values()}) == len(masks)        # every site / layer draws its own mask
+    names = list(masks)                                                       # every site / layer draws its own mask
+    for i in range(len(names)):
+        for j in range(i + 1, len(names)):
+            a_, b_ = masks[names[i]], masks[names[j]]
+            assert a_.shape != b_.shape or not torch.equal(a_, b_), (names[i], names[j])
     Po = {k: v.clone().requires_grad_(True) for k, v in P.items()}
     mlm, itm = O.forward(Po, cfg, b["cls_tok"], b["input_txt"], b["attn_mask"], b["segment"], b["img_feats"], b["img_pos"],
                          b["sep_tok"], masks=masks)
@@ -426,11 +430,13 @@ def test_half_batches_sum_to_full_batch_gradient(B):
     assert torch.isfinite(g_full).all() and rel < 2e-2
 
 
-@pytest.mark.parametrize("family,B,N,S", [("mixed", 7, 6, 120), ("full", 3, 36, 473), ("s2s", 4, 1, 70)])
-def test_packed_rows_reproduce_the_padded_step(family, B, N, S):
+@pytest.mark.parametrize("family,B,N,S,tq", [("mixed", 7, 6, 120, True), ("full", 3, 36, 473, False), ("full", 3, 36, 473, True), ("s2s", 4, 1, 70, True)])
+def test_packed_rows_reproduce_the_padded_step(family, B, N, S, tq):
     """Padding removal (TrainStep pack_rows): running the encoder on the valid rows only must give the padded run's
     loss statistics and gradients -- valid rows go through identical arithmetic (same MFMA contraction order, same key
-    tiling), only the order of the row-reductions in weight gradients differs (fp32 summation order)."""
+    tiling), only the order of the row-reductions in weight gradients differs (fp32 summation order).  tq: the all-bidirectional
+    batch also runs its LAST layer on reordered rows with the consumed rows as the only queries (Engine.tail_queries): the keys
+    of that layer's softmax are then summed in another order, which shows at the 16-bit rounding level of its outputs."""
     cfg = mv.ModelConfig(hidden=128, heads=2, intermediate=512, layers=2, vocab_size=1024, max_pos=512, dropout=0.0)
     # ragged to the extremes: a single text token, no padding at all, and drawn lengths in between
     lens = [1, S] + [None] * (B - 2)
@@ -443,10 +449,12 @@ def test_packed_rows_reproduce_the_padded_step(family, B, N, S):
         model = mv.CXRBERT(cfg, None, dtype=torch.bfloat16, device=DEV)
         model.reset_parameters(seed=5)
         model.train()
+        model.engine.tail_queries = tq
         ts = mv.TrainStep(model, lr=0.0, pack_rows=pack)
         stats = ts(batch, train=True)
         eng = model.engine
         assert (eng.S["cu"] is not None) == pack
+        assert (eng.S["tq"] is not None) == (pack and tq and family == "full")
         if pack:
             vl = batch["attn_desc"].host_desc()[:, 2]
             assert eng.S["M"] == int(vl.sum()) < B * (N + S + 3) and eng.S["layers"][0]["x"].shape[0] == eng.S["M"]
@@ -457,7 +465,8 @@ def test_packed_rows_reproduce_the_padded_step(family, B, N, S):
     rel = float((g0 - g1).norm() / g0.norm())
     worst = float((g0 - g1).abs().max() / g0.abs().max())
     print(f"packed vs padded gradient: rel L2 {rel:.2e}, max-abs/max {worst:.2e}")
-    assert rel < 1e-4 and worst < 1e-4
+    tol = 5e-4 if (tq and family == "full") else 1e-4
+    assert rel < tol and worst < tol
 
 
 @pytest.mark.parametrize("family,N,S", [("mixed", 36, 473), ("s2s", 100, 665)])
@@ -731,6 +740,16 @@ def _kernel_dropout_masks(eng, B, Lq, H, A, n_layers):
     for (site, l), key in S["drop_keys"].items():
         if site == eng.SITE_ATTN:          # keep-bits tensor of the layer (blocks beyond a sample's packed length: unused garbage)
             keep = ops.attn_keep_mask(S["layers"][l]["dropbits"], B, Lq, A)
+            if l == n_layers - 1 and S.get("tq") is not None:
+                # the last layer ran on reordered rows (consumed rows first): entry (i, j) of the kernel's mask belongs to the logical
+                # positions (perm[i], perm[j]) of the sample
+                perm, cu = S["tq"][0].long(), S["cu"].long()
+                out = keep.clone()
+                for b in range(B):
+                    lo, hi = int(cu[b]), int(cu[b + 1])
+                    pb = perm[lo:hi] - lo
+                    out[b][:, pb[:, None], pb[None, :]] = keep[b][:, :hi - lo, :hi - lo]
+                keep = out
             masks[("attn", l)] = (keep.float() * (65536.0 / (65536.0 - 6554.0))).cpu()
             continue
         name = {eng.SITE_EMB: "emb", eng.SITE_OUT1: ("out1", l), eng.SITE_OUT2: ("out2", l)}[site]
