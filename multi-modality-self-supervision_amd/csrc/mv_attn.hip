@@ -202,7 +202,10 @@ __device__ __forceinline__ size_t dbits_block(const AttnArgs& a, size_t bh, int 
 template <int PL>
 __global__ __launch_bounds__(256) void attn_dropmask_kernel(unsigned k0, unsigned k1, unsigned thr16, int A, int L, int NQB, int NKT,
                                                             const int32_t* __restrict__ cu, unsigned long long* __restrict__ out, size_t nwords) {
-  const size_t w = (size_t)blockIdx.x * 256 + threadIdx.x;
+  // thread blocks of one (sample, head) are spread over the dispatch order (see att_block: its later query blocks are the empty ones)
+  const unsigned nbh = (unsigned)(nwords / ((size_t)NQB * NKT * 32)), per = gridDim.x / nbh;
+  const unsigned lb = (per * nbh == gridDim.x) ? (blockIdx.x % nbh) * per + blockIdx.x / nbh : blockIdx.x;
+  const size_t w = (size_t)lb * 256 + threadIdx.x;
   if (w >= nwords) return;
   const size_t blk = w >> 5;
   const int kt = (int)(blk % NKT), qb = (int)((blk / NKT) % NQB);
