@@ -149,9 +149,10 @@ def _drop_in_user_timings(mv, model, step, cfg, dev, B, N, S, n, out, time, Simp
         tr._run_epoch(host * 2, 0, True)                # warm-up: workspaces, the first batches' every-entry mask checks
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        tr._run_epoch(host * (n + 1), 0, True)
+        reps = 4 * (n + 1)                              # one epoch of 2 * reps steps: its first / last step (pipeline fill, counter read-back) amortised
+        tr._run_epoch(host * reps, 0, True)
         torch.cuda.synchronize()
-        out[f"trainer_hostloader_{fam}_ms_per_step"] = (time.perf_counter() - t0) / (2 * (n + 1)) * 1e3
+        out[f"trainer_hostloader_{fam}_ms_per_step"] = (time.perf_counter() - t0) / (2 * reps) * 1e3
     del tr
     b16 = mv.data.synthetic_batch(cfg.vocab_size, 16, N, S, "full", seed=999, device=dev)
     ce_m, ce_i = torch.nn.CrossEntropyLoss(ignore_index=-100), torch.nn.CrossEntropyLoss()
@@ -280,6 +281,7 @@ def main():
     st = stats.cpu()
     exposed_ms = step.exchange_exposed_ms() if dist_on else 0.0
     packed = model.engine.S.get("cu") is not None
+    tq_on = model.engine.S.get("tq") is not None          # last layer's attention ran with the consumed rows as its only queries
 
     extras = {}
     if not args.no_extras:
@@ -324,6 +326,9 @@ def main():
         if step.tail_rows:
             # the last layer's output projection and FFN run on the consumed rows only (labelled rows + one [CLS] row per sample)
             f_enc -= (rows_mean - (n_lab + 1.0)) * (2.0 * Hh * Hh + 4.0 * Hh * Ii)
+        if tq_on:
+            # ... and its attention scores / context only for those rows as queries (every row stays a key)
+            f_enc -= 4.0 * (float((vls * vls).mean()) - (n_lab + 1.0) * rows_mean) * Hh
         f_exec = 3.0 * (2.0 * N * cfg.img_hidden * Hh + f_enc + 2.0 * Hh * Hh + n_lab * (2.0 * Hh * Hh + 2.0 * Hh * Vv) + 4.0 * Hh)
         executed = value / world * f_exec / 1e12
         # dominant kernel: the FFN-up GEMM with its fused epilogue (largest single launch of the step; its symbol, the 256x256 ring
@@ -357,7 +362,9 @@ def main():
                        "rows": (f"padding removed: encoder on the valid rows only (mean {rows_mean:.1f} of {L} positions per sample; "
                                 "results equal the padded run)") if packed else "padded",
                        "last_layer": "output projection / FFN / LayerNorms of the last layer on the consumed rows only (labelled rows + "
-                                     "[CLS] rows; the other rows' outputs are unused and their gradients exactly zero)" if step.tail_rows else "all rows",
+                                     "[CLS] rows; the other rows' outputs are unused and their gradients exactly zero)"
+                                     + ("; its attention takes those rows as the only queries (rows reordered with them first, per-sample query limits)"
+                                        if tq_on else "") if step.tail_rows else "all rows",
                        "padded_ms_per_step": extras.get("padded_ms_per_step"), "padded_pairs_per_s": pps(extras.get("padded_ms_per_step")),
                        "full_length_ms_per_step": extras.get("full_length_ms_per_step"),
                        "full_length_pairs_per_s": pps(extras.get("full_length_ms_per_step")),
