@@ -164,10 +164,17 @@ struct AttnArgs {
 };
 // ---- precomputed dropout keep-bits -------------------------------------------------------------------------------------------
 typedef unsigned long long u64x8 __attribute__((ext_vector_type(8)));
-// 16 select masks (one 32-key half of a tile) from a wave-uniform address: two scalar loads and their wait in ONE statement --
-// the compiler does not track an asm load, so the destination registers must be complete when the statement ends
+// 16 select masks (one 32-key half of a tile) from a wave-uniform address.  The pointer is made provably uniform (readfirstlane) and
+// read through the constant address space, so hipcc emits two s_load_dwordx16 that IT tracks: it may issue them ahead of the tile's
+// last MFMAs and waits where the first select needs them (round 3 first had both loads and their wait inside one asm statement, i.e.
+// a full scalar-memory round trip in front of every 32-key half: forward -2..5 %, backward unchanged).
 __device__ __forceinline__ void sload_masks16(const void* p, u64x8& m0, u64x8& m1) {
-  asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %2, 0x40\n\ts_waitcnt lgkmcnt(0)" : "=&s"(m0), "=&s"(m1) : "s"(p) : "memory");
+  const unsigned long long v = (unsigned long long)(uintptr_t)p;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  typedef const u64x8 __attribute__((address_space(4))) cmask_t;
+  cmask_t* q = (cmask_t*)(uintptr_t)(((unsigned long long)hi << 32) | lo);
+  m0 = q[0];
+  m1 = q[1];
 }
 // Selects by a 64-lane mask held in an SGPR pair: one VALU instruction (v_cndmask_b32 with an SGPR condition).  hipcc pads no hazard
 // for an asm statement, so the VGPR inputs must never be the direct result of an MFMA (18 wait states) or of a transcendental
@@ -451,6 +458,10 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_mfma_kernel(AttnArgs a) {
     const int cls = !wave_on ? 0 : (((tmk.w_is1 >> cur) & 1) ? 1 : (((tmk.w_nz >> cur) & 1) ? 2 : 0));
     if (wave_on && cls != 0) {
       const int k0 = cur * 64;
+      // (lane index opaque per tile: the fragment offsets are recomputed instead of held in -- and spilled from -- registers; see dkv_tile)
+      int lane_o = lane;
+      asm volatile("" : "+v"(lane_o));
+      const int l31 = lane_o & 31, h = lane_o >> 5;
       f32x16 st[2];
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
@@ -526,7 +537,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_mfma_kernel(AttnArgs a) {
           const bf16x8 pf = pack8t<F16>(st[kk], s2);
 #pragma unroll
           for (int dt = 0; dt < 2; ++dt)
-            o[dt] = mma32<F16>(frag_tr(tV, 32 * dt, 32 * kk + 16 * s2, lane), pf, o[dt]);
+            o[dt] = mma32<F16>(frag_tr(tV, 32 * dt, 32 * kk + 16 * s2, lane_o), pf, o[dt]);
         }
     }
     if (ATT_ISSUE_LATE && iss < nkt) issue();
@@ -725,7 +736,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_mfma_kernel(AttnArgs a) {
 template <bool MASKED, bool DROP, bool F16>
 __device__ __forceinline__ void dkv_tile(const AttnArgs& a, const char* tQ, const char* tD, const float* s_lse, const float* s_dl,
                                          const uint32_t* s_w, const bf16x8 (&kf)[4], const bf16x8 (&vf)[4], f32x16 (&dk)[2],
-                                         f32x16 (&dv)[2], int b, int head, int cur, int key, int wid, float c2, int lane, const uint32_t* s_db) {
+                                         f32x16 (&dv)[2], int b, int head, int cur, int key, int wid, float c2, int lane_in, const uint32_t* s_db) {
+  // The lane index is made opaque per tile: hipcc otherwise hoists every lane-dependent LDS offset of the 48 fragment reads out of the tile
+  // loop (a dozen registers), runs out at the 256-register cap of two waves per SIMD and SPILLS them -- each reload inside a tile body was a
+  // scratch load whose `s_waitcnt vmcnt(0)` also drained the LDS-DMA ring (8-11 per tile; SQ_WAIT_ANY 50 % of the wave cycles).  Recomputing
+  // the offsets costs a few VALU instructions per tile.
+  int lane = lane_in;
+  asm volatile("" : "+v"(lane));
   const int l31 = lane & 31, h = lane >> 5;
   const float dscale = DROP ? a.inv_keep * a.scale : a.scale;
 #pragma unroll
@@ -733,10 +750,20 @@ __device__ __forceinline__ void dkv_tile(const AttnArgs& a, const char* tQ, cons
     f32x16 sc, dp;
 #pragma unroll
     for (int i = 0; i < 16; ++i) { sc[i] = 0.f; dp[i] = 0.f; }
+    {
+      // the Q / dO fragments one step ahead of their MFMAs and no further: hipcc otherwise requests all eight up front (32 registers)
+      // and spills elsewhere -- every reload of a spilled register is a scratch load whose `vmcnt(0)` also drains the LDS-DMA ring
+      bf16x8 qc = frag_row(tQ, 32 * qq, 0, l31, h), dc = frag_row(tD, 32 * qq, 0, l31, h);
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      sc = mma32<F16>(frag_row(tQ, 32 * qq, s, l31, h), kf[s], sc);
-      dp = mma32<F16>(frag_row(tD, 32 * qq, s, l31, h), vf[s], dp);
+      for (int s = 0; s < 4; ++s) {
+        bf16x8 qn = qc, dn = dc;
+        if (s + 1 < 4) { qn = frag_row(tQ, 32 * qq, s + 1, l31, h); dn = frag_row(tD, 32 * qq, s + 1, l31, h); }
+        __builtin_amdgcn_sched_barrier(0);
+        sc = mma32<F16>(qc, kf[s], sc);
+        dp = mma32<F16>(dc, vf[s], dp);
+        __builtin_amdgcn_sched_barrier(0);
+        qc = qn; dc = dn;
+      }
     }
     f32x16& pv = dp;                          // P (dropped-out) overwrites dP element by element
 #pragma unroll
