@@ -205,6 +205,16 @@ __global__ __launch_bounds__(256, SB ? 3 : 2) void gemm_mfma_kernel(GemmArgs p) 
   // bias once per tile, residual rows one 16-row group ahead of the stores (see epilogue4v)
 #define EPI_BODY(E_)                                                                                          \
   {                                                                                                           \
+    constexpr int EE = (E_);                                                                                  \
+    constexpr bool WIDE_E = (E_) == MV_EPI_NONE || (E_) == MV_EPI_BIAS || (E_) == MV_EPI_BIAS_GELU_D;         \
+    constexpr bool WIDE_R = (E_) == MV_EPI_MUL || (E_) == MV_EPI_RES || (E_) == MV_EPI_BIAS_RES;              \
+    constexpr int NJ = 4;                                                                                     \
+    if (!CONV && G2_WIDE_COND(NJ)) {                                                                          \
+      /* 16-bit output, whole 64-column strip: 16-byte stores of whole lines through the wave's LDS scratch (the stage is free: the K     \
+         loop ended with a barrier) instead of 8-byte pieces of 16 different rows per instruction */         \
+      char* scr = smem + wid * 4608;                                                                          \
+      G2_EPI_WIDE(E_, 4)                                                                                      \
+    } else {                                                                                                  \
     f32x4 b4[4], rc[4], rn[4];                                                                                \
     bool fast[4];                                                                                             \
     _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                           \
@@ -229,6 +239,7 @@ __global__ __launch_bounds__(256, SB ? 3 : 2) void gemm_mfma_kernel(GemmArgs p) 
         else epilogue4_slow(p, m, n, acc[i][j]);                                                              \
       }                                                                                                       \
       _Pragma("unroll") for (int j = 0; j < 4; ++j) rc[j] = rn[j];                                            \
+    }                                                                                                         \
     }                                                                                                         \
   }
   MV_EPI_SWITCH(p.epi, EPI_BODY)

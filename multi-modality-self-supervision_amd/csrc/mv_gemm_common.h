@@ -179,7 +179,13 @@ __device__ __forceinline__ void epilogue8_16(const GemmArgs& p, const OutRsrc& r
   if (m >= p.M) return;
   if (p.dbg & 16) m &= 255;       // experiment: every tile stores into the same 256 rows (they stay in L2): what the epilogue costs without HBM writes
   float o[8] = {v0[0] + b0[0], v0[1] + b0[1], v0[2] + b0[2], v0[3] + b0[3], v1[0] + b1[0], v1[1] + b1[1], v1[2] + b1[2], v1[3] + b1[3]};
-  if (E == MV_EPI_MUL || E == MV_EPI_RES) {
+  if (E == MV_EPI_BIAS_RES && p.drop.thr) {      // hidden-state dropout of the projection output, before the residual is added
+    const size_t li = (size_t)m * p.N + n;
+    const f32x4 d0 = mv_drop4((f32x4){o[0], o[1], o[2], o[3]}, li, p.drop), d1 = mv_drop4((f32x4){o[4], o[5], o[6], o[7]}, li + 4, p.drop);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { o[e] = d0[e]; o[4 + e] = d1[e]; }
+  }
+  if (E == MV_EPI_MUL || E == MV_EPI_RES || E == MV_EPI_BIAS_RES) {
     float r[8];
     dec8_16(rraw, p.r_dtype, r);
 #pragma unroll
@@ -318,19 +324,18 @@ __device__ __forceinline__ bf16x8 g2_frag(const char* tile, int base, int l15, i
 // through its own 4.25-KiB scratch (272-B row pitch: conflict-free both ways) so that 16 lanes cover one full output
 // row: whole 128/256-byte lines per store.  Loads run one row-group ahead of the stores (see epilogue4v).
 // Expects in scope: p, acc, scr, split, m0, n0, wm, wn, l15, lq, rrow, c4, col_on, NJ.
-#define G2_RG 4
-#define G2_EPI_BODY(E_)                                                                                        \
-  {                                                                                                            \
-    constexpr int EE = (E_) < 0 ? 0 : (E_);                                                                    \
-    constexpr bool HAS_R = (E_) == MV_EPI_BIAS_RES || (E_) == MV_EPI_RES || (E_) == MV_EPI_MUL || (E_) == MV_EPI_DGELU || (E_) == MV_EPI_BIAS_RES_RELU; \
-    constexpr bool WIDE_E = (E_) == MV_EPI_NONE || (E_) == MV_EPI_BIAS || (E_) == MV_EPI_BIAS_GELU_D;          \
-    constexpr bool WIDE_R = (E_) == MV_EPI_MUL || (E_) == MV_EPI_RES;      /* 16-bit elementwise operand, 16-byte loads */ \
-    if ((WIDE_E || (WIDE_R && p.r8_ok)) && NJ == 4 && p.vec8_ok && p.c_dtype != MV_F32 && !p.accumulate && n0 + wn + 64 <= p.N) { \
+// 16-bit outputs, a wave's 64 whole columns: the accumulators of one 16-row group go through the wave's LDS scratch (272-B row pitch) so that
+// a lane owns 8 consecutive columns of a row (8 lanes per row, 8 rows per pass): 16-byte stores, whole 128-byte lines per row.  NI_ = number
+// of 16-row groups per wave (8 in the 256-row kernels, 4 in the 128x128 kernel).  Expects in scope: p, acc[NI_][4], scr, m0, n0, wm, wn, l15,
+// lq, lane, WIDE_E / WIDE_R (constexpr), EE.
+#define G2_WIDE_COND(NJ_) ((WIDE_E || (WIDE_R && p.r8_ok)) && (NJ_) == 4 && p.vec8_ok && p.c_dtype != MV_F32 && !p.accumulate && n0 + wn + 64 <= p.N)
+#define G2_EPI_WIDE(E_, NI_)                                                                                   \
+    {                                                                                                          \
       /* 16-bit outputs, 64 whole columns: a lane owns 8 consecutive columns of a row (8 lanes per row, 8 rows per pass) */ \
       const int r8 = lane >> 3, c8 = lane & 7;                                                                 \
       const int ncol8 = n0 + wn + c8 * 8;                                                                      \
       f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;                                                                \
-      if (WIDE_E && (E_) != MV_EPI_NONE) { b0 = *(const f32x4*)(p.bias + ncol8); b1 = *(const f32x4*)(p.bias + ncol8 + 4); } \
+      if ((WIDE_E && (E_) != MV_EPI_NONE) || (E_) == MV_EPI_BIAS_RES) { b0 = *(const f32x4*)(p.bias + ncol8); b1 = *(const f32x4*)(p.bias + ncol8 + 4); } \
       /* the elementwise operand's rows are requested two 16-row groups ahead of their use (4 x 16 bytes per lane in flight) */ \
       u32x4 rq[2][2];                                                                                          \
       float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};                                                  \
@@ -343,7 +348,7 @@ __device__ __forceinline__ bf16x8 g2_frag(const char* tile, int base, int l15, i
         _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                          \
           _Pragma("unroll") for (int rr = 0; rr < 2; ++rr) rq[t][rr] = ld8_raw(p, m0 + wm + t * 16 + rr * 8 + r8, ncol8); \
       }                                                                                                        \
-      _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                          \
+      _Pragma("unroll") for (int i = 0; i < (NI_); ++i) {                                                          \
         _Pragma("unroll") for (int j = 0; j < NJ; ++j) *(f32x4*)(scr + l15 * 272 + j * 64 + lq * 16) = acc[i][j]; \
         _Pragma("unroll") for (int rr = 0; rr < 2; ++rr) {                                                     \
           const int row = rr * 8 + r8;                                                                         \
@@ -351,7 +356,7 @@ __device__ __forceinline__ bf16x8 g2_frag(const char* tile, int base, int l15, i
           const f32x4 v1 = *(const f32x4*)(scr + row * 272 + c8 * 32 + 16);                                    \
           if (WIDE_R) {                                                                                        \
             const u32x4 rcur = rq[i & 1][rr];                                                                  \
-            if (i + 2 < 8) rq[i & 1][rr] = ld8_raw(p, m0 + wm + (i + 2) * 16 + row, ncol8);                    \
+            if (i + 2 < (NI_)) rq[i & 1][rr] = ld8_raw(p, m0 + wm + (i + 2) * 16 + row, ncol8);                    \
             epilogue8_16<EE>(p, ors, m0 + wm + i * 16 + row, ncol8, v0, v1, b0, b1, cs, do_cs, rcur);          \
           } else {                                                                                             \
             epilogue8_16<EE>(p, ors, m0 + wm + i * 16 + row, ncol8, v0, v1, b0, b1, cs, do_cs);                \
@@ -370,7 +375,16 @@ __device__ __forceinline__ bf16x8 g2_frag(const char* tile, int base, int l15, i
           *(f32x4*)(cp + 4) = (f32x4){cs[4], cs[5], cs[6], cs[7]};                                             \
         }                                                                                                      \
       }                                                                                                        \
-    } else {                                                                                                   \
+    }
+#define G2_RG 4
+#define G2_EPI_BODY(E_)                                                                                        \
+  {                                                                                                            \
+    constexpr int EE = (E_) < 0 ? 0 : (E_);                                                                    \
+    constexpr bool HAS_R = (E_) == MV_EPI_BIAS_RES || (E_) == MV_EPI_RES || (E_) == MV_EPI_MUL || (E_) == MV_EPI_DGELU || (E_) == MV_EPI_BIAS_RES_RELU; \
+    constexpr bool WIDE_E = (E_) == MV_EPI_NONE || (E_) == MV_EPI_BIAS || (E_) == MV_EPI_BIAS_GELU_D;          \
+    constexpr bool WIDE_R = (E_) == MV_EPI_MUL || (E_) == MV_EPI_RES || (E_) == MV_EPI_BIAS_RES;      /* 16-bit elementwise operand, 16-byte loads */ \
+    if (G2_WIDE_COND(NJ)) G2_EPI_WIDE(E_, 8)                                                                  \
+    else {                                                                                                     \
     const int ncol = n0 + wn + c4 * 4;                                                                         \
     const bool lane_fast = ((E_) >= 0) && col_on && p.vec_ok && (p.N - ncol >= 4);                             \
     f32x4 b4 = {0.f, 0.f, 0.f, 0.f};                                                                           \
