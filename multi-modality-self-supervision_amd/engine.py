@@ -112,6 +112,20 @@ ALIASES = {  # reference state-dict aliases -> canonical tensor (cxrbert_origin.
 }
 
 
+# The engine's extra HIP streams are shared by every Engine of the process (engines never run concurrently).  HIP hands streams to a
+# fixed number of hardware queues round-robin in creation order; a second model's streams could land on the queue of the first one's main
+# stream and serialise its backward (measured in bench.py: the second model of a process ran L = 768 steps at 40.7 ms instead of 35.8).
+_SHARED_STREAMS = {}
+
+
+def _shared_stream(device, kind):
+    key = (str(device), kind)
+    st = _SHARED_STREAMS.get(key)
+    if st is None:
+        st = _SHARED_STREAMS[key] = torch.cuda.Stream(device=device)
+    return st
+
+
 class Engine:
     """dtype = torch.float32: the exact path (VALU kernels).  dtype = torch.bfloat16: the 16-bit MFMA path -- fp32 master
     weights, accumulation, LayerNorm / softmax statistics, losses and optimizer; every MFMA operand is 16 bits wide.
@@ -276,7 +290,7 @@ class Engine:
             self._w2t = [torch.empty((I, H), dtype=self.adt, device=self.device) for _ in range(cfg.layers)]
         main = torch.cuda.current_stream()
         if self._side is None:
-            self._side = torch.cuda.Stream(device=self.device)
+            self._side = _shared_stream(self.device, "side")
         side = self._side if (on_side and os.environ.get("MV_SINGLE_STREAM") != "1") else main
         side.wait_stream(main)
         with torch.cuda.stream(side):
@@ -292,7 +306,7 @@ class Engine:
         if os.environ.get("MV_SINGLE_STREAM") == "1":
             return torch.cuda.current_stream()
         if self._side is None:
-            self._side = torch.cuda.Stream(device=self.device)
+            self._side = _shared_stream(self.device, "side")
         return self._side
 
     def zero_grad(self):
@@ -497,7 +511,7 @@ class Engine:
             # kernels select with.  It depends on the keys (and the packed lengths) only: all layers' bits are generated now, on
             # their own stream, under the embedding / first projection kernels
             if self._mask_stream is None:
-                self._mask_stream = torch.cuda.Stream(device=dev)
+                self._mask_stream = _shared_stream(dev, "mask")
             ms, main_ = self._mask_stream, torch.cuda.current_stream()
             ms.wait_stream(main_)                     # the previous step's backward has read the buffers; `cu` is ready
             db_ev = []
@@ -635,7 +649,7 @@ class Engine:
         # workspace: it runs on the side stream, which is idle until the encoder's backward starts; embed_bwd waits for it.
         main = torch.cuda.current_stream()
         if self._side is None:
-            self._side = torch.cuda.Stream(device=self.device)
+            self._side = _shared_stream(self.device, "side")
         side = self._side if (self.head_on_side and os.environ.get("MV_SINGLE_STREAM") != "1") else main
         side.wait_stream(main)
         with torch.cuda.stream(side):
@@ -797,7 +811,7 @@ class Engine:
         dy = S["dhidden"]
         main = torch.cuda.current_stream()
         if self._side is None:
-            self._side = torch.cuda.Stream(device=self.device)
+            self._side = _shared_stream(self.device, "side")
         side = main if os.environ.get("MV_SINGLE_STREAM") == "1" else self._side     # measurement switch
         side.wait_stream(main)              # the heads' gradients and the zeroed flat gradient are ordered before us
 
