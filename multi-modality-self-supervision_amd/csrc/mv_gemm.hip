@@ -375,7 +375,9 @@ extern "C" int mv_gemm(int dtype, int ta, int tb, int M, int N, int K, const voi
   p.r8_ok = need_r && mv_is16(r_dtype) && ((ldr & 7) == 0) && aligned_to(R, 16);
   p.vec8_ok = mv_is16(c_dtype) && ((ldc & 7) == 0) && aligned_to(C, 16) && (!need_bias || aligned_to(bias, 16)) &&
               (!C3 || (((ldc3 & 7) == 0) && aligned_to(C3, 16))) &&
-              ((epi != MV_EPI_BIAS_GELU && epi != MV_EPI_BIAS_GELU_D) || (((ldc2 & 7) == 0) && aligned_to(C2, 16))) && ((N & 3) == 0);
+              ((epi != MV_EPI_BIAS_GELU && epi != MV_EPI_BIAS_GELU_D) || (((ldc2 & 7) == 0) && aligned_to(C2, 16)));
+  // (N itself need not be a multiple of anything: the 16-byte path covers whole 64-column strips only, the ragged last strip of e.g. the
+  //  30,522-column decoder takes the per-lane path)
   {   // the 16-byte-store epilogue addresses its outputs through buffer descriptors: sizes below 2 GiB, else the 8-byte path
     const size_t bC = (size_t)M * ldc * 2, bC2 = C2 ? (size_t)M * ldc2 * 2 : 0, bC3 = C3 ? (size_t)M * ldc3 * 2 : 0;
     if (bC >= 0x7fffffffULL || bC2 >= 0x7fffffffULL || bC3 >= 0x7fffffffULL) p.vec8_ok = 0;

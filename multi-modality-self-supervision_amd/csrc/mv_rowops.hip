@@ -719,6 +719,8 @@ extern "C" int mv_ce_fwd_bwd(const void* logits, int l_dtype, int ld, const int3
     else if (l_dtype == MV_F32 && d_dtype == MV_BF16) CEV_LAUNCH(float, bf16_t);
     else if (l_dtype == MV_BF16 && d_dtype == MV_BF16) CEV_LAUNCH(bf16_t, bf16_t);
     else if (l_dtype == MV_BF16 && d_dtype == MV_F32) CEV_LAUNCH(bf16_t, float);
+    else if (l_dtype == MV_F16 && d_dtype == MV_F16) CEV_LAUNCH(f16_t, f16_t);
+    else if (l_dtype == MV_F16 && d_dtype == MV_F32) CEV_LAUNCH(f16_t, float);
     else return MV_E_DTYPE;
 #undef CEV_LAUNCH
     MV_CHECK_LAUNCH();
@@ -734,6 +736,8 @@ extern "C" int mv_ce_fwd_bwd(const void* logits, int l_dtype, int ld, const int3
   else if (l_dtype == MV_F32 && d_dtype == MV_BF16) CE_LAUNCH(float, bf16_t);
   else if (l_dtype == MV_BF16 && d_dtype == MV_BF16) CE_LAUNCH(bf16_t, bf16_t);
   else if (l_dtype == MV_BF16 && d_dtype == MV_F32) CE_LAUNCH(bf16_t, float);
+  else if (l_dtype == MV_F16 && d_dtype == MV_F16) CE_LAUNCH(f16_t, f16_t);
+  else if (l_dtype == MV_F16 && d_dtype == MV_F32) CE_LAUNCH(f16_t, float);
   else return MV_E_DTYPE;
 #undef CE_LAUNCH
   MV_CHECK_LAUNCH();

@@ -195,6 +195,7 @@ class Engine:
         self._w2t, self._w2t_ev, self._w2t_stale = None, None, True
         self.head_on_side = True  # the tied decoder's weight gradient on the side stream (see _mlm_backward)
         self.fused_colsum = os.environ.get("MV_FUSED_COLSUM", "1") != "0"   # bias gradients from partial sums of the producing kernels
+        self.logits_16 = os.environ.get("MV_LOGITS_F32", "0") != "1"      # fused step, 16-bit path: MLM logits in the forward encoding (see _mlm_forward)
         self.tail_queries = os.environ.get("MV_TAIL_QUERIES", "1") != "0"    # last layer's attention: consumed rows only as queries (see encoder_forward)
         self._mask_stream = None      # third stream: the attention-dropout keep-bits of every layer are generated at the start of a forward
         self._dE_ev = None
@@ -615,9 +616,11 @@ class Engine:
         ops.gemm(S["pooled_f"], self.wf["itm.linear.weight"], itm, M=S["B"], N=2, K=H, bias=self.p["itm.linear.bias"], epi=EPI_BIAS)
         return itm
 
-    def _mlm_forward(self, xr, xr_b, R, tag, pad=True):
+    def _mlm_forward(self, xr, xr_b, R, tag, pad=True, logits16=False):
         """xr [R,H] (forward encoding; xr_b = its gradient-product copy) -> logits [R, Vp] f32 (Vp = V rounded up to 8
-        when `pad`; pad columns unspecified)."""
+        when `pad`; pad columns unspecified).  logits16 (fused training step, 16-bit path): the logits in the forward encoding -- they
+        only feed the fused cross-entropy, which computes in f32 from them (what autocast-style mixed precision does); halves the
+        decoder's output traffic and the loss kernel's input."""
         cfg, H, V = self.cfg, self.cfg.hidden, self.cfg.vocab_size
         f32 = torch.float32
         Vp = (V + 7) // 8 * 8 if pad else V
@@ -633,7 +636,7 @@ class Engine:
         ops.layernorm_fwd(tact, self.p["mlm.predictions.transform.LayerNorm.weight"],
                           self.p["mlm.predictions.transform.LayerNorm.bias"], t, hs["mean"], hs["rstd"], R, H, cfg.head_ln_eps,
                           y_bf16=t_b if self.dual else None)
-        logits = hs["logits"] = torch.empty((R, Vp), dtype=f32, device=self.device)
+        logits = hs["logits"] = torch.empty((R, Vp), dtype=self.fadt if (logits16 and self.is16 and not self.dual) else f32, device=self.device)
         ops.gemm(t, self.wf["enc.txt_embeddings.word_embeddings.weight"], logits, M=R, N=V, K=H, ldc=Vp,
                  bias=self.p["mlm.predictions.bias"], epi=EPI_BIAS)
         return logits
@@ -772,7 +775,7 @@ class Engine:
                 ops.gather_rows(S["hidden_f"], H, label_rows, R, H, xr, H)
                 if self.dual:
                     ops.gather_rows(S["hidden"], H, label_rows, R, H, xr_b, H)
-            logits = self._mlm_forward(xr, xr_b, R, "ht_")
+            logits = self._mlm_forward(xr, xr_b, R, "ht_", logits16=self.logits_16)
             Vp = logits.shape[1]
             dl = torch.empty((R, Vp), dtype=self.adt, device=self.device) if compute_grad else None
             ops.ce_fwd_bwd(logits, Vp, label_ids, R, V, stats[0:3], dl, Vp, grad_scale_dev=mlm_scale_dev,

@@ -7,3 +7,4 @@ f=$(find /tmp/prof_tr -name "*kernel_trace.csv" | head -1)
 python3 $R/profiles/tools/trace_steps.py $f --small --gaps
 g=$(find /tmp/prof_tr -name "*kernel_stats.csv" | head -1)
 mkdir -p $R/gpurun_out/tr && cp $g $R/gpurun_out/tr/kernel_stats.csv
+cp $f $R/gpurun_out/tr/kernel_trace.csv
