@@ -195,7 +195,10 @@ class Engine:
         self._w2t, self._w2t_ev, self._w2t_stale = None, None, True
         self.head_on_side = True  # the tied decoder's weight gradient on the side stream (see _mlm_backward)
         self.fused_colsum = os.environ.get("MV_FUSED_COLSUM", "1") != "0"   # bias gradients from partial sums of the producing kernels
-        self.logits_16 = os.environ.get("MV_LOGITS_F32", "0") != "1"      # fused step, 16-bit path: MLM logits in the forward encoding (see _mlm_forward)
+        self.itm_on_side = True       # ITM head on the side stream under the MLM head's decoder GEMM (heads_train)
+        # fused step, 16-bit path: MLM logits in the forward encoding (see _mlm_forward).  Off: the in-process A/B showed no gain
+        # (24.60 vs 24.58 ms, profiles/r03_notes.txt), so the logits stay f32
+        self.logits_16 = os.environ.get("MV_LOGITS_16", "0") == "1"
         self.tail_queries = os.environ.get("MV_TAIL_QUERIES", "1") != "0"    # last layer's attention: consumed rows only as queries (see encoder_forward)
         self._mask_stream = None      # third stream: the attention-dropout keep-bits of every layer are generated at the start of a forward
         self._dE_ev = None
@@ -767,6 +770,20 @@ class Engine:
             else:
                 dhid = S["dhidden"] = self._buf("dhidden", (M, H), self.adt)
                 dhid.zero_()
+        # The ITM head (pooler -> 2-way classifier, its loss and backward: a dozen latency-bound launches on [B, H] matrices, ~100 us in a
+        # row) runs on the side stream, which is idle until the encoder's backward, under the MLM head's decoder GEMM on the main stream.
+        # The two heads touch disjoint rows of dhidden, disjoint statistics and disjoint parameter gradients.
+        main = torch.cuda.current_stream() if self.device.type == "cuda" else None
+        side = main
+        if main is not None and self.itm_on_side and os.environ.get("MV_SINGLE_STREAM") != "1":
+            if self._side is None:
+                self._side = _shared_stream(self.device, "side")
+            side = self._side
+        if side is not main:
+            side.wait_stream(main)
+            stats.record_stream(side)
+            with torch.cuda.stream(side):
+                self._itm_head(stats, is_aligned, B, itm_scale, itm_scale_dev, compute_grad)
         if R > 0:
             if compact:
                 xr, xr_b = S["hidden_f"][:R], S["hidden"][:R]
@@ -786,13 +803,19 @@ class Engine:
                     dhid[:R].copy_(dxr)
                 else:
                     ops.scatter_rows(dxr, H, label_rows, R, H, dhid, H, accumulate=False)
+        if side is main:
+            self._itm_head(stats, is_aligned, B, itm_scale, itm_scale_dev, compute_grad)
+        else:
+            main.wait_stream(side)
+        return stats
+
+    def _itm_head(self, stats, is_aligned, B, itm_scale, itm_scale_dev, compute_grad):
         itm = self._itm_forward()
         d8 = self._buf("ditm8", (B, 8), self.adt) if compute_grad else None
         ops.ce_fwd_bwd(itm, 2, is_aligned, B, 2, stats[3:6], d8, 8, grad_scale_dev=itm_scale_dev,
                        grad_scale=(itm_scale if itm_scale is not None else 1.0 / B), loss_scale_dev=self.loss_scale_dev)
         if compute_grad:
             self._itm_backward(d8)
-        return stats
 
     # ------------------------------------------------------------------ encoder backward
     def encoder_backward(self, bucket_hook=None):

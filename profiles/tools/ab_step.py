@@ -54,6 +54,10 @@ VARIANTS = {
            ("prefetch, 8 waves x 512 blocks", lambda: mv.hip_ops.set_rowops_variant(0)),
            ("prefetch, 16 waves x 256 blocks", lambda: mv.hip_ops.set_rowops_variant(3)),
            ("prefetch, 4 waves x 512 blocks", lambda: mv.hip_ops.set_rowops_variant(2 | (512 << 8)))],
+    "itm": [("ITM head after the MLM head on the main stream", lambda: setattr(model.engine, "itm_on_side", False)),
+            ("ITM head on the side stream under the decoder GEMM", lambda: setattr(model.engine, "itm_on_side", True))],
+    "logits": [("MLM logits f32", lambda: setattr(model.engine, "logits_16", False)),
+               ("MLM logits in the forward encoding (f16)", lambda: setattr(model.engine, "logits_16", True))],
     "tq": [("last layer's attention: every row a query", lambda: setattr(model.engine, "tail_queries", False)),
            ("consumed rows only as queries (reordered rows, qlim)", lambda: setattr(model.engine, "tail_queries", True))],
     "tail": [("last layer on all rows", lambda: setattr(step, "tail_rows", False)), ("last layer on consumed rows", lambda: setattr(step, "tail_rows", True))],
