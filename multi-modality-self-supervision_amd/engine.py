@@ -195,6 +195,7 @@ class Engine:
         self._w2t, self._w2t_ev, self._w2t_stale = None, None, True
         self.head_on_side = True  # the tied decoder's weight gradient on the side stream (see _mlm_backward)
         self.fused_colsum = os.environ.get("MV_FUSED_COLSUM", "1") != "0"   # bias gradients from partial sums of the producing kernels
+        self.late_opt_wait = True     # the forward's preparation kernels run under the optimizer's first kernel (encoder_forward)
         self.itm_on_side = True       # ITM head on the side stream under the MLM head's decoder GEMM (heads_train)
         # fused step, 16-bit path: MLM logits in the forward encoding (see _mlm_forward).  Off: the in-process A/B showed no gain
         # (24.60 vs 24.58 ms, profiles/r03_notes.txt), so the logits stay f32
@@ -427,7 +428,8 @@ class Engine:
             raise ValueError(f"attn_mask shape {tuple(attn_mask.shape)} does not match L = N+T+2 = {Lq}")
         if self.shadow_dirty:
             self.sync_shadow()
-        self._wait_opt("embeddings")
+        if not self.late_opt_wait:
+            self._wait_opt("embeddings")
         f32 = torch.float32
         S = self.S = dict(B=B, T=T, N=N, L=Lq, M=M, cu=None, rowmap=None, inv=None, sel=None, n_lab=0, tq=None)
         if pack:
@@ -497,18 +499,6 @@ class Engine:
         # 16-bit path) and the copy the backward's gradient products read (bf16); they are the same buffer when the
         # encodings coincide.  The saved-for-backward dictionaries keep the `_b` one.
         xb2 = lambda f, b_: b_ if dual else None          # extra output of the producing kernel
-        imgproj = self._buf("imgproj", (B * N, H), fadt)
-        ops.gemm(feats_f, wf["enc.img_embeddings.img_embeddings.weight"], imgproj, M=B * N, N=H, K=D,
-                 bias=self.p["enc.img_embeddings.img_embeddings.bias"], epi=EPI_BIAS)
-        x, x_b = self._pair("x0", (M, H))
-        pre0 = self._buf("pre0", (M, H), f32)
-        mean0, rstd0 = self._buf("mean0", (M,), f32), self._buf("rstd0", (M,), f32)
-        ops.embed_fwd(self.fdt, S["cls_tok"], S["txt"], S["segment"], S["img_pos"], S["sep_tok"], imgproj,
-                      wf[e + "word_embeddings.weight"], wf[e + "position_embeddings.weight"],
-                      wf[e + "token_type_embeddings.weight"], self.p[e + "LayerNorm.weight"], self.p[e + "LayerNorm.bias"],
-                      x, pre0, mean0, rstd0, B, N, T, H, cfg.vocab_size, cfg.max_pos, cfg.ln_eps, p_drop=pd,
-                      drop_key=dk[(self.SITE_EMB, 0)], rowmap=rowmap, n_rows=M, x0_bf16=xb2(x, x_b))
-        S["layers"] = []
         db_ev = None
         if pd > 0:
             # attention-probability dropout: the mask is a tensor of keep-bits (mv_attn_dropmask) that the forward and both backward
@@ -526,6 +516,21 @@ class Engine:
                     ev = torch.cuda.Event()
                     ev.record(ms)
                     db_ev.append((dbl, ev))
+        imgproj = self._buf("imgproj", (B * N, H), fadt)
+        # first reader of the embeddings parameter range: everything above (row plan, mask words, keep-bits of every layer) did not need
+        # the optimizer's first kernel (113 us over the word table) and ran under it
+        self._wait_opt("embeddings")
+        ops.gemm(feats_f, wf["enc.img_embeddings.img_embeddings.weight"], imgproj, M=B * N, N=H, K=D,
+                 bias=self.p["enc.img_embeddings.img_embeddings.bias"], epi=EPI_BIAS)
+        x, x_b = self._pair("x0", (M, H))
+        pre0 = self._buf("pre0", (M, H), f32)
+        mean0, rstd0 = self._buf("mean0", (M,), f32), self._buf("rstd0", (M,), f32)
+        ops.embed_fwd(self.fdt, S["cls_tok"], S["txt"], S["segment"], S["img_pos"], S["sep_tok"], imgproj,
+                      wf[e + "word_embeddings.weight"], wf[e + "position_embeddings.weight"],
+                      wf[e + "token_type_embeddings.weight"], self.p[e + "LayerNorm.weight"], self.p[e + "LayerNorm.bias"],
+                      x, pre0, mean0, rstd0, B, N, T, H, cfg.vocab_size, cfg.max_pos, cfg.ln_eps, p_drop=pd,
+                      drop_key=dk[(self.SITE_EMB, 0)], rowmap=rowmap, n_rows=M, x0_bf16=xb2(x, x_b))
+        S["layers"] = []
         for l in range(cfg.layers):
             self._wait_opt(f"layer{l}")
             p = f"enc.encoder.layer.{l}."

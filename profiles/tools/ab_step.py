@@ -13,7 +13,7 @@ cfg = mv.ModelConfig()
 torch.manual_seed(1234)
 model = mv.CXRBERT(cfg, None, dtype=torch.bfloat16, device=dev)
 model.train()
-step = mv.TrainStep(model, lr=1e-5)
+step = mv.TrainStep(model, lr=1e-5, overlap_optimizer=True)      # as bench.py and CXRBERT_Trainer build it
 B, N, S = 64, 36, 473
 batches = [mv.data.synthetic_batch(cfg.vocab_size, B, N, S, "full", seed=1234 + 1000 * i, device=dev) for i in range(4)]
 
@@ -54,6 +54,8 @@ VARIANTS = {
            ("prefetch, 8 waves x 512 blocks", lambda: mv.hip_ops.set_rowops_variant(0)),
            ("prefetch, 16 waves x 256 blocks", lambda: mv.hip_ops.set_rowops_variant(3)),
            ("prefetch, 4 waves x 512 blocks", lambda: mv.hip_ops.set_rowops_variant(2 | (512 << 8)))],
+    "optwait": [("forward waits for the optimizer's first kernel before its preparation kernels", lambda: setattr(model.engine, "late_opt_wait", False)),
+                ("... right before the first reader of the embeddings range", lambda: setattr(model.engine, "late_opt_wait", True))],
     "itm": [("ITM head after the MLM head on the main stream", lambda: setattr(model.engine, "itm_on_side", False)),
             ("ITM head on the side stream under the decoder GEMM", lambda: setattr(model.engine, "itm_on_side", True))],
     "logits": [("MLM logits f32", lambda: setattr(model.engine, "logits_16", False)),
