@@ -40,7 +40,8 @@ class TrainStep:
         self.dp = None
         self.time_exchange = False
         if distributed:
-            self.dp = GradAllReducer(self.eng.flat_g, self.eng.layout, self.eng.n_flat, self.eng.cfg.layers, group=group)
+            self.dp = GradAllReducer(self.eng.flat_g, self.eng.layout, self.eng.n_flat, self.eng.cfg.layers, group=group,
+                                     stream=self.eng.side_stream() if self.eng.device.type == "cuda" else None)
             self.dp.check_replicas(self.eng.flat_p)
             # every rank draws its own dropout masks (the same key would repeat rank 0's masks on every shard)
             self.eng.drop_seed = (self.eng.drop_seed + 0x9E3779B97F4A7C15 * (self.dp.rank + 1)) & 0xFFFFFFFFFFFFFFFF

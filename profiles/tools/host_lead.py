@@ -8,11 +8,17 @@ import torch
 import medvill_amd as mv
 
 dev = torch.device("cuda", 0)
+dist_on = os.environ.get("MV_DP_FORCE") == "1"           # one-rank RCCL group, every collective issued (MV_DP_FORCE=1 python host_lead.py)
+if dist_on:
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29544")
+    os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+    torch.cuda.set_device(0)
+    torch.distributed.init_process_group("nccl", device_id=dev)
 cfg = mv.ModelConfig()
 torch.manual_seed(1234)
 model = mv.CXRBERT(cfg, None, dtype=torch.bfloat16, device=dev)
 model.train()
-step = mv.TrainStep(model, lr=1e-5, overlap_optimizer=True)
+step = mv.TrainStep(model, lr=1e-5, overlap_optimizer=True, distributed=dist_on)
 B, N, S = 64, 36, 473
 batches = [mv.data.synthetic_batch(cfg.vocab_size, B, N, S, "full", seed=1234 + 1000 * i, device=dev) for i in range(4)]
 for i in range(4):

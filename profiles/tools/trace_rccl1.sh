@@ -7,5 +7,6 @@ rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_rc -- python3 
 g=$(find /tmp/prof_rc -name "*kernel_stats.csv" | head -1)
 python3 $R/profiles/tools/kernel_stats_summary.py $g 14
 f=$(find /tmp/prof_rc -name "*kernel_trace.csv" | head -1)
-python3 $R/profiles/tools/trace_steps.py $f | head -12
+python3 $R/profiles/tools/trace_steps.py $f > /tmp/prof_rc_steps.txt 2>&1; head -14 /tmp/prof_rc_steps.txt
 grep -o '"ms_per_step": [0-9.]*' /tmp/prof_rc.log
+mkdir -p $R/gpurun_out/tr_rccl && cp $f $R/gpurun_out/tr_rccl/kernel_trace.csv
