@@ -195,6 +195,7 @@ class Engine:
         self._w2t, self._w2t_ev, self._w2t_stale = None, None, True
         self.head_on_side = True  # the tied decoder's weight gradient on the side stream (see _mlm_backward)
         self.fused_colsum = os.environ.get("MV_FUSED_COLSUM", "1") != "0"   # bias gradients from partial sums of the producing kernels
+        self.head_params_on_side = True   # MLM head: decoder-bias column sums and the transform's parameter gradients on the side stream
         self.late_opt_wait = True     # the forward's preparation kernels run under the optimizer's first kernel (encoder_forward)
         self.itm_on_side = True       # ITM head on the side stream under the MLM head's decoder GEMM (heads_train)
         # fused step, 16-bit path: MLM logits in the forward encoding (see _mlm_forward).  Off: the in-process A/B showed no gain
@@ -655,15 +656,19 @@ class Engine:
         hs = self.S[tag]
         R, Vp = hs["R"], hs["Vp"]
         g, us = self.g, self.unscale_dev
-        ops.colsum(dlogits, Vp, R, V, g["mlm.predictions.bias"], accumulate=True, unscale=us)
         # tied decoder: dE = dlogits^T . t  (the embedding scatter-add comes later, in embed_bwd).  360 tiles, no split-K, no
         # workspace: it runs on the side stream, which is idle until the encoder's backward starts; embed_bwd waits for it.
+        # The decoder bias gradient (column sums over the 207 MB of dlogits) goes with it: nothing on the main chain needs it.
         main = torch.cuda.current_stream()
         if self._side is None:
             self._side = _shared_stream(self.device, "side")
         side = self._side if (self.head_on_side and os.environ.get("MV_SINGLE_STREAM") != "1") else main
         side.wait_stream(main)
+        if not self.head_params_on_side:
+            ops.colsum(dlogits, Vp, R, V, g["mlm.predictions.bias"], accumulate=True, unscale=us)
         with torch.cuda.stream(side):
+            if self.head_params_on_side:
+                ops.colsum(dlogits, Vp, R, V, g["mlm.predictions.bias"], accumulate=True, unscale=us)
             self._dW(dlogits, hs["t"], g["enc.txt_embeddings.word_embeddings.weight"], V, H, R, lda=Vp, ldb=H)
             self._dE_ev = torch.cuda.Event()
             self._dE_ev.record(side)
@@ -692,8 +697,12 @@ class Engine:
             tzc = hs["tz"]
         dtz = self._buf(tag + "dtz", (R, H), self.adt)
         ops.dact(0, dtact, tzc, dtz, R * H)
-        ops.colsum(dtz, H, R, H, g["mlm.predictions.transform.dense.bias"], accumulate=True, unscale=us)
-        self._dW(dtz, hs["xr"], g["mlm.predictions.transform.dense.weight"], H, H, R, lda=H, ldb=H)
+        pside = side if self.head_params_on_side else main
+        if pside is not main:          # the transform's bias / weight gradients: parameter gradients, off the main chain like the encoder's
+            pside.wait_stream(main)
+        with torch.cuda.stream(pside):
+            ops.colsum(dtz, H, R, H, g["mlm.predictions.transform.dense.bias"], accumulate=True, unscale=us)
+            self._dW(dtz, hs["xr"], g["mlm.predictions.transform.dense.weight"], H, H, R, lda=H, ldb=H)
         dxr = self._buf(tag + "dxr", (R, H), self.adt)
         ops.gemm(dtz, self.w["mlm.predictions.transform.dense.weight"], dxr, tb=True, M=R, N=H, K=H)
         return dxr

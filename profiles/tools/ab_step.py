@@ -56,6 +56,8 @@ VARIANTS = {
            ("prefetch, 4 waves x 512 blocks", lambda: mv.hip_ops.set_rowops_variant(2 | (512 << 8)))],
     "optwait": [("forward waits for the optimizer's first kernel before its preparation kernels", lambda: setattr(model.engine, "late_opt_wait", False)),
                 ("... right before the first reader of the embeddings range", lambda: setattr(model.engine, "late_opt_wait", True))],
+    "hps": [("MLM head's bias / transform parameter gradients on the main chain", lambda: setattr(model.engine, "head_params_on_side", False)),
+            ("... on the side stream", lambda: setattr(model.engine, "head_params_on_side", True))],
     "itm": [("ITM head after the MLM head on the main stream", lambda: setattr(model.engine, "itm_on_side", False)),
             ("ITM head on the side stream under the decoder GEMM", lambda: setattr(model.engine, "itm_on_side", True))],
     "logits": [("MLM logits f32", lambda: setattr(model.engine, "logits_16", False)),
