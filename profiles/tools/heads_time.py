@@ -1,5 +1,9 @@
-import os, sys, torch
-sys.path.insert(0, "/root/repo")
+"""MLM head forward (transform + LayerNorm + tied decoder) and the loss kernel at the step's shape, f32 against f16 logits.
+usage: python profiles/tools/heads_time.py"""
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
 import medvill_amd as mv
 from medvill_amd import hip_ops as ops
 dev = torch.device("cuda", 0)
