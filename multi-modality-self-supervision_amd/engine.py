@@ -430,6 +430,7 @@ class Engine:
         if self.shadow_dirty:
             self.sync_shadow()
         if not self.late_opt_wait:
+            self._wait_opt("embeddings_rest")
             self._wait_opt("embeddings")
         f32 = torch.float32
         S = self.S = dict(B=B, T=T, N=N, L=Lq, M=M, cu=None, rowmap=None, inv=None, sel=None, n_lab=0, tq=None)
@@ -520,9 +521,10 @@ class Engine:
         imgproj = self._buf("imgproj", (B * N, H), fadt)
         # first reader of the embeddings parameter range: everything above (row plan, mask words, keep-bits of every layer) did not need
         # the optimizer's first kernel (113 us over the word table) and ran under it
-        self._wait_opt("embeddings")
+        self._wait_opt("embeddings_rest")
         ops.gemm(feats_f, wf["enc.img_embeddings.img_embeddings.weight"], imgproj, M=B * N, N=H, K=D,
                  bias=self.p["enc.img_embeddings.img_embeddings.bias"], epi=EPI_BIAS)
+        self._wait_opt("embeddings")                # the word table
         x, x_b = self._pair("x0", (M, H))
         pre0 = self._buf("pre0", (M, H), f32)
         mean0, rstd0 = self._buf("mean0", (M,), f32), self._buf("rstd0", (M,), f32)
@@ -1018,8 +1020,13 @@ class Engine:
         use_w2t = self.dz_nt and self.is16
         if use_w2t and self._w2t is None:
             self._w2t = [torch.empty((cfg.intermediate, cfg.hidden), dtype=self.adt, device=self.device) for _ in range(cfg.layers)]
+        # the embeddings range in two kernels: the small tables / LayerNorm / image projection first (the next forward's first GEMM reads the
+        # image projection), then the word table (110 us of HBM traffic that this GEMM no longer waits for)
+        word_end = self.layout["enc.txt_embeddings.position_embeddings.weight"][0]
+        ranges["embeddings_rest"] = (word_end, ranges["embeddings"][1])
+        ranges["embeddings"] = (ranges["embeddings"][0], word_end)
         with torch.cuda.stream(side):
-            for name in ["embeddings"] + [f"layer{l}" for l in range(cfg.layers)] + ["heads"]:
+            for name in ["embeddings_rest", "embeddings"] + [f"layer{l}" for l in range(cfg.layers)] + ["heads"]:
                 s_, e_ = ranges[name]
                 sl = slice(s_, e_)
                 ops.adamw_step(self.flat_p[sl], self.flat_g[sl], self.flat_m[sl], self.flat_v[sl],
