@@ -13,6 +13,10 @@ import os as _os
 # 26.9).  The variable is read when the HIP runtime initialises, i.e. at the first device call -- importing torch is not one.
 _hwq_preset = "GPU_MAX_HW_QUEUES" in _os.environ          # exported by the caller (bench.py does) before anything could start HIP
 _os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# Kernel arguments in device memory instead of host-coherent memory (also read when the HIP runtime initialises): a dependent kernel starts
+# sooner, and a step is ~390 mostly dependent launches -- 24.56 / 24.72 ms without against 24.31 / 24.29 ms with it, alternating runs on one
+# box (profiles/r03_notes.txt).  AMD's MI300-series tuning notes recommend the setting.
+_os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 
 
 def _warn_if_hip_started():
