@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MV_ABI_VERSION 4
+#define MV_ABI_VERSION 5
 
 /* MV_F16 is the encoding of the 16-bit path (weights' f16 shadow, stored activations, gradients): 11 significand bits
  * instead of bf16's 8 at the same MFMA rate.  At BERT-base depth bf16-encoded forward operands cannot meet the 1e-2 logit
@@ -169,6 +169,14 @@ int mv_mlm_corrupt(const int64_t* ids, const int32_t* lengths, const float* u, c
                    int B, int N, int S, int64_t* input_txt, int64_t* segment, int64_t* txt_labels, int32_t* n_ids,
                    int32_t* desc, int32_t* counts, int32_t* label_rows, int32_t* label_ids, int32_t* n_labels, void* stream);
 
+/* HOST function (no device work, no stream): every entry of a materialised reference mask (int64 [B,L,L], or [B,L] for the 1-D
+ * family; data/dataset_origin.py:138-176) against the closed form of its descriptor desc[b] = {family, n2, vl} -- the predicates of
+ * mv_mask_build, a 32-column word at a time, `threads` host threads split by sample.  *first_mismatch = -1 when every entry agrees,
+ * else the linear index (b*L + i)*L + j (b*L + j for 2-D masks) of the first entry that differs.  CXRBERT_Trainer runs it one batch
+ * ahead of the step on a worker thread: the descriptors it derives from probe entries are proven bit for bit on EVERY batch without
+ * moving the 134 MB matrix over PCIe.  Both pointers are HOST pointers. */
+int mv_mask_verify_host(const int64_t* mask, int mask_ndim, const int32_t* desc, int B, int L, int threads, long long* first_mismatch);
+
 /* ---- packed rows (padding removal) -------------------------------------------------------------------
  * In the full, seq2seq and 1-D mask families no valid query can see a position after the sample's text [SEP]
  * (SURVEY.md Appendix B), and those positions carry no label: their rows contribute exactly nothing to the loss,
@@ -257,13 +265,16 @@ int mv_layernorm_bwd(int dtype, const void* dy, const void* x, int x_dtype, cons
  *               E[txt[b,t]]+Ty[segment[b,t]]+P[t] ] )         L = N + T + 2
  * straight into the concatenated [B,L,H] buffer.  imgproj = feats.Wi^T + bi comes from mv_gemm.
  * Tables E, P, Ty and imgproj are in `dtype`; gamma/beta f32.  `pre` (f32 [B,L,H]) keeps the
- * pre-LayerNorm sums for the backward.  x0_bf16 (nullable, dtype MV_F16 only): bf16 copy of x0.  */
+ * pre-LayerNorm sums for the backward.  x0_bf16 (nullable, dtype MV_F16 only): bf16 copy of x0.
+ * img_pos NULL: the image rows get NO position embedding (args.img_postion false, cxrbert_origin.py:27-31).
+ * p_drop: dropout of the text / [CLS] / [SEP] rows (HF hidden_dropout_prob); p_drop_img: of the image rows
+ * (ImageBertEmbeddings' nn.Dropout(args.dropout_prob), cxrbert_origin.py:19); same key and element index.  */
 int mv_embed_fwd(int dtype, const int64_t* cls_tok, const int64_t* txt, const int64_t* segment,
                  const int64_t* img_pos, const int64_t* sep_tok, const void* imgproj,
                  const void* E, const void* P, const void* Ty, const float* gamma, const float* beta,
                  void* x0, void* x0_bf16, float* pre, float* mean, float* rstd,
                  int B, int N, int T, int H, int V, int maxpos, float eps,
-                 float p_drop, unsigned long long drop_key, const int32_t* rowmap, int n_rows, void* stream);
+                 float p_drop, float p_drop_img, unsigned long long drop_key, const int32_t* rowmap, int n_rows, void* stream);
 
 /* Backward of the above: LN backward of dx0, scatter-add (f32 atomics) into dE [V,H], dP, dTy,
  * dgamma, dbeta (all ACCUMULATED) and write d(imgproj) [B,N,H] in `dtype`.  Row `pad_token_id`
@@ -274,7 +285,7 @@ int mv_embed_bwd(int dtype, const void* dx0, const float* pre, const float* mean
                  const int64_t* img_pos, const int64_t* sep_tok,
                  float* dE, float* dP, float* dTy, float* dgamma, float* dbeta, void* dimgproj,
                  int B, int N, int T, int H, int V, int maxpos, int pad_token_id,
-                 float p_drop, unsigned long long drop_key, const int32_t* rowmap, int n_rows,
+                 float p_drop, float p_drop_img, unsigned long long drop_key, const int32_t* rowmap, int n_rows,
                  const float* grad_unscale_dev, void* stream);
 
 /* ---- losses + step metrics ------------------------------------------------------------------

@@ -35,6 +35,7 @@ PROTOTYPES = {
                 i32, vp, sz, i32, f32, u64, vp, vp, vp],
     "mv_mask_pack": [vp, i32, i32, i32, vp, vp, vp],
     "mv_mask_build": [vp, i32, i32, vp, vp, vp],
+    "mv_mask_verify_host": [vp, i32, vp, i32, i32, i32, C.POINTER(C.c_longlong)],
     "mv_mlm_draws": [u64, i32, i32, i32, vp, vp, vp],
     "mv_mlm_corrupt": [vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "mv_pack_plan": [vp, i32, i32, vp, vp, vp, vp],
@@ -44,9 +45,9 @@ PROTOTYPES = {
     "mv_attn_bwd": [i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp, vp, i32, vp, vp],
     "mv_layernorm_fwd": [i32, vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, f32, vp],
     "mv_layernorm_bwd": [i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, f32, u64, vp, vp],
-    "mv_embed_fwd": [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, f32,
+    "mv_embed_fwd": [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, f32, f32,
                      u64, vp, i32, vp],
-    "mv_embed_bwd": [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32,
+    "mv_embed_bwd": [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, f32,
                      u64, vp, i32, vp, vp],
     "mv_dropout_mask": [f32, u64, sz, vp, C.POINTER(C.c_float), vp],
     "mv_ce_fwd_bwd": [vp, i32, i32, vp, i32, i32, vp, vp, i32, i32, vp, f32, vp, vp],
@@ -93,7 +94,7 @@ def load(build_if_missing: bool = False):
         fn = getattr(lib, name)          # AttributeError if an exported symbol is missing
         fn.argtypes = args
         fn.restype = _RESTYPE.get(name, C.c_int)
-    if lib.mv_abi_version() != 4:
+    if lib.mv_abi_version() != 5:
         raise RuntimeError("libmedvill_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -325,10 +325,15 @@ struct EmbArgs {
   int n_rows;
 };
 // position l of sample b -> (token id or -1 for an image region, position id, type id, region index)
+// img_pos == NULL: image rows get no position embedding (args.img_postion false, cxrbert_origin.py:27-31): pos = -1 for them
 __device__ __forceinline__ void emb_decode(const EmbArgs& a, int b, int l, int& tok, int& pos, int& typ, int& reg) {
   reg = -1;
   if (l == 0) { tok = (int)a.cls_tok[b]; pos = 0; typ = 0; }
-  else if (l <= a.N) { tok = -1; reg = l - 1; pos = (int)a.img_pos[(size_t)b * a.N + reg]; typ = 0; }
+  else if (l <= a.N) {
+    tok = -1; reg = l - 1; typ = 0;
+    if (!a.img_pos) { pos = -1; return; }
+    pos = (int)a.img_pos[(size_t)b * a.N + reg];
+  }
   else if (l == a.N + 1) { tok = (int)a.sep_tok[b]; pos = 0; typ = 0; }
   else { const int t = l - a.N - 2; tok = (int)a.txt[(size_t)b * a.T + t]; pos = t; typ = (int)a.segment[(size_t)b * a.T + t]; }
   // clamp so that a bad id can never fault (HF would raise an index error on the host)
@@ -343,7 +348,8 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(EmbArgs a, const T* __re
                                                         const T* __restrict__ P, const T* __restrict__ Ty,
                                                         const float* __restrict__ g, const float* __restrict__ bta,
                                                         T* __restrict__ x0, float* __restrict__ pre, float* __restrict__ mean,
-                                                        float* __restrict__ rstd, float eps, DropCfg drop, bf16_t* __restrict__ x0_bf16) {
+                                                        float* __restrict__ rstd, float eps, DropCfg drop_txt, DropCfg drop_img,
+                                                        bf16_t* __restrict__ x0_bf16) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= a.n_rows) return;
@@ -351,8 +357,10 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(EmbArgs a, const T* __re
   const int b = li / a.L, l = li - b * a.L, H = a.H;
   int tok, pos, typ, reg;
   emb_decode(a, b, l, tok, pos, typ, reg);
+  const DropCfg drop = (tok < 0) ? drop_img : drop_txt;      // image rows: nn.Dropout(args.dropout_prob), cxrbert_origin.py:19
   const T* src = (tok >= 0) ? E + (size_t)tok * H : imgproj + ((size_t)b * a.N + reg) * H;
-  const T* pr = P + (size_t)pos * H;
+  const bool haspos = pos >= 0;
+  const T* pr = P + (size_t)(haspos ? pos : 0) * H;
   const T* tr = Ty + (size_t)typ * H;
   f32x4 v[NC];
   float s = 0.f;
@@ -362,8 +370,8 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(EmbArgs a, const T* __re
     v[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (c < H) {
       const f32x4 e = ld4<T>(src + c), p = ld4<T>(pr + c), t = ld4<T>(tr + c);
-      // summation order of the reference: (word|img) + position + type  (cxrbert_origin.py:29)
-      v[n] = e + p + t;
+      // summation order of the reference: (word|img) + position + type  (cxrbert_origin.py:29; :31 without the position)
+      v[n] = haspos ? e + p + t : e + t;
       s += v[n][0] + v[n][1] + v[n][2] + v[n][3];
     }
   }
@@ -399,8 +407,8 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(EmbArgs a, const T* __re
                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
                                                         const float* __restrict__ g, float* __restrict__ dE, float* __restrict__ dP,
                                                         float* __restrict__ dTy, float* __restrict__ dgamma,
-                                                        float* __restrict__ dbeta, T* __restrict__ dimg, int pad_id, DropCfg drop,
-                                                        const float* __restrict__ gscale) {
+                                                        float* __restrict__ dbeta, T* __restrict__ dimg, int pad_id, DropCfg drop_txt,
+                                                        DropCfg drop_img, const float* __restrict__ gscale) {
   __shared__ float red[4][4][260];
   __shared__ __attribute__((aligned(16))) float rowbuf[4][MV_MAX_H];   // per-wave row, re-read lane-contiguously for the atomics
   const int lane = threadIdx.x & 63, wl = threadIdx.x >> 6, H = a.H;
@@ -414,6 +422,7 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(EmbArgs a, const T* __re
     const int b = li / a.L, l = li - b * a.L;
     int tok, pos, typ, reg;
     emb_decode(a, b, l, tok, pos, typ, reg);
+    const DropCfg drop = (tok < 0) ? drop_img : drop_txt;
     const float mu = mean[row], rs = rstd[row];
     f32x4 xh[NC], gd[NC];
     float s1 = 0.f, s2 = 0.f;
@@ -449,12 +458,12 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(EmbArgs a, const T* __re
     }
     // scatter-add with 64 consecutive floats per wave instruction (the shape float atomics run at full rate in);
     // the [PAD] row receives no look-up gradient (nn.Embedding padding_idx of HF BertEmbeddings)
-    const bool do_e = (tok >= 0) && (tok != pad_id);
-    float* pp = dP + (size_t)pos * H;
+    const bool do_e = (tok >= 0) && (tok != pad_id), do_p = pos >= 0;
+    float* pp = dP + (size_t)(do_p ? pos : 0) * H;
     float* ep = dE + (size_t)(tok >= 0 ? tok : 0) * H;
     for (int c = lane; c < H; c += 64) {
       const float v = rowbuf[wl][c] * gs;
-      atomicAdd(pp + c, v);
+      if (do_p) atomicAdd(pp + c, v);
       if (do_e) atomicAdd(ep + c, v);
     }
   }
@@ -488,20 +497,20 @@ static int emb_check(int B, int N, int T, int H, int V, int maxpos) {
 extern "C" int mv_embed_fwd(int dtype, const int64_t* cls_tok, const int64_t* txt, const int64_t* segment, const int64_t* img_pos,
                             const int64_t* sep_tok, const void* imgproj, const void* E, const void* P, const void* Ty,
                             const float* gamma, const float* beta, void* x0, void* x0_bf16, float* pre, float* mean, float* rstd,
-                            int B, int N, int T, int H, int V, int maxpos, float eps, float p_drop, unsigned long long drop_key,
-                            const int32_t* rowmap, int n_rows, void* stream_) {
+                            int B, int N, int T, int H, int V, int maxpos, float eps, float p_drop, float p_drop_img,
+                            unsigned long long drop_key, const int32_t* rowmap, int n_rows, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!cls_tok || !txt || !segment || !sep_tok || !E || !P || !Ty || !gamma || !beta || !x0 || !pre || !mean || !rstd) return MV_E_ARG;
-  if (N > 0 && (!img_pos || !imgproj)) return MV_E_ARG;
+  if (N > 0 && !imgproj) return MV_E_ARG;          // img_pos may be NULL: no position embedding on the image rows
   int rc = emb_check(B, N, T, H, V, maxpos);
   if (rc) return rc;
   if (T > maxpos) return MV_E_SHAPE;   // text positions 0..T-1 must exist
   if (rowmap && (n_rows <= 0 || n_rows > B * (N + T + 2))) return MV_E_ARG;
   EmbArgs a{cls_tok, txt, segment, img_pos, sep_tok, B, N, T, H, V, maxpos, N + T + 2, rowmap, rowmap ? n_rows : B * (N + T + 2)};
   dim3 grid((a.n_rows + 3) / 4), block(256);
-  const DropCfg drop = mv_make_drop(p_drop, drop_key);
+  const DropCfg drop = mv_make_drop(p_drop, drop_key), drop_img = mv_make_drop(p_drop_img, drop_key);
   if (x0_bf16 && dtype != MV_F16) return MV_E_DTYPE;
-#define EMF(NC_) hipLaunchKernelGGL((embed_fwd_kernel<T_, NC_>), grid, block, 0, stream, a, (const T_*)imgproj, (const T_*)E, (const T_*)P, (const T_*)Ty, gamma, beta, (T_*)x0, pre, mean, rstd, eps, drop, (bf16_t*)x0_bf16)
+#define EMF(NC_) hipLaunchKernelGGL((embed_fwd_kernel<T_, NC_>), grid, block, 0, stream, a, (const T_*)imgproj, (const T_*)E, (const T_*)P, (const T_*)Ty, gamma, beta, (T_*)x0, pre, mean, rstd, eps, drop, drop_img, (bf16_t*)x0_bf16)
   if (dtype == MV_F32) { typedef float T_; NC_DISPATCH(H, EMF); }
   else if (dtype == MV_BF16) { typedef bf16_t T_; NC_DISPATCH(H, EMF); }
   else if (dtype == MV_F16) { typedef f16_t T_; NC_DISPATCH(H, EMF); }
@@ -514,13 +523,13 @@ extern "C" int mv_embed_fwd(int dtype, const int64_t* cls_tok, const int64_t* tx
 extern "C" int mv_embed_bwd(int dtype, const void* dx0, const float* pre, const float* mean, const float* rstd, const float* gamma,
                             const int64_t* cls_tok, const int64_t* txt, const int64_t* segment, const int64_t* img_pos,
                             const int64_t* sep_tok, float* dE, float* dP, float* dTy, float* dgamma, float* dbeta, void* dimgproj,
-                            int B, int N, int T, int H, int V, int maxpos, int pad_token_id, float p_drop,
+                            int B, int N, int T, int H, int V, int maxpos, int pad_token_id, float p_drop, float p_drop_img,
                             unsigned long long drop_key, const int32_t* rowmap, int n_rows, const float* grad_unscale_dev,
                             void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!dx0 || !pre || !mean || !rstd || !gamma || !cls_tok || !txt || !segment || !sep_tok || !dE || !dP || !dTy || !dgamma || !dbeta)
     return MV_E_ARG;
-  if (N > 0 && (!img_pos || !dimgproj)) return MV_E_ARG;
+  if (N > 0 && !dimgproj) return MV_E_ARG;
   int rc = emb_check(B, N, T, H, V, maxpos);
   if (rc) return rc;
   if (rowmap && (n_rows <= 0 || n_rows > B * (N + T + 2))) return MV_E_ARG;
@@ -528,8 +537,8 @@ extern "C" int mv_embed_bwd(int dtype, const void* dx0, const float* pre, const 
   int blocks = (a.n_rows + 3) / 4;
   if (blocks > 1024) blocks = 1024;
   dim3 grid(blocks), block(256);
-  const DropCfg drop = mv_make_drop(p_drop, drop_key);
-#define EMB(NC_) hipLaunchKernelGGL((embed_bwd_kernel<T_, NC_>), grid, block, 0, stream, a, (const T_*)dx0, pre, mean, rstd, gamma, dE, dP, dTy, dgamma, dbeta, (T_*)dimgproj, pad_token_id, drop, grad_unscale_dev)
+  const DropCfg drop = mv_make_drop(p_drop, drop_key), drop_img = mv_make_drop(p_drop_img, drop_key);
+#define EMB(NC_) hipLaunchKernelGGL((embed_bwd_kernel<T_, NC_>), grid, block, 0, stream, a, (const T_*)dx0, pre, mean, rstd, gamma, dE, dP, dTy, dgamma, dbeta, (T_*)dimgproj, pad_token_id, drop, drop_img, grad_unscale_dev)
   if (dtype == MV_F32) { typedef float T_; NC_DISPATCH(H, EMB); }
   else if (dtype == MV_BF16) { typedef bf16_t T_; NC_DISPATCH(H, EMB); }
   else if (dtype == MV_F16) { typedef f16_t T_; NC_DISPATCH(H, EMB); }

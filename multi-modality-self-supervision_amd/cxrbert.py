@@ -18,6 +18,7 @@ from __future__ import annotations
 import json
 import os
 from collections import OrderedDict
+from dataclasses import replace
 from types import SimpleNamespace
 
 import torch
@@ -26,16 +27,29 @@ import torch.nn as nn
 from .engine import ALIASES, Engine, ModelConfig
 
 
-def model_config_from(config) -> ModelConfig:
-    """Accepts a ModelConfig, a HF-BertConfig-like object or a dict (config.json contents)."""
+def model_config_from(config, args=None) -> ModelConfig:
+    """Accepts a ModelConfig, a HF-BertConfig-like object or a dict (config.json contents).  `args` (the reference's argparse
+    namespace) contributes the two fields ImageBertEmbeddings reads from it (cxrbert_origin.py:19,27-31):
+      args.img_postion (sic)  falsy -> the image rows get no position embedding.  Python truthiness, as in the reference
+                              (`if self.args.img_postion:`; main_origin.py:129 declares the flag without a type, so the
+                              command-line string "False" is truthy there as well);
+      args.dropout_prob       probability of the image embeddings' own nn.Dropout (text rows use hidden_dropout_prob)."""
     if isinstance(config, ModelConfig):
-        return config
-    get = (lambda k, d=None: config.get(k, d)) if isinstance(config, dict) else (lambda k, d=None: getattr(config, k, d))
-    return ModelConfig(vocab_size=get("vocab_size", 30522), hidden=get("hidden_size", 768), layers=get("num_hidden_layers", 12),
-                       heads=get("num_attention_heads", 12), intermediate=get("intermediate_size", 3072),
-                       max_pos=get("max_position_embeddings", 512), type_vocab=get("type_vocab_size", 2),
-                       img_hidden=get("img_hidden_sz", 2048), ln_eps=get("layer_norm_eps", 1e-12),
-                       dropout=get("hidden_dropout_prob", 0.1))
+        cfg = replace(config)
+    else:
+        get = (lambda k, d=None: config.get(k, d)) if isinstance(config, dict) else (lambda k, d=None: getattr(config, k, d))
+        cfg = ModelConfig(vocab_size=get("vocab_size", 30522), hidden=get("hidden_size", 768), layers=get("num_hidden_layers", 12),
+                          heads=get("num_attention_heads", 12), intermediate=get("intermediate_size", 3072),
+                          max_pos=get("max_position_embeddings", 512), type_vocab=get("type_vocab_size", 2),
+                          # nn.Linear(args.img_hidden_sz, args.embedding_size), cxrbert_origin.py:16 (a config entry wins)
+                          img_hidden=get("img_hidden_sz", None) or int(getattr(args, "img_hidden_sz", None) or 2048), ln_eps=get("layer_norm_eps", 1e-12),
+                          dropout=get("hidden_dropout_prob", 0.1))
+    if args is not None:
+        if hasattr(args, "img_postion"):
+            cfg.img_position = bool(args.img_postion)
+        if getattr(args, "dropout_prob", None) is not None:
+            cfg.img_dropout = float(args.dropout_prob)
+    return cfg
 
 
 class _CXRBertFn(torch.autograd.Function):
@@ -49,6 +63,7 @@ class _CXRBertFn(torch.autograd.Function):
         eng = model.engine
         eng.shadow_dirty = True                 # parameters may have been stepped by an external optimizer
         eng.training = model.training           # dropout (p = 0.1 at every site of the reference) only in train mode
+        eng.keep_acts = bool(model._want_grad)  # under torch.no_grad() nothing is saved for a backward
         hidden, pooled = eng.encoder_forward(cls_tok, input_txt, attn_mask, segment, feats, pos, sep_tok)
         ctx.model, ctx.want_heads = model, want_heads
         if want_heads == 2:                     # ITM head only (retrieval: `self.itm(cls)` on the pooled output)
@@ -109,6 +124,108 @@ class _CXRBertFn(torch.autograd.Function):
         return (None,) * 9 + grads
 
 
+_MLM_PARAMS = ("mlm.predictions.transform.dense.weight", "mlm.predictions.transform.dense.bias",
+               "mlm.predictions.transform.LayerNorm.weight", "mlm.predictions.transform.LayerNorm.bias", "mlm.predictions.bias",
+               "enc.txt_embeddings.word_embeddings.weight")
+_ITM_PARAMS = ("itm.linear.weight", "itm.linear.bias")
+
+
+def _scaled_retry(eng, run):
+    """f16 gradient operands travel under the engine's loss scale S.  A head called on its own hands its gradients to torch, so an
+    overflow cannot become a skipped optimizer step: `run()` (-> tensors to test) is redone with S / 16 until everything is finite."""
+    outs = run()
+    if eng.scaler is None:
+        return outs
+    for _ in range(8):
+        if all(bool(torch.isfinite(t).all()) for t in outs) or float(eng.scaler[0]) <= 1.0:
+            break
+        eng.reset_scaler(max(float(eng.scaler[0]) / 16.0, 1.0))
+        outs = run()
+    return outs
+
+
+class _HeadFn(torch.autograd.Function):
+    """`model.itm(pooled)` / `model.mlm(hidden)` as the reference's callers use them on their own
+    (cxrbert_origin.py:147-148; Downstream_task/Retrieval/retrieval.py:26-31): the head's HIP kernels over ANY input tensor,
+    differentiable w.r.t. the input and the head's parameters (gradients come back as fresh tensors, like _CXRBertFn's)."""
+
+    @staticmethod
+    def forward(ctx, model, kind, x, *params):
+        from . import hip_ops as ops
+        from ._lib import EPI_BIAS
+        eng = model.engine
+        H, V = eng.cfg.hidden, eng.cfg.vocab_size
+        if x.shape[-1] != H:
+            raise ValueError(f"{kind}: last dimension {x.shape[-1]} != hidden size {H}")
+        if eng.shadow_dirty:
+            eng.sync_shadow()
+        eng.wait_optimizer()
+        xin = x.detach().to(eng.device).reshape(-1, H)
+        R = xin.shape[0]
+        xf = xin.to(eng.fadt).contiguous()
+        xb = xf if not eng.dual else xin.to(eng.adt).contiguous()
+        ctx.model, ctx.kind, ctx.R, ctx.xb, ctx.in_dtype = model, kind, R, xb, x.dtype
+        if kind == "itm":
+            out = torch.empty((R, 2), dtype=torch.float32, device=eng.device)
+            ops.gemm(xf, eng.wf["itm.linear.weight"], out, M=R, N=2, K=H, bias=eng.p["itm.linear.bias"], epi=EPI_BIAS)
+            return out.view(*x.shape[:-1], 2)
+        if not hasattr(eng, "S"):
+            eng.S = {}
+        logits = eng._mlm_forward(xf, xb, R, "hm_", pad=False)
+        ctx.hs = eng.S["hm_"]
+        return logits.view(*x.shape[:-1], V)
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import hip_ops as ops
+        from .dist import bucket_ranges
+        model, kind, R = ctx.model, ctx.kind, ctx.R
+        eng = model.engine
+        H, V = eng.cfg.hidden, eng.cfg.vocab_size
+        adt, dev = eng.adt, eng.device
+        g32 = g.detach().to(dev, torch.float32).contiguous()
+        eng.ensure_grad()
+
+        def scaled(t):
+            return t if eng.loss_scale_dev is None else t * eng.loss_scale_dev
+
+        def unscaled(t):
+            t = t.float()
+            return t if eng.unscale_dev is None else t * eng.unscale_dev
+
+        if kind == "itm":
+            def run():
+                us = eng.unscale_dev
+                d8 = torch.zeros((R, 8), dtype=adt, device=dev)
+                ops.cast2d(scaled(g32.view(R, 2)), 2, d8, 8, R, 2)
+                gW = torch.zeros((2, H), dtype=torch.float32, device=dev)
+                gb = torch.zeros((2,), dtype=torch.float32, device=dev)
+                ops.colsum(d8, 8, R, 2, gb, accumulate=True, unscale=us)
+                eng._dW(d8, ctx.xb, gW, 2, H, R, lda=8, ldb=H)
+                dx = torch.empty((R, H), dtype=adt, device=dev)
+                ops.gemm(d8, eng.w["itm.linear.weight"], dx, tb=True, M=R, N=H, K=2, lda=8, ldb=H)
+                return [unscaled(dx), gW, gb]
+            dx, gW, gb = _scaled_retry(eng, run)
+            return None, None, dx.view(*g.shape[:-1], H).to(ctx.in_dtype), gW, gb
+
+        Vp = (V + 7) // 8 * 8
+        s_, e_ = bucket_ranges(eng.layout, eng.n_flat, eng.cfg.layers)["heads"]
+
+        def run():
+            eng.S["hm_"] = ctx.hs
+            ctx.hs["Vp"] = Vp
+            eng.flat_g[s_:e_].zero_()
+            dl = torch.empty((R, Vp), dtype=adt, device=dev)
+            ops.cast2d(scaled(g32.view(R, V)), V, dl, Vp, R, V)
+            dxr = eng._mlm_backward(dl, "hm_")
+            if eng._side is not None:
+                torch.cuda.current_stream().wait_stream(eng._side)     # the decoder's / transform's parameter gradients (side stream)
+            eng._dE_ev = None
+            return [unscaled(dxr)] + [eng.g[n].clone() for n in _MLM_PARAMS]
+        outs = _scaled_retry(eng, run)
+        return (None, None, outs[0].view(*g.shape[:-1], H).to(ctx.in_dtype)) + tuple(outs[1:])
+
+
 class _Sub(nn.Module):
     """Namespace module so that parameters appear under the reference's dotted names."""
 
@@ -120,7 +237,7 @@ class CXRBERT(nn.Module):
         """dtype: torch.float32 (exact path) or torch.bfloat16 (16-bit MFMA path); fwd_operand / grad_operand: encodings of the
         operands of the forward / gradient products of the 16-bit path ("f16" (default) or "bf16") -- see engine.Engine."""
         super().__init__()
-        self.cfg = model_config_from(config)
+        self.cfg = model_config_from(config, args)
         self.config = config
         self.args = args if args is not None else SimpleNamespace()
         if getattr(self.args, "disturbing_mask", False):
@@ -150,6 +267,10 @@ class CXRBERT(nn.Module):
             par = nn.Parameter(self.engine.p[name], requires_grad=True)
             mod._parameters[parts[-1]] = par
         self.enc.forward = self._enc_forward
+        # the heads are callable on their own like the reference's sub-modules (cxrbert_origin.py:147-148, retrieval.py:31)
+        self.itm.forward = self._itm_module_forward
+        self.mlm.forward = self._mlm_module_forward
+        self.mlm.predictions.forward = lambda hidden: self._mlm_module_forward(hidden)[0]       # BertLMPredictionHead, :234-238
 
     def _rebind(self):
         for name in self._param_names:
@@ -211,6 +332,7 @@ class CXRBERT(nn.Module):
             raise NotImplementedError            # cxrbert_origin.py:80-81
         feats, pos = self._regions(input_img)
         params = [self.get_parameter(n) for n in self._param_names]
+        self._want_grad = torch.is_grad_enabled()        # (grad mode is always off inside autograd.Function.forward)
         return _CXRBertFn.apply(self, want_heads, cls_tok, input_txt, attn_mask, segment, feats, pos, sep_tok, *params)
 
     def _enc_forward(self, cls_tok, input_txt, attn_mask, segment, input_img, sep_tok):
@@ -219,6 +341,14 @@ class CXRBERT(nn.Module):
 
     def forward(self, cls_tok, input_txt, attn_mask, segment, input_img, sep_tok):
         return self._run(True, cls_tok, input_txt, attn_mask, segment, input_img, sep_tok)
+
+    def _itm_module_forward(self, x):
+        """ImageTextMatching.forward (cxrbert_origin.py:172-173): x [..., H] -> [..., 2]."""
+        return _HeadFn.apply(self, "itm", x, *[self.get_parameter(n) for n in _ITM_PARAMS])
+
+    def _mlm_module_forward(self, sequence_output):
+        """BertPreTrainingHeads.forward (cxrbert_origin.py:245-248): [..., H] -> (prediction_scores [..., V], None)."""
+        return _HeadFn.apply(self, "mlm", sequence_output, *[self.get_parameter(n) for n in _MLM_PARAMS]), None
 
     def _itm_only(self, cls_tok, input_txt, attn_mask, segment, input_img, sep_tok):
         """ITM logits [B,2] of enc + itm without the MLM head (the retrieval model's forward), differentiable."""

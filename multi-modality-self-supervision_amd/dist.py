@@ -84,15 +84,6 @@ class GradAllReducer:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t
 
-    def all_agree(self, ok: bool) -> bool:
-        """True iff `ok` on every rank (one tiny MIN all-reduce, host-synchronous); every rank of the group must call it."""
-        if self.world == 1 and not self.force:
-            return bool(ok)
-        dev = self.flat_g.device
-        t = torch.tensor([1.0 if ok else 0.0], dtype=torch.float32, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
-        return bool(t.item() > 0.5)
-
     def _launch(self, s, e, events=()):
         if (self.world == 1 and not self.force) or e <= s:
             return
@@ -114,7 +105,7 @@ class GradAllReducer:
         event after the bucket's weight-gradient GEMMs, or None when everything is on the current stream)."""
         if name == "heads":
             # mlm.predictions.* / pooler / itm are final; the tied E gradient is NOT (embedding scatter comes last)
-            self._launch(*self.ranges["heads"])
+            self._launch(*self.ranges["heads"], events=(event,))
         elif name.startswith("layer"):
             l = int(name[5:])
             if self._pending_hi is None:

@@ -40,7 +40,9 @@ class ModelConfig:
     img_hidden: int = 2048
     ln_eps: float = 1e-12
     head_ln_eps: float = 1e-5
-    dropout: float = 0.1          # hidden_dropout_prob = attention_probs_dropout_prob = args.dropout_prob = 0.1 in the reference
+    dropout: float = 0.1          # hidden_dropout_prob = attention_probs_dropout_prob = 0.1 in the reference's BertConfig
+    img_position: bool = True     # args.img_postion (sic): image rows add P[img_pos]  (cxrbert_origin.py:27-31)
+    img_dropout: float = -1.0     # args.dropout_prob: ImageBertEmbeddings' own nn.Dropout (cxrbert_origin.py:19); < 0: same as `dropout`
 
     def to_dict(self):
         return asdict(self)
@@ -112,6 +114,29 @@ ALIASES = {  # reference state-dict aliases -> canonical tensor (cxrbert_origin.
 }
 
 
+# roctx ranges around the phases of a step: MV_ROCTX=1 pushes / pops a range per phase (embed, layer<l>.attention,
+# layer<l>.ffn, heads, backward.layer<l>, backward.embed, overflow_check, optimizer; the data-parallel exchange marks "exchange") so that
+# `rocprofv3 --marker-trace --kernel-trace` shows which launches belong to which phase.  The ranges are HOST ranges -- the host runs
+# ~17 ms ahead of the device -- so MV_ROCTX=2 also synchronises the device at every phase boundary: each range then lasts as long as its
+# kernels (at the price of the two-stream overlap).  Off (the default) costs one attribute test per phase.
+_ROCTX = int(os.environ.get("MV_ROCTX", "0") or 0)
+_phase_open = [False]
+
+
+def phase(name):
+    """Close the open roctx range, open `name` (None: just close)."""
+    if not _ROCTX:
+        return
+    if _phase_open[0]:
+        if _ROCTX >= 2:
+            torch.cuda.synchronize()
+        torch.cuda.nvtx.range_pop()
+        _phase_open[0] = False
+    if name is not None:
+        torch.cuda.nvtx.range_push(name)
+        _phase_open[0] = True
+
+
 # The engine's extra HIP streams are shared by every Engine of the process (engines never run concurrently).  HIP hands streams to a
 # fixed number of hardware queues round-robin in creation order; a second model's streams could land on the queue of the first one's main
 # stream and serialise its backward (measured in bench.py: the second model of a process ran L = 768 steps at 40.7 ms instead of 35.8).
@@ -181,6 +206,7 @@ class Engine:
         self._gemm_ws = {}             # split-K workspaces, one per stream that runs split-K GEMMs (never shared across streams)
         self._side = None             # side HIP stream for the weight-gradient GEMMs of the backward
         self.training = False         # dropout is active only when True (CXRBERT.train() / TrainStep(train=True))
+        self.keep_acts = True         # False: the forward keeps no per-layer activations (inference; see encoder_forward)
         # dropout stream: keyed by torch's seed (set_seed of utils/utils.py:9-16 -> torch.manual_seed), a per-rank offset
         # added by TrainStep under data parallelism, and a counter advanced once per forward (every step draws fresh masks)
         # f16 forward path: the encoder layers' LayerNorm inputs (residual sums, written by the output-projection / FFN-down GEMMs
@@ -518,6 +544,7 @@ class Engine:
                     ev = torch.cuda.Event()
                     ev.record(ms)
                     db_ev.append((dbl, ev))
+        phase("embed")
         imgproj = self._buf("imgproj", (B * N, H), fadt)
         # first reader of the embeddings parameter range: everything above (row plan, mask words, keep-bits of every layer) did not need
         # the optimizer's first kernel (113 us over the word table) and ran under it
@@ -528,13 +555,22 @@ class Engine:
         x, x_b = self._pair("x0", (M, H))
         pre0 = self._buf("pre0", (M, H), f32)
         mean0, rstd0 = self._buf("mean0", (M,), f32), self._buf("rstd0", (M,), f32)
+        pdi = S["p_drop_img"] = (pd if cfg.img_dropout < 0 else (float(cfg.img_dropout) if self.training else 0.0))
+        if not cfg.img_position:
+            S["img_pos"] = None                  # args.img_postion false: no position embedding on the image rows
         ops.embed_fwd(self.fdt, S["cls_tok"], S["txt"], S["segment"], S["img_pos"], S["sep_tok"], imgproj,
                       wf[e + "word_embeddings.weight"], wf[e + "position_embeddings.weight"],
                       wf[e + "token_type_embeddings.weight"], self.p[e + "LayerNorm.weight"], self.p[e + "LayerNorm.bias"],
                       x, pre0, mean0, rstd0, B, N, T, H, cfg.vocab_size, cfg.max_pos, cfg.ln_eps, p_drop=pd,
-                      drop_key=dk[(self.SITE_EMB, 0)], rowmap=rowmap, n_rows=M, x0_bf16=xb2(x, x_b))
+                      drop_key=dk[(self.SITE_EMB, 0)], rowmap=rowmap, n_rows=M, x0_bf16=xb2(x, x_b), p_drop_img=pdi)
         S["layers"] = []
+        # keep_acts False (a forward nothing will back-propagate through: torch.no_grad() / eval scoring): the per-layer activations are
+        # not kept -- every layer writes the same scratch set (12 x 0.95 GB -> 0.95 GB at B = 64, L = 512) and S["layers"] is not a
+        # valid input of encoder_backward
+        keep = S["keep"] = bool(self.keep_acts)
         for l in range(cfg.layers):
+            lk = l if keep else "_nk"
+            phase(f"layer{l}.attention")
             self._wait_opt(f"layer{l}")
             p = f"enc.encoder.layer.{l}."
             Wqkv, bqkv, _, _ = self.qkv_views(l, fwd=True)
@@ -548,12 +584,12 @@ class Engine:
                     ops.gather_rows(x_b, H, tq[0], M, H, xp_b, H)
                 x, x_b = xp, xp_b
             a_["x"] = x_b
-            qkv, qkv_b = self._pair(f"qkv{l}", (M, 3 * H))
+            qkv, qkv_b = self._pair(f"qkv{lk}", (M, 3 * H))
             a_["qkv"] = qkv_b
             ops.gemm(x, Wqkv, qkv, M=M, N=3 * H, K=H, bias=bqkv, epi=EPI_BIAS, c3=xb2(qkv, qkv_b))
-            ctx, ctx_b = self._pair(f"ctx{l}", (M, H))
+            ctx, ctx_b = self._pair(f"ctx{lk}", (M, H))
             a_["ctx"] = ctx_b
-            lse = a_["lse"] = self._buf(f"lse{l}", (B, A, Lq), f32)
+            lse = a_["lse"] = self._buf(f"lse{lk}", (B, A, Lq), f32)
             a_["dropbits"] = None
             if db_ev is not None:
                 a_["dropbits"] = db_ev[l][0]
@@ -576,32 +612,34 @@ class Engine:
             a_["rows"] = Mr
             M_all, M = M, Mr        # (restored after the layer; nothing follows the last layer)
             pre_dt = self.fadt if (self.fdt == MV_F16 and self.ln_in_16) else f32
-            pre1 = a_["pre1"] = self._buf(f"pre1_{l}" + ("h" if pre_dt != f32 else ""), (M, H), pre_dt)
+            pre1 = a_["pre1"] = self._buf(f"pre1_{lk}" + ("h" if pre_dt != f32 else ""), (M, H), pre_dt)
             ops.gemm(ctx, wf[p + "attention.output.dense.weight"], pre1, M=M, N=H, K=H,
                      bias=self.p[p + "attention.output.dense.bias"], epi=EPI_BIAS_RES, r=x, p_drop=pd,
                      drop_key=dk[(self.SITE_OUT1, l)])
-            a1, a1_b = self._pair(f"a{l}", (M, H))
+            a1, a1_b = self._pair(f"a{lk}", (M, H))
             a_["a"] = a1_b
-            a_["mean1"], a_["rstd1"] = self._buf(f"mean1_{l}", (M,), f32), self._buf(f"rstd1_{l}", (M,), f32)
+            a_["mean1"], a_["rstd1"] = self._buf(f"mean1_{lk}", (M,), f32), self._buf(f"rstd1_{lk}", (M,), f32)
             ops.layernorm_fwd(pre1, self.p[p + "attention.output.LayerNorm.weight"], self.p[p + "attention.output.LayerNorm.bias"],
                               a1, a_["mean1"], a_["rstd1"], M, H, cfg.ln_eps, y_bf16=xb2(a1, a1_b))
-            act, act_b = self._pair(f"i{l}", (M, I))
+            phase(f"layer{l}.ffn")
+            act, act_b = self._pair(f"i{lk}", (M, I))
             a_["i"] = act_b
             # the second output is gelu'(z), not z: the derivative shares the forward's exp / reciprocal, and the backward
             # GEMM then only multiplies by it (an elementwise operand: either encoding serves)
-            dg = a_["dgelu"] = self._buf(f"dgelu{l}", (M, I), fadt)
+            dg = a_["dgelu"] = self._buf(f"dgelu{lk}", (M, I), fadt)
             ops.gemm(a1, wf[p + "intermediate.dense.weight"], act, M=M, N=I, K=H, bias=self.p[p + "intermediate.dense.bias"],
                      epi=EPI_BIAS_GELU_D, c2=dg, c3=xb2(act, act_b))
-            pre2 = a_["pre2"] = self._buf(f"pre2_{l}" + ("h" if pre_dt != f32 else ""), (M, H), pre_dt)
+            pre2 = a_["pre2"] = self._buf(f"pre2_{lk}" + ("h" if pre_dt != f32 else ""), (M, H), pre_dt)
             ops.gemm(act, wf[p + "output.dense.weight"], pre2, M=M, N=H, K=I, bias=self.p[p + "output.dense.bias"],
                      epi=EPI_BIAS_RES, r=a1, p_drop=pd, drop_key=dk[(self.SITE_OUT2, l)])
-            x, x_b = self._pair(f"x{l + 1}", (M, H))
-            a_["mean2"], a_["rstd2"] = self._buf(f"mean2_{l}", (M,), f32), self._buf(f"rstd2_{l}", (M,), f32)
+            x, x_b = self._pair(f"x{l + 1}" if keep else f"x_pp{l & 1}", (M, H))
+            a_["mean2"], a_["rstd2"] = self._buf(f"mean2_{lk}", (M,), f32), self._buf(f"rstd2_{lk}", (M,), f32)
             ops.layernorm_fwd(pre2, self.p[p + "output.LayerNorm.weight"], self.p[p + "output.LayerNorm.bias"], x, a_["mean2"],
                               a_["rstd2"], M, H, cfg.ln_eps, y_bf16=xb2(x, x_b))
             M = M_all
             S["layers"].append(a_)
         S["hidden_f"], S["hidden"] = x, x_b
+        phase("heads")
         pooled, pooled_b = self._pair("pooled", (B, H))
         S["pooled_f"], S["pooled"] = pooled, pooled_b
         if S["sel"] is not None:
@@ -800,6 +838,8 @@ class Engine:
             stats.record_stream(side)
             with torch.cuda.stream(side):
                 self._itm_head(stats, is_aligned, B, itm_scale, itm_scale_dev, compute_grad)
+                itm_ev = torch.cuda.Event()       # main joins the ITM head alone, not what _mlm_backward queues behind it on this stream
+                itm_ev.record(side)
         if R > 0:
             if compact:
                 xr, xr_b = S["hidden_f"][:R], S["hidden"][:R]
@@ -822,7 +862,7 @@ class Engine:
         if side is main:
             self._itm_head(stats, is_aligned, B, itm_scale, itm_scale_dev, compute_grad)
         else:
-            main.wait_stream(side)
+            main.wait_event(itm_ev)     # (the tied decoder's dW, the decoder-bias sums and the transform's dW stay off the main chain: _dE_ev)
         return stats
 
     def _itm_head(self, stats, is_aligned, B, itm_scale, itm_scale_dev, compute_grad):
@@ -846,6 +886,8 @@ class Engine:
         bucket_hook(name, event) is called when the gradients of a contiguous parameter range are final on the side
         stream ('heads', 'layer<l>', 'embeddings') so a data-parallel driver can start its all-reduce."""
         cfg, S = self.cfg, self.S
+        if not S.get("keep", True):
+            raise RuntimeError("encoder_backward after a forward that kept no activations (Engine.keep_acts = False / torch.no_grad())")
         H, A, I, D = cfg.hidden, cfg.heads, cfg.intermediate, cfg.img_hidden
         dh = H // A
         B, Lq, M, N, T = S["B"], S["L"], S["M"], S["N"], S["T"]
@@ -868,7 +910,8 @@ class Engine:
             return ev
 
         if bucket_hook:
-            bucket_hook("heads", None)
+            # the MLM head's parameter gradients were written on the side stream (heads_train joins the ITM head only)
+            bucket_hook("heads", side_done() if side is not main else None)
         use_w2t = self.dz_nt and self.is16
         mfma_on = self.fused_colsum and self.is16 and ops.get_impl() == 0       # partial column sums exist in the MFMA kernels only
         if use_w2t:
@@ -884,6 +927,7 @@ class Engine:
         for l in reversed(range(cfg.layers)):
             p = f"enc.encoder.layer.{l}."
             a_ = S["layers"][l]
+            phase(f"backward.layer{l}")
             Wqkv, _, gWqkv, gbqkv = self.qkv_views(l)
             # the last layer's per-row part ran on the consumed rows only (encoder_forward, tail_rows): so does its backward
             tail = a_["rows"] != M_all
@@ -964,6 +1008,7 @@ class Engine:
                 # LayerNorm / bias gradients of the layer were written on the main stream, the weights on the side stream
                 bucket_hook(f"layer{l}", ev_layer)
         e = "enc.txt_embeddings."
+        phase("backward.embed")
         dimg = self._buf("bw_dimg", (B * N, H), adt)
         if getattr(self, "_dE_ev", None) is not None:
             main.wait_event(self._dE_ev)      # the decoder's word-embedding gradient (written, not accumulated) is in place
@@ -972,13 +1017,15 @@ class Engine:
                       self.p[e + "LayerNorm.weight"], S["cls_tok"], S["txt"], S["segment"], S["img_pos"], S["sep_tok"],
                       g[e + "word_embeddings.weight"], g[e + "position_embeddings.weight"], g[e + "token_type_embeddings.weight"],
                       g[e + "LayerNorm.weight"], g[e + "LayerNorm.bias"], dimg, B, N, T, H, cfg.vocab_size, cfg.max_pos,
-                      pad_token_id=0, p_drop=pd, drop_key=dk[(self.SITE_EMB, 0)], rowmap=S["rowmap"], n_rows=M, unscale=us)
+                      pad_token_id=0, p_drop=pd, drop_key=dk[(self.SITE_EMB, 0)], rowmap=S["rowmap"], n_rows=M, unscale=us,
+                      p_drop_img=S["p_drop_img"])
         main.wait_stream(side)              # every weight gradient is final; the split-K workspace is ours again
         if N > 0:
             ops.colsum(dimg, H, B * N, H, g["enc.img_embeddings.img_embeddings.bias"], accumulate=True, unscale=us)
             self._dW(dimg, S["feats"], g["enc.img_embeddings.img_embeddings.weight"], H, D, B * N, lda=H, ldb=D)
         if bucket_hook:
             bucket_hook("embeddings", None)
+        phase(None)
 
     # ------------------------------------------------------------------ optimizer
     def check_overflow(self):
@@ -987,6 +1034,7 @@ class Engine:
         synchronisation; under data parallelism every rank sees the same all-reduced gradient and decides alike."""
         if self.scaler is None:
             return
+        phase("overflow_check")
         # (counting everything but the embeddings bucket on the side stream under the embedding backward was measured: no change)
         ops.count_nonfinite(self.flat_g, self.scaler[6:7])
         ops.scaler_update(self.scaler, growth_interval=self.scale_growth_interval)
@@ -1003,6 +1051,7 @@ class Engine:
         under the next step's first layers (MFMA-bound).  Anything else that reads parameters on the current stream must call
         `wait_optimizer()` first (CXRBERT.state_dict / save / load do)."""
         self.ensure_opt()
+        phase("optimizer")
         scaler_state = self.scaler if (use_scaler and self.scaler is not None) else None
         if not (overlap and self.device.type == "cuda" and os.environ.get("MV_SINGLE_STREAM") != "1"):
             self.wait_optimizer()
@@ -1010,6 +1059,7 @@ class Engine:
                            weight_decay, step, correct_bias, grad_scale, shadow_f16=self.shadow_f, scaler_state=scaler_state)
             self.shadow_dirty = False
             self.refresh_w2t()
+            phase(None)
             return
         from .dist import bucket_ranges
         cfg = self.cfg
@@ -1042,6 +1092,7 @@ class Engine:
         self._opt_ev = evs
         self._w2t_ev, self._w2t_stale = evs["heads"], False
         self.shadow_dirty = False
+        phase(None)
 
     def _wait_opt(self, name):
         """Current stream waits for the optimizer's kernel over parameter range `name` (overlapped AdamW), once."""

@@ -59,6 +59,24 @@ def mask_build(desc, B, Lq, bits, tileinfo):
     L.check(rc, "mv_mask_build")
 
 
+def mask_verify_host(mask, desc, threads=4):
+    """HOST tensors: int64 [B,L,L] / [B,L] reference mask against int32 [B,3] descriptors (see mv_mask_verify_host).
+    -> -1 when every entry agrees, else the linear index of the first mismatch.  Pure host work; releases the GIL."""
+    import ctypes
+    if mask.is_cuda or desc.is_cuda or mask.dtype != torch.int64 or desc.dtype != torch.int32:
+        raise TypeError("mask_verify_host: host int64 mask and host int32 [B,3] descriptors")
+    if mask.dim() not in (2, 3):
+        raise NotImplementedError          # cxrbert_origin.py:80-81
+    B, Lq = mask.shape[0], mask.shape[-1]
+    if tuple(desc.shape) != (B, 3):
+        raise TypeError("desc must be int32 [B,3]")
+    mask, desc = mask.contiguous(), desc.contiguous()
+    out = ctypes.c_longlong(0)
+    rc = _lib().mv_mask_verify_host(mask.data_ptr(), mask.dim(), desc.data_ptr(), B, Lq, int(threads), ctypes.byref(out))
+    L.check(rc, "mv_mask_verify_host")
+    return int(out.value)
+
+
 def mlm_draws(key, B, S, vocab, device):
     """(u f32 [B,S], rnd int32 [B,S]): the counter-based stand-ins for random_word's two random sources."""
     u = torch.empty((B, S), dtype=torch.float32, device=device)
@@ -195,21 +213,25 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dx, dgamma, dbeta, colsum, M, H, dx_
 
 
 def embed_fwd(dt, cls_tok, txt, segment, img_pos, sep_tok, imgproj, E, P, Ty, gamma, beta, x0, pre, mean, rstd, B, N, T, H, V,
-              maxpos, eps, p_drop=0.0, drop_key=0, rowmap=None, n_rows=0, x0_bf16=None):
+              maxpos, eps, p_drop=0.0, drop_key=0, rowmap=None, n_rows=0, x0_bf16=None, p_drop_img=None):
+    """img_pos None: the image rows get no position embedding (args.img_postion false); p_drop_img: dropout probability of the image
+    rows (args.dropout_prob, cxrbert_origin.py:19; default = p_drop)."""
     if any(L.dt_of(t) != dt for t in (E, P, Ty, x0)) or (imgproj is not None and L.dt_of(imgproj) != dt):
         raise TypeError("embed_fwd: tables, imgproj and x0 must be in the encoding `dt`")
     rc = _lib().mv_embed_fwd(dt, L.ptr(cls_tok), L.ptr(txt), L.ptr(segment), L.ptr(img_pos), L.ptr(sep_tok), L.ptr(imgproj),
                              L.ptr(E), L.ptr(P), L.ptr(Ty), L.ptr(gamma), L.ptr(beta), L.ptr(x0), L.ptr(x0_bf16), L.ptr(pre), L.ptr(mean),
-                             L.ptr(rstd), B, N, T, H, V, maxpos, float(eps), float(p_drop), int(drop_key), L.ptr(rowmap), int(n_rows),
+                             L.ptr(rstd), B, N, T, H, V, maxpos, float(eps), float(p_drop),
+                             float(p_drop if p_drop_img is None else p_drop_img), int(drop_key), L.ptr(rowmap), int(n_rows),
                              L.stream_ptr())
     L.check(rc, "mv_embed_fwd")
 
 
 def embed_bwd(dt, dx0, pre, mean, rstd, gamma, cls_tok, txt, segment, img_pos, sep_tok, dE, dP, dTy, dgamma, dbeta, dimgproj, B,
-              N, T, H, V, maxpos, pad_token_id=0, p_drop=0.0, drop_key=0, rowmap=None, n_rows=0, unscale=None):
+              N, T, H, V, maxpos, pad_token_id=0, p_drop=0.0, drop_key=0, rowmap=None, n_rows=0, unscale=None, p_drop_img=None):
     rc = _lib().mv_embed_bwd(dt, L.ptr(dx0), L.ptr(pre), L.ptr(mean), L.ptr(rstd), L.ptr(gamma), L.ptr(cls_tok), L.ptr(txt),
                              L.ptr(segment), L.ptr(img_pos), L.ptr(sep_tok), L.ptr(dE), L.ptr(dP), L.ptr(dTy), L.ptr(dgamma),
-                             L.ptr(dbeta), L.ptr(dimgproj), B, N, T, H, V, maxpos, int(pad_token_id), float(p_drop), int(drop_key),
+                             L.ptr(dbeta), L.ptr(dimgproj), B, N, T, H, V, maxpos, int(pad_token_id), float(p_drop),
+                             float(p_drop if p_drop_img is None else p_drop_img), int(drop_key),
                              L.ptr(rowmap), int(n_rows), L.ptr(unscale), L.stream_ptr())
     L.check(rc, "mv_embed_bwd")
 

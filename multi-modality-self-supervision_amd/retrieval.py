@@ -24,7 +24,8 @@ class CXRBertForRetrieval(nn.Module):
         return m
 
     def forward(self, cls_tok, input_txt, attn_mask, segment, input_img, sep_tok):
-        """-> ITM logits [B,2] (retrieval.py:26-31: `_, cls, _ = self.enc(...); return self.itm(cls)`)."""
+        """-> ITM logits [B,2] (retrieval.py:26-31: `_, cls, _ = self.enc(...); return self.itm(cls)` -- that literal form works
+        too, `enc` and `itm` are callable; this is the same arithmetic as ONE autograd node, without the hand-over tensors)."""
         return self.bert._itm_only(cls_tok, input_txt, attn_mask, segment, input_img, sep_tok)
 
     @torch.no_grad()
@@ -36,7 +37,7 @@ class CXRBertForRetrieval(nn.Module):
         eng = self.bert.engine
         if isinstance(attn_mask, MaskDesc) and eng.is16 and attn_mask.packable():
             feats, pos = self.bert._regions(input_img)
-            eng.training = False
+            eng.training, eng.keep_acts = False, False
             eng.encoder_forward(cls_tok, input_txt, attn_mask, segment, feats, pos, sep_tok, pack=True)
             logits = eng._itm_forward().clone()
         else:

@@ -56,26 +56,15 @@ class TrainStep:
             rows, ids = D.label_index(batch["txt_labels"])
         return rows.to(dev), ids.to(dev), batch["is_aligned"].to(dev, torch.int32)
 
-    def __call__(self, batch, train=True, verify=None, agree=False):
+    def __call__(self, batch, train=True, use_desc=True):
         """batch: dict with the reference's batch fields (cls_tok, input_txt, attn_mask, segment,
-        img_feats, img_pos, sep_tok, txt_labels, is_aligned) [+ label_rows/label_ids].
+        img_feats, img_pos, sep_tok, txt_labels, is_aligned) [+ label_rows/label_ids] [+ attn_desc].
         Returns the device tensor stats f32[6] = [mlm_nll_sum, n_lab, mlm_correct, itm_nll_sum, B, itm_correct]
         (local to this rank); no host sync happens here.
-        verify (optional callable -> bool): called after the forward and backward have been enqueued and before the
-        optimizer; when it returns False the step is redone with batch["attn_mask"] instead of batch["attn_desc"]
-        (CXRBERT_Trainer uses it to check, off the critical path, that descriptors it derived from a materialised
-        mask describe that mask bit for bit).  agree: under data parallelism, all-reduce the outcome so that every rank takes
-        the same branch; the caller must pass the same `agree` on every rank."""
-        stats = self._run(batch, train, use_desc=True)
-        if verify is not None or agree:
-            ok = True if verify is None else bool(verify())
-            if agree and self.dp is not None:
-                # the first _run has already issued this step's collectives: a rank that redid the step on its own would issue a
-                # second set while its peers moved on.  `agree` is set by the caller on EVERY rank for this step (whether or not
-                # the rank has something to verify): all ranks agree (MIN) and redo the step together.
-                ok = self.dp.all_agree(ok)
-            if not ok:
-                stats = self._run(batch, train, use_desc=False)
+        use_desc=False: ignore batch["attn_desc"] and run on the materialised batch["attn_mask"] (padded rows).  Which of the two a
+        rank takes changes no collective (same count all-reduce, same gradient buckets), so under data parallelism every rank
+        decides for itself (CXRBERT_Trainer does, from its host-side check of the shipped matrix)."""
+        stats = self._run(batch, train, use_desc=use_desc)
         if train:
             self.step_cnt += 1
             # f16 gradients: overflow check of the (all-reduced) flat gradient, device-side skip / loss-scale decision
@@ -94,6 +83,7 @@ class TrainStep:
             self.dp.timing = self.time_exchange
         rows, ids, aligned = self._prep(batch)
         eng.training = bool(train and self.model.training)      # dropout like the reference's model.train()
+        eng.keep_acts = bool(train)                              # eval steps keep no per-layer activations
         zero_ev = None
         if train:
             # the flat gradient is cleared on the engine's side stream, which is idle during the forward; the heads wait for it
@@ -133,7 +123,10 @@ class TrainStep:
         if train:
             eng.encoder_backward(bucket_hook=self.dp.hook if self.dp is not None else None)
             if self.dp is not None:
+                from .engine import phase
+                phase("exchange")          # roctx range (MV_ROCTX): the wait for the outstanding gradient buckets
                 self.dp.finish()
+                phase(None)
         return stats
 
 
@@ -179,46 +172,55 @@ class CXRBERT_Trainer:
         self.step = TrainStep(self.model, lr=getattr(args, "lr", 1e-5), distributed=self.distributed, mlm_task=self.mlm_task,
                               overlap_optimizer=True,
                               itm_task=self.itm_task)
-        self.recognise_masks = True     # derive {family, n2, vl} descriptors from the Dataset's materialised masks (verified)
-        self.n_recognised = 0
-        # how the derived descriptors are checked against the shipped matrices (see _recognise_masks): "full" = every entry of
-        # every batch on the device (134 MB over PCIe per step at B=64, L=512), "sampled" = every entry of the first
-        # `verify_first` batches and of every `verify_every`-th one, probe rows on the host otherwise, "off" = probes only
-        self.verify_masks = getattr(args, "verify_masks", "sampled")
-        self.verify_first, self.verify_every, self.verify_probes = 2, 64, 4
-        self._mask_batches, self._full_check = 0, True
+        self._init_mask_policy(args)
         self._pinned = {}
-        self._vstream = None
         self.log_freq = getattr(args, "log_freq", 10)
         self.logger = logger            # optional callable(dict, step=epoch): stands in for wandb.log
         print("Total Parameters:", sum(p.nelement() for p in self.model.parameters()))
 
-    def _check_policy(self):
-        """Counts the batch and decides whether it gets the every-entry device check; a function of the batch count alone, so
-        that the ranks of a data-parallel job decide alike (they then agree on the outcome with one collective)."""
-        self._mask_batches += 1
-        self._full_check = self.verify_masks == "full" or (self.verify_masks == "sampled" and (
-            self._mask_batches <= self.verify_first or self._mask_batches % self.verify_every == 0))
-        return self._full_check
+    def _init_mask_policy(self, args):
+        """Host-side state of the mask recognition / verification (no device needed: tests/test_host_logic.py drives it on the CPU)."""
+        self.recognise_masks = True     # derive {family, n2, vl} descriptors from the Dataset's materialised masks (verified)
+        self.n_recognised = 0           # batches whose masks were recognised as one of the closed-form families
+        self.n_rejected = 0             # ... of which the every-entry check then found a deviating entry (ran on the matrix instead)
+        # How the derived descriptors are checked against the shipped matrices (see _recognise_masks / _ticket):
+        #   "full" (default)  EVERY entry of EVERY batch, on the host (mv_mask_verify_host: one pass over the 134 MB at memory speed on
+        #                     `verify_threads` worker threads), one batch AHEAD of the step, so the result is known before the step is
+        #                     enqueued: nothing crosses PCIe, nothing is redone, no rank has to agree with another
+        #   "sampled"         every entry of the first `verify_first` batches and of every `verify_every`-th one, `verify_probes` random
+        #                     rows per sample otherwise (explicit opt-in: a foreign mask that matches a family on the probes only would
+        #                     train with the closed form on the unchecked batches)
+        #   "off"             the probe lines of the recognition only
+        self.verify_masks = getattr(args, "verify_masks", "full")
+        if self.verify_masks not in ("full", "sampled", "off"):
+            raise ValueError("args.verify_masks must be 'full', 'sampled' or 'off'")
+        self.verify_first, self.verify_every, self.verify_probes = 2, 64, 4
+        self.verify_threads = int(getattr(args, "verify_threads", 4))
+        self._mask_batches = {True: 0, False: 0}     # train / eval batches seen (the sampled policy counts them separately)
+        self._pool = None
 
-    def _recognise_masks(self, attn_masks, input_ids, N, txt_labels=None):
+    def _full_check_now(self, train):
+        """Counts the batch (training and evaluation batches separately) and says whether it gets the every-entry check."""
+        self._mask_batches[train] += 1
+        n = self._mask_batches[train]
+        return self.verify_masks == "full" or (self.verify_masks == "sampled" and (n <= self.verify_first or n % self.verify_every == 0))
+
+    def _recognise_masks(self, attn_masks, input_ids, N, txt_labels=None, probe_seed=None):
         """The reference Dataset ships a materialised int64 mask per sample (dataset_origin.py:138-176: 134 MB per batch at
         B=64, L=512).  Its five families are closed forms of {family, n2, vl}: derive the descriptors from a few probe
-        entries on the host (two rows and a column per sample, all samples at once), let the step run on them (packed rows,
-        mask bits built on the device).  `verify` then checks the descriptors against the shipped matrix: EVERY entry, on the
-        device, on a side stream (`self.verify_masks == "full"`, or the first `verify_first` batches and every
-        `verify_every`-th one under the default "sampled" policy); the other batches are checked on the host on the three
-        probe lines plus `verify_probes` random rows per sample -- no 134 MB host-to-device copy on those steps.  A mask
-        outside the families -- or any mismatch -- falls back to the matrix itself.
-        Returns (MaskDesc, verify callable or None) or (None, None)."""
+        entries on the host (two rows and a column per sample, all samples at once) so that the step can run on them (packed
+        rows, mask bits built on the device).  probe_seed (the "sampled" policy's cheap batches): `verify_probes` random rows per
+        sample are compared with the closed form as well.  A mask outside the families returns None.
+        The descriptors are a HYPOTHESIS until `_ticket`'s every-entry check has confirmed them.
+        Returns MaskDesc or None."""
         m = attn_masks
         if not torch.is_tensor(m) or m.dtype != torch.int64 or m.dim() not in (2, 3) or m.is_cuda:
-            return None, None
+            return None
         B, L = m.shape[0], m.shape[-1]
         S = L - N - 3
         n2 = N + 2
         if S < 1 or input_ids.shape[1] != S + 1:
-            return None, None
+            return None
         # numpy views of the host tensors: the probes touch a few KB of the 134 MB matrix, and torch's CPU operators would hand each of
         # these tiny jobs to its OpenMP pool (measured on the 16-core share of a GPU box: 3 ms .. 90 ms per batch, and the kernel
         # launches of the step that follows slowed down 3-5x by the spinning workers)
@@ -236,11 +238,11 @@ class CXRBERT_Trainer:
         if txt_labels is not None and torch.is_tensor(txt_labels):
             lab = txt_labels.cpu().numpy() != -100
             if lab.shape == (B, L) and bool((lab & (j >= vl.reshape(B, 1))).any()):
-                return None, None          # a label after the derived valid length: the packed rows would drop it
+                return None          # a label after the derived valid length: the packed rows would drop it
         full_row = (j < vl.reshape(B, 1)).astype(np.int64)
         if m.dim() == 2:
             if not np.array_equal(mn, full_row):
-                return None, None
+                return None
             fam_id = np.full((B,), D.FAMILY_ID["1d"], dtype=np.int32)
         else:
             r0, rl, cl = mn[:, 0, :], mn[:, L - 1, :], mn[:, :, L - 1]
@@ -258,17 +260,10 @@ class CXRBERT_Trainer:
             for cond, name in ((is_non, "noncross"), (is_bar, "bar"), (is_s2s, "s2s"), (is_full, "full")):
                 fam_id = np.where(cond, np.int32(D.FAMILY_ID[name]), fam_id).astype(np.int32)
             if bool((fam_id < 0).any()):
-                return None, None
-        dn = np.empty((B, 3), dtype=np.int32)
-        dn[:, 0], dn[:, 1], dn[:, 2] = fam_id, n2, vl.astype(np.int32)
-        d = torch.from_numpy(dn)
-        desc = D.MaskDesc(d, L, host=d)          # uploaded with the batch's other integer fields (_upload_small)
-        if self.verify_masks == "off":
-            return desc, None
-        if not self._full_check:
-            # host-side spot check of `verify_probes` random rows per sample against the closed forms
-            if m.dim() == 3 and self.verify_probes > 0:
-                rng = np.random.default_rng(self._mask_batches)
+                return None
+            if probe_seed is not None and self.verify_probes > 0:
+                # host-side spot check of `verify_probes` random rows per sample against the closed forms
+                rng = np.random.default_rng(probe_seed)
                 rows = rng.integers(0, L, size=(B, self.verify_probes))
                 got = mn[np.arange(B).reshape(B, 1), rows]                      # [B, P, L]
                 i_ = rows.reshape(B, -1, 1)
@@ -278,29 +273,55 @@ class CXRBERT_Trainer:
                        np.where(f == 2, (i_ < n2) | (jj < n2) | (jj <= i_),
                        np.where(f == 3, (i_ < n2) == (jj < n2), jj < vl.reshape(B, 1, 1))))
                 if not np.array_equal(got != 0, want):
-                    return None, None
-            return desc, None
-        state = {}
+                    return None
+        dn = np.empty((B, 3), dtype=np.int32)
+        dn[:, 0], dn[:, 1], dn[:, 2] = fam_id, n2, vl.astype(np.int32)
+        d = torch.from_numpy(dn)
+        return D.MaskDesc(d, L, host=d)          # uploaded with the batch's other integer fields (_upload_small)
 
-        def verify():
-            # after the step's kernels are enqueued: ship the matrix on the side stream, pack it, compare with the bits the
-            # forward built from the descriptors (still in the engine's workspace), read one flag
+    def _ticket(self, data, train):
+        """Host-side look at a batch BEFORE its step: derive the mask descriptors and start the every-entry check of the shipped
+        matrix against them on a worker thread (one GIL-free C call; `_prefetch` issues this one batch ahead, so it runs under
+        the launches of the previous step).  -> {"data", "desc", "check"}: `check` is a future of the first mismatching entry
+        (-1: none) or None when this batch is not checked entry by entry."""
+        t = {"data": data, "desc": None, "check": None}
+        attn_masks = data[3]
+        if not self.recognise_masks or isinstance(attn_masks, D.MaskDesc):
+            return t
+        full = self._full_check_now(train)
+        img = data[4]
+        N = self.args_num_regions(img)
+        probe = None if (full or self.verify_masks == "off") else self._mask_batches[train]
+        desc = self._recognise_masks(attn_masks, data[1], N, data[2], probe_seed=probe) if N is not None else None
+        if desc is None:
+            return t
+        t["desc"] = desc
+        if full:
             from . import hip_ops as ops
-            eng = self.model.engine
-            if self._vstream is None:
-                self._vstream = torch.cuda.Stream(device=self.device)
-            ev = eng.S["bits_ev"]                  # recorded right after the forward built its mask bits
-            with torch.cuda.stream(self._vstream):
-                md = m.to(self.device, non_blocking=True)
-                W32, Tt = (L + 31) // 32, (L + 63) // 64
-                bits = torch.empty((B, L, W32), dtype=torch.int32, device=self.device)
-                tinfo = torch.empty((B, Tt, Tt), dtype=torch.uint8, device=self.device)
-                ops.mask_pack(md, bits, tinfo)
-                self._vstream.wait_event(ev)
-                same = torch.equal(bits, eng.S["bits"][:B])       # host sync on this stream only
-            state["ok"] = bool(same)
-            return state["ok"]
-        return desc, verify
+            if self._pool is None:
+                from concurrent.futures import ThreadPoolExecutor
+                self._pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="medvill-maskcheck")
+            t["check"] = self._pool.submit(ops.mask_verify_host, attn_masks, desc.host_desc(), self.verify_threads)
+        return t
+
+    def args_num_regions(self, img):
+        """Number of image regions N of a batch without running the region encoder: region features [B,N,D] carry it; for pixel
+        batches it is what ImageEncoder_cnn will sample (args.num_image_embeds, models/image.py:63-68)."""
+        if isinstance(img, (tuple, list)) and len(img) == 2 and torch.is_tensor(img[0]):
+            return int(img[0].shape[1])
+        n = getattr(self.args, "num_image_embeds", None)
+        return int(n) if n else None
+
+    def _prefetch(self, loader, train):
+        """The loader's batches with their tickets, the ticket of batch k+1 issued before batch k is handed out."""
+        it = iter(loader)
+        nxt = next(it, None)
+        tk = self._ticket(nxt, train) if nxt is not None else None
+        while tk is not None:
+            cur = tk
+            nxt = next(it, None)
+            tk = self._ticket(nxt, train) if nxt is not None else None
+            yield cur
 
     def _stage(self, key, n, dtype):
         """One of two reused pinned staging buffers of >= n elements (the copy that last used it has finished)."""
@@ -324,7 +345,9 @@ class CXRBERT_Trainer:
         slot[2][i].record(torch.cuda.current_stream())
         return d
 
-    def _to_batch(self, data):
+    def _to_batch(self, ticket):
+        """-> (batch dict, use_desc).  Waits for the ticket's mask check: a single deviating entry sends the step to the matrix."""
+        data = ticket["data"]
         cls_tok, input_ids, txt_labels, attn_masks, img, segment, is_aligned, sep_tok = data[:8]
         if torch.is_tensor(img):     # pixels [B,3,H,W] (dataset_origin.py:85-89): region features from the mirrored CNN
             if self.model.img_encoder is None:
@@ -336,18 +359,17 @@ class CXRBERT_Trainer:
             feats = self._upload(feats)
         batch = dict(cls_tok=cls_tok, input_txt=input_ids, attn_mask=attn_masks, segment=segment, img_feats=feats, img_pos=pos,
                      sep_tok=sep_tok, txt_labels=txt_labels, is_aligned=is_aligned)
-        verify = None
         if isinstance(attn_masks, D.MaskDesc):             # a loader that already ships descriptors
             batch["attn_desc"], batch["attn_mask"] = attn_masks, None
-        else:
-            if self.recognise_masks:
-                self._check_policy()
-            desc, verify = self._recognise_masks(attn_masks, input_ids, feats.shape[1], txt_labels) if self.recognise_masks else (None, None)
-            if desc is not None:
-                batch["attn_desc"] = desc
-                self.n_recognised += 1
+        elif ticket["desc"] is not None and ticket["desc"].L == feats.shape[1] + input_ids.shape[1] + 2:
+            self.n_recognised += 1
+            bad = ticket["check"].result() if ticket["check"] is not None else -1
+            if bad < 0:
+                batch["attn_desc"] = ticket["desc"]
+            else:
+                self.n_rejected += 1            # the matrix is not the closed form the probes suggested: it is the mask that counts
         self._upload_small(batch)
-        return batch, verify
+        return batch, ("attn_desc" in batch)
 
     def _upload_small(self, batch):
         """Every small integer field of a HOST batch (token ids, labels, segment, positions, the labelled-row index, mask
@@ -356,15 +378,17 @@ class CXRBERT_Trainer:
         serialised the host with the GPU (47-75 ms per step measured against 26 ms for resident batches)."""
         names = [k for k in ("cls_tok", "input_txt", "txt_labels", "segment", "is_aligned", "sep_tok", "img_pos")
                  if torch.is_tensor(batch.get(k)) and not batch[k].is_cuda and batch[k].dtype == torch.int64]
-        if len(names) < 7:
+        # whichever of them are on the host are staged together (with pixel input the region positions come from the CNN, on the device)
+        if not names:
             return
         import numpy as np
         parts = {k: batch[k].contiguous().numpy() for k in names}
-        flat_lab = parts["txt_labels"].reshape(-1)
-        rows = np.flatnonzero(flat_lab != -100)                     # the labelled-row index: R is needed on the host anyway
-        parts["label_rows"], parts["label_ids"] = rows.astype(np.int64), flat_lab[rows]
+        if "txt_labels" in parts:
+            flat_lab = parts["txt_labels"].reshape(-1)
+            rows = np.flatnonzero(flat_lab != -100)                     # the labelled-row index: R is needed on the host anyway
+            parts["label_rows"], parts["label_ids"] = rows.astype(np.int64), flat_lab[rows]
         desc = batch.get("attn_desc")
-        if desc is not None and desc._host is not None:
+        if desc is not None and desc._host is not None and not desc.desc.is_cuda:
             parts["_desc"] = desc._host.numpy().astype(np.int64)
         n = sum(v.size for v in parts.values())
         stage, slot, i = self._stage((torch.int64, "ints"), n, torch.int64)
@@ -396,10 +420,9 @@ class CXRBERT_Trainer:
             if pending:
                 rows.extend(torch.stack(pending).double().cpu().unbind(0))
                 pending.clear()
-        for i, data in enumerate(loader):
-            batch, verify = self._to_batch(data)
-            agree = bool(train and self.distributed and self.recognise_masks and self.verify_masks != "off" and self._full_check)
-            pending.append(self.step(batch, train=train, verify=verify, agree=agree))
+        for ticket in self._prefetch(loader, train):
+            batch, use_desc = self._to_batch(ticket)
+            pending.append(self.step(batch, train=train, use_desc=use_desc))
             if len(pending) >= max(1, int(self.log_freq)):
                 flush()
         flush()

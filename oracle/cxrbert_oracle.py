@@ -55,9 +55,13 @@ class OracleConfig:
     img_hidden: int = 2048
     ln_eps: float = 1e-12        # HF bert-base config (embeddings + encoder LayerNorms)
     head_ln_eps: float = 1e-5    # cxrbert_origin.py:189-202,214 (TF-style LN of the MLM transform)
+    img_position: bool = True    # args.img_postion (sic), cxrbert_origin.py:27-31: False -> image rows add no position embedding
 
     def to_dict(self):
-        return asdict(self)
+        d = asdict(self)
+        if d["img_position"]:    # the default is left out, so the metadata of the earlier fixtures regenerates byte for byte
+            del d["img_position"]
+        return d
 
 
 CONFIGS = {
@@ -221,7 +225,10 @@ def embed(P, cfg, cls_tok, input_txt, segment, img_feats, img_pos, sep_tok, p_dr
 
     cls_o = ln_drop(word(cls_tok) + Ty[torch.zeros_like(cls_tok)] + Pos[:1][None])
     sep_o = ln_drop(word(sep_tok) + Ty[torch.zeros_like(sep_tok)] + Pos[:1][None])
-    img_o = ln_drop(F.linear(img_feats, Wi, bi) + Pos[img_pos] + Ty[0][None, None])
+    if cfg.img_position:         # cxrbert_origin.py:27-31
+        img_o = ln_drop(F.linear(img_feats, Wi, bi) + Pos[img_pos] + Ty[0][None, None])
+    else:
+        img_o = ln_drop(F.linear(img_feats, Wi, bi) + Ty[0][None, None])
     txt_o = ln_drop(word(input_txt) + Ty[segment] + Pos[:T][None])
     x = torch.cat([cls_o, img_o, sep_o, txt_o], dim=1)
     return x * masks["emb"] if masks is not None else x

@@ -17,6 +17,7 @@ Fixtures:
   c1_<fam>.npz   config C1 (2L/2H/128, L=64, B=4): hidden, pooled, ITM logits, MLM-logit
                  summaries, both losses, per-parameter gradient norms + sampled entries
   c1v1k_full.npz same model with V=1024: full logits
+  c1v1k_nopos.npz  the same with args.img_postion = False (no position embedding on the image rows), full logits + gradients
   base_s2s.npz   BERT-base L=512 B=1: losses, ITM logits, logit summaries
   base_full.npz  BERT-base L=512 B=2 ragged, bidirectional (BASELINE config 2's family) + gradients of every parameter
   base_noncross.npz  BERT-base L=512 B=1, non-cross modality mask (config 4; n2 = 38 is not tile-aligned)
@@ -116,7 +117,7 @@ def build_reference_model(cx, CfgCls, cfg: O.OracleConfig, N: int, params):
     config = CfgCls.from_pretrained("bert-base-uncased")
     args = types.SimpleNamespace(bert_model="bert-base-scratch", img_hidden_sz=cfg.img_hidden,
                                  embedding_size=cfg.hidden, hidden_size=cfg.hidden, dropout_prob=0.1,
-                                 img_postion=True, img_encoder="random-pixel", img_size=512,
+                                 img_postion=cfg.img_position, img_encoder="random-pixel", img_size=512,
                                  num_image_embeds=N, disturbing_mask=False, vocab_size=cfg.vocab_size)
     model = cx.CXRBERT(config, args)
     inner = model.enc.encoder
@@ -352,6 +353,11 @@ def main(argv=()):
     if want("c1v1k_full"):
         r = run_case(cx, CfgCls, c1v, B=4, N=16, S=45, family="full", seed=12, with_grads=True, full_logits=True)
         np.savez_compressed(os.path.join(OUT, "c1v1k_full.npz"), **r)
+    # args.img_postion = False (cxrbert_origin.py:27-31): the image rows add no position embedding
+    if want("c1v1k_nopos"):
+        c1n = O.OracleConfig(**{**c1v.to_dict(), "img_position": False})
+        r = run_case(cx, CfgCls, c1n, B=4, N=16, S=45, family="full", seed=14, with_grads=True, full_logits=True)
+        np.savez_compressed(os.path.join(OUT, "c1v1k_nopos.npz"), **r)
     # odd, non-tile-aligned geometry (L=37) to pin ragged handling
     if want("c1v1k_bar_ragged"):
         r = run_case(cx, CfgCls, c1v, B=3, N=5, S=29, family="bar", seed=13, with_grads=True, full_logits=True)

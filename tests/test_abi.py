@@ -26,7 +26,7 @@ def header_functions():
 def test_library_is_built_and_loads():
     assert os.path.exists(_lib.LIB_PATH), "run __graft_entry__.build() first"
     lib = _lib.load()
-    assert lib.mv_abi_version() == 4
+    assert lib.mv_abi_version() == 5
     assert b"gfx950" in lib.mv_build_info()
 
 

@@ -181,3 +181,50 @@ def test_one_rank_rccl_group_runs_every_collective():
     d = (p_d - p_s).abs()
     assert float(d.max()) < 3 * 2e-3 + 1e-4 and float(d.mean()) < 5e-5
     assert float(s_d[1]) == float(s_s[1]) and exposed >= 0.0
+
+
+def _trainer_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from types import SimpleNamespace
+    import medvill_amd as mv
+    V, B, N, S = 2048, 4, 6, 41
+    cfgd = dict(vocab_size=V, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=512, max_position_embeddings=64)
+
+    def tup(seed, flip=False):
+        b = mv.data.synthetic_batch(V, B, N, S, "full", seed=seed, device="cpu")
+        m = b["attn_mask"].clone()
+        if flip:
+            m[2, N + 9, N + 5] ^= 1               # deep inside the matrix: the recognition probes still say "full"
+        return (b["cls_tok"], b["input_txt"], b["txt_labels"], m, (b["img_feats"], b["img_pos"]), b["segment"], b["is_aligned"], b["sep_tok"],
+                torch.zeros(B))
+    train = [tup(100 * rank + i, flip=(rank == 1 and i == 1)) for i in range(3)]
+    evals = [tup(900 + 10 * rank + i) for i in range(1 + rank)]             # uneven: rank 0 holds one eval batch, rank 1 two
+    args = SimpleNamespace(with_cuda=True, weight_load=False, bert_model="custom", lr=1e-3, log_freq=2, mlm_task=True, itm_task=True,
+                           cuda_devices=[0], dropout_prob=0.1)
+    torch.manual_seed(3)
+    tr = mv.CXRBERT_Trainer(args, train, evals, config=cfgd, dtype=torch.bfloat16)
+    for ep in range(2):
+        res = tr.train(ep)
+    torch.cuda.synchronize()
+    out[rank] = (tr.model.engine.flat_p.cpu(), tr.n_recognised, tr.n_rejected, tr.distributed, float(res["avg_loss"]))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_one_rank_failing_its_mask_check_changes_no_collective():
+    """the mask check's outcome is rank-local and known BEFORE the step is enqueued (host-side every-entry check one
+    batch ahead), and the matrix path issues the same collectives as the descriptor path -- so the rank whose batch fails simply runs
+    that step on the matrix while its peer runs on descriptors.  Uneven evaluation loaders (no collective in evaluation) and two
+    epochs: nothing hangs, the replicas stay identical."""
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_trainer_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    (p0, rec0, rej0, d0, l0), (p1, rec1, rej1, d1, l1) = out[0], out[1]
+    assert d0 and d1
+    assert torch.equal(p0, p1) and bool(torch.isfinite(p0).all())
+    assert rej0 == 0 and rej1 == 2                     # the flipped batch, once per epoch
+    assert rec0 == 2 * (3 + 1) and rec1 == 2 * (3 + 2)

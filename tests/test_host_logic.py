@@ -167,3 +167,89 @@ def test_region_encoder_container_matches_torchvision_layout():
     from oracle import resnet_oracle as R
     y = R.trunk({k: v.float() for k, v in sd.items()}, torch.zeros(1, 3, 64, 64), training=False)
     assert y.shape == (1, 2048, 2, 2)
+
+
+# ------------------------------------------------------------------ host-side every-entry mask check (mv_mask_verify_host)
+def _golden_mask_cases():
+    import json
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "masks.npz"))
+    return z, json.loads(str(z["cases"]))
+
+
+def _unpack_bits(words, L):
+    """inverse of oracle.data_oracle.pack_bits: uint32 [..., W] -> 0/1 [..., L]"""
+    b = (words[..., :, None] >> np.arange(32, dtype=np.uint32)) & 1
+    return b.reshape(words.shape[:-1] + (-1,))[..., :L]
+
+
+def test_host_mask_check_accepts_every_reference_built_matrix_and_finds_any_flipped_entry():
+    """mv_mask_verify_host is the host twin of mv_mask_build: the reference Dataset's own matrices (tests/golden/masks.npz, built by
+    CXRDataset.__getitem__ for every family over a grid of geometries) agree with the closed form of their descriptors in every
+    entry, and flipping ANY single entry is reported with its exact index."""
+    from medvill_amd import hip_ops as ops
+    z, cases = _golden_mask_cases()
+    rng = np.random.default_rng(0)
+    seen = set()
+    for c in cases:
+        L = c["N"] + c["S"] + 3
+        bits = z[f"bits_{c['tag']}"]
+        m = _unpack_bits(bits, L).astype(np.int64)
+        assert m.ndim == c["mask_ndim"]
+        desc = mv.data.MaskDesc.make(c["family"], c["N"], c["S"], [c["n_ids"]]).host_desc()
+        mt = torch.from_numpy(np.ascontiguousarray(m[None]))
+        assert ops.mask_verify_host(mt, desc, threads=1) == -1, c
+        idx = tuple(int(rng.integers(0, s)) for s in mt.shape)
+        bad = mt.clone()
+        bad[idx] ^= 1
+        assert ops.mask_verify_host(bad, desc, threads=2) == int(np.ravel_multi_index(idx, mt.shape)), (c, idx)
+        seen.add(c["family"])
+    assert seen == {"full", "s2s", "bar", "noncross", "1d"}
+    # a wrong descriptor (valid length off by one) is a mismatch too; descriptors out of range are refused
+    c = next(c for c in cases if c["family"] == "full" and c["n_ids"] < c["S"])
+    L = c["N"] + c["S"] + 3
+    mt = torch.from_numpy(_unpack_bits(z[f"bits_{c['tag']}"], L).astype(np.int64)[None].copy())
+    d = mv.data.MaskDesc.make("full", c["N"], c["S"], [c["n_ids"] + 1]).host_desc()
+    assert ops.mask_verify_host(mt, d) == c["N"] + 2 + c["n_ids"]               # first row, first column past the true valid length
+    d2 = d.clone()
+    d2[0, 0] = 9
+    with pytest.raises(RuntimeError):
+        ops.mask_verify_host(mt, d2)
+
+
+def test_trainer_checks_every_entry_of_every_batch_one_batch_ahead():
+    """the DEFAULT policy proves the derived descriptors on every entry of every batch.  Row 300 of sample 17 of
+    batch 5 (B = 64, L = 512: the benchmark geometry) is flipped -- the probes still recognise the family, the check names the entry,
+    and only that batch falls back to the matrix.  Host logic only: the trainer object is built without its model."""
+    from types import SimpleNamespace
+    from medvill_amd.trainer import CXRBERT_Trainer
+    B, N, S = 64, 36, 473
+    L = N + S + 3
+    tr = object.__new__(CXRBERT_Trainer)
+    tr.args = SimpleNamespace(num_image_embeds=N)
+    tr._init_mask_policy(tr.args)
+    assert tr.verify_masks == "full"
+    b = mv.data.synthetic_batch(30522, B, N, S, "full", seed=5, device="cpu")
+    good = b["attn_mask"]
+    bad = good.clone()
+    bad[17, 300, 200] ^= 1
+    feats = torch.zeros((B, N, 8))
+
+    def tup(m):
+        return (b["cls_tok"], b["input_txt"], b["txt_labels"], m, (feats, b["img_pos"]), b["segment"], b["is_aligned"], b["sep_tok"])
+    loader = [tup(bad if i == 5 else good) for i in range(7)]
+    results = []
+    for i, tk in enumerate(tr._prefetch(loader, True)):
+        assert tk["desc"] is not None and tk["check"] is not None          # recognised, and every batch gets the every-entry check
+        results.append(tk["check"].result())
+    assert results == [-1] * 5 + [(17 * L + 300) * L + 200, -1]
+    # the opt-in "sampled" policy checks every entry of the first two batches and every 64th only (random probe rows otherwise);
+    # training and evaluation batches are counted separately (ADVICE r3: eval batches must not shift the training schedule)
+    tr2 = object.__new__(CXRBERT_Trainer)
+    tr2.args = SimpleNamespace(num_image_embeds=N, verify_masks="sampled")
+    tr2._init_mask_policy(tr2.args)
+    sched = [tr2._full_check_now(True) for _ in range(130)]
+    assert [i + 1 for i, f in enumerate(sched) if f] == [1, 2, 64, 128]
+    assert [tr2._full_check_now(False) for _ in range(3)] == [True, True, False]
+    assert tr2._full_check_now(True) is False and tr2._mask_batches == {True: 131, False: 3}
+    with pytest.raises(ValueError):
+        tr2._init_mask_policy(SimpleNamespace(verify_masks="sometimes"))

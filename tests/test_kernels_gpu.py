@@ -591,6 +591,77 @@ def test_embed_fwd_bwd(dt):
     assert float(dE[0].abs().max()) == 0.0          # no look-up gradient for the [PAD] row
 
 
+def test_embed_without_image_positions_and_with_its_own_image_dropout():
+    """args.img_postion false (cxrbert_origin.py:27-31): img_pos = NULL -> image rows = LN(imgproj + Ty[0]), no dP contribution from them.
+    args.dropout_prob (cxrbert_origin.py:19): the image rows' dropout probability is separate from the text rows'."""
+    B, N, T, H, V, maxpos = 3, 5, 30, 128, 1024, 512
+    Lq = N + T + 2
+    g_ = torch.Generator().manual_seed(41)
+    cls_tok = torch.full((B,), 101, dtype=torch.int64, device=DEV)
+    sep_tok = torch.full((B,), 102, dtype=torch.int64, device=DEV)
+    txt = torch.randint(1, V, (B, T), generator=g_).to(DEV)
+    seg = torch.ones((B, T), dtype=torch.int64, device=DEV)
+    dt = torch.float32
+    E, P, Ty = rnd((V, H), dt, 42, 0.05), rnd((maxpos, H), dt, 43, 0.05), rnd((2, H), dt, 44, 0.05)
+    imgproj = rnd((B, N, H), dt, 45, 0.5)
+    g, b = rnd((H,), torch.float32, 46) * 0.1 + 1.0, rnd((H,), torch.float32, 47) * 0.1
+    x0 = torch.zeros((B, Lq, H), dtype=dt, device=DEV)
+    pre = torch.zeros((B, Lq, H), device=DEV)
+    mean, rstd = torch.zeros(B * Lq, device=DEV), torch.zeros(B * Lq, device=DEV)
+    ops.embed_fwd(0, cls_tok, txt, seg, None, sep_tok, imgproj, E, P, Ty, g, b, x0, pre, mean, rstd, B, N, T, H, V, maxpos, 1e-12)
+    Ed, Pd, Td, Id = [t.double().requires_grad_(True) for t in (E, P, Ty, imgproj)]
+    gd, bd = g.double().requires_grad_(True), b.double().requires_grad_(True)
+    z = torch.zeros((B, 1), dtype=torch.int64, device=DEV)
+    rows = torch.cat([Ed[cls_tok][:, None] + Pd[z] + Td[z], Id + Td[0][None, None],
+                      Ed[sep_tok][:, None] + Pd[z] + Td[z], Ed[txt] + Pd[torch.arange(T, device=DEV)][None] + Td[seg]], 1)
+    ref = torch.nn.functional.layer_norm(rows, (H,), gd, bd, 1e-12)
+    assert relerr(x0, ref) < 1e-5
+    dx0 = rnd((B, Lq, H), dt, 48)
+    dE, dP, dTy = torch.zeros((V, H), device=DEV), torch.zeros((maxpos, H), device=DEV), torch.zeros((2, H), device=DEV)
+    dg, db = torch.zeros(H, device=DEV), torch.zeros(H, device=DEV)
+    dimg = torch.zeros((B, N, H), dtype=dt, device=DEV)
+    ops.embed_bwd(0, dx0, pre, mean, rstd, g, cls_tok, txt, seg, None, sep_tok, dE, dP, dTy, dg, db, dimg, B, N, T, H, V, maxpos,
+                  pad_token_id=-1)
+    (ref * dx0.double()).sum().backward()
+    for got, want in ((dE, Ed.grad), (dP, Pd.grad), (dTy, Td.grad), (dg, gd.grad), (db, bd.grad), (dimg, Id.grad)):
+        assert relerr(got, want) < 1e-4
+    assert float(dP[T:].abs().max()) == 0.0          # only the text / [CLS] / [SEP] positions 0..T-1 received anything
+    # separate dropout probabilities: text rows p = 0.1, image rows p = 0.5 (same key, same element index)
+    B2, N2, T2 = 8, 64, 64
+    L2 = N2 + T2 + 2
+    pos = torch.arange(N2, device=DEV).view(1, N2).expand(B2, N2).contiguous()
+    txt2 = torch.randint(1, V, (B2, T2), generator=g_).to(DEV)
+    seg2 = torch.ones((B2, T2), dtype=torch.int64, device=DEV)
+    cls2, sep2 = torch.full((B2,), 101, dtype=torch.int64, device=DEV), torch.full((B2,), 102, dtype=torch.int64, device=DEV)
+    img2 = rnd((B2, N2, H), dt, 49, 0.5)
+    xs = []
+    for pt, pi in ((0.0, 0.0), (0.1, 0.5)):
+        x = torch.zeros((B2, L2, H), device=DEV)
+        pre2 = torch.zeros((B2, L2, H), device=DEV)
+        m2, r2 = torch.zeros(B2 * L2, device=DEV), torch.zeros(B2 * L2, device=DEV)
+        ops.embed_fwd(0, cls2, txt2, seg2, pos, sep2, img2, E, P, Ty, g, b, x, pre2, m2, r2, B2, N2, T2, H, V, maxpos, 1e-12,
+                      p_drop=pt, drop_key=1234, p_drop_img=pi)
+        xs.append(x)
+    clean, dropped = xs
+    zi = float((dropped[:, 1:N2 + 1] == 0).float().mean())
+    zt = float((dropped[:, N2 + 2:] == 0).float().mean())
+    assert abs(zi - 0.5) < 0.01 and abs(zt - 0.1) < 0.01, (zi, zt)
+    kept_i = dropped[:, 1:N2 + 1] != 0
+    assert relerr(dropped[:, 1:N2 + 1][kept_i], clean[:, 1:N2 + 1][kept_i] * 2.0) < 1e-5            # survivors scaled by 1 / (1 - 0.5)
+    # the backward regenerates the same two masks
+    dxo = torch.ones((B2, L2, H), device=DEV)
+    dEa, dPa, dTa = torch.zeros((V, H), device=DEV), torch.zeros((maxpos, H), device=DEV), torch.zeros((2, H), device=DEV)
+    dga, dba = torch.zeros(H, device=DEV), torch.zeros(H, device=DEV)
+    dimg2 = torch.zeros((B2, N2, H), device=DEV)
+    ops.embed_bwd(0, dxo, pre2, m2, r2, g, cls2, txt2, seg2, pos, sep2, dEa, dPa, dTa, dga, dba, dimg2, B2, N2, T2, H, V, maxpos,
+                  p_drop=0.1, drop_key=1234, p_drop_img=0.5)
+    keep = (dropped != 0).double()
+    keep[:, 1:N2 + 1] *= 2.0
+    keep[:, :1] *= 1.0 / 0.9
+    keep[:, N2 + 1:] *= 1.0 / 0.9
+    assert relerr(dba, keep.sum((0, 1))) < 2e-3          # dbeta = column sums of the masked, rescaled incoming gradient
+
+
 @pytest.mark.parametrize("V,ld", [(2, 2), (1000, 1000), (30522, 30528)])
 @pytest.mark.parametrize("ddt", [torch.float32, torch.bfloat16])
 def test_cross_entropy_fused(V, ld, ddt):

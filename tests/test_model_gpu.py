@@ -4,6 +4,7 @@ seeded inputs.  Tolerances are the ones BASELINE.json's north_star states: logit
 (fp32 path) / 1e-2 (bf16 path) of the reference; mask handling bit-exact (test_kernels_gpu)."""
 import json
 import os
+from types import SimpleNamespace
 
 import numpy as np
 import pytest
@@ -35,7 +36,9 @@ def load_case(golden_dir, name):
 
 
 def make_model(cfg, P, dtype, fwd_operand=None, grad_operand=None):
-    m = mv.CXRBERT(cfg_dict(cfg), None, dtype=dtype, device=DEV, fwd_operand=fwd_operand, grad_operand=grad_operand)
+    # the two fields ImageBertEmbeddings reads from the reference's argparse namespace (cxrbert_origin.py:19,27-31)
+    args = None if cfg.img_position else SimpleNamespace(img_postion=False, dropout_prob=0.1)
+    m = mv.CXRBERT(cfg_dict(cfg), args, dtype=dtype, device=DEV, fwd_operand=fwd_operand, grad_operand=grad_operand)
     m.load_state_dict(P, strict=True)
     m.eval()            # parity runs with dropout off, like the golden vectors (the reference in .eval())
     return m
@@ -46,7 +49,7 @@ def fwd(model, b):
                  (b["img_feats"].to(DEV), b["img_pos"].to(DEV)), b["sep_tok"].to(DEV))
 
 
-CASES = ["c1_full", "c1_s2s", "c1_bar", "c1_noncross", "c1_1d", "c1v1k_full", "c1v1k_bar_ragged"]
+CASES = ["c1_full", "c1_s2s", "c1_bar", "c1_noncross", "c1_1d", "c1v1k_full", "c1v1k_bar_ragged", "c1v1k_nopos"]
 
 
 @pytest.mark.parametrize("name", CASES)
@@ -75,7 +78,7 @@ def test_forward_matches_reference_golden(golden_dir, name, dtype, tol):
     assert abs(float(ml) - float(z["mlm_loss"])) < tol and abs(float(il) - float(z["itm_loss"])) < tol
 
 
-@pytest.mark.parametrize("name", ["c1_full", "c1_s2s", "c1v1k_full", "c1v1k_bar_ragged"])
+@pytest.mark.parametrize("name", ["c1_full", "c1_s2s", "c1v1k_full", "c1v1k_bar_ragged", "c1v1k_nopos"])
 @pytest.mark.parametrize("dtype,rtol", [(torch.float32, 1e-3), (torch.bfloat16, 4e-2)])
 def test_dropin_backward_matches_reference_gradients(golden_dir, name, dtype, rtol):
     """loss.backward() through CXRBERT.forward, exactly as train_origin.py:106-130 does."""
@@ -340,6 +343,79 @@ def test_retrieval_head_with_1d_masks(golden_dir):
         assert float((sc.cpu() - ref).abs().max()) < tol
 
 
+@pytest.mark.parametrize("dtype,tol,gtol", [(torch.float32, FP32_TOL, 1e-4), (torch.bfloat16, BF16_TOL, 3e-2)])
+def test_head_submodules_are_callable_like_the_reference(golden_dir, dtype, tol, gtol):
+    """The reference composes the model from callable sub-modules: CXRBERT.forward is `x_mlm, x_itm, _ = self.enc(...);
+    scores, _ = self.mlm(x_mlm); itm = self.itm(x_itm)` (cxrbert_origin.py:144-149) and the retrieval model is
+    `_, cls, _ = self.enc(...); self.itm(cls)` (Downstream_task/Retrieval/retrieval.py:26-31).  Both literal forms run here, on
+    the HIP kernels, equal the golden logits, and back-propagate the same gradients as the fused forward()."""
+    z, meta, cfg, P, b = load_case(golden_dir, "c1v1k_full")
+    model = make_model(cfg, P, dtype)
+    args = (b["cls_tok"].to(DEV), b["input_txt"].to(DEV), b["attn_mask"].to(DEV), b["segment"].to(DEV),
+            (b["img_feats"].to(DEV), b["img_pos"].to(DEV)), b["sep_tok"].to(DEV))
+    x_mlm, x_itm, _ = model.enc(*args)
+    scores, none = model.mlm(x_mlm)
+    itm = model.itm(x_itm)
+    assert none is None and scores.shape == (meta["B"], meta["N"] + meta["S"] + 3, cfg.vocab_size) and itm.shape == (meta["B"], 2)
+    assert float(np.abs(scores.detach().float().cpu().numpy() - z["mlm"]).max()) < tol
+    assert float(np.abs(itm.detach().float().cpu().numpy() - z["itm"]).max()) < tol
+    assert float(np.abs(model.mlm.predictions(x_mlm).detach().float().cpu().numpy() - z["mlm"]).max()) < tol     # BertLMPredictionHead
+    ce_m, ce_i = torch.nn.CrossEntropyLoss(ignore_index=-100), torch.nn.CrossEntropyLoss()
+    loss = ce_m(scores.float().transpose(1, 2), b["txt_labels"].to(DEV)) + ce_i(itm.float(), b["is_aligned"].to(DEV))
+    loss.backward()
+    got = {n: p.grad.clone() for n, p in model.named_parameters()}
+    model.zero_grad()
+    mlm2, itm2 = model(*args)
+    (ce_m(mlm2.transpose(1, 2), b["txt_labels"].to(DEV)) + ce_i(itm2, b["is_aligned"].to(DEV))).backward()
+    gmax = max(float(p.grad.abs().max()) for p in model.parameters())
+    for n, p in model.named_parameters():
+        scale = max(float(p.grad.abs().max()), 1e-3 * gmax)
+        assert float((got[n] - p.grad).abs().max()) <= gtol * scale, (n, float((got[n] - p.grad).abs().max()), scale)
+    # the retrieval composition on the 1-D mask case, under no_grad like full_dset_retrieval.py's scoring loop
+    z1, meta1, cfg1, P1, b1 = load_case(golden_dir, "c1_1d")
+    m1 = make_model(cfg1, P1, dtype)
+    with torch.no_grad():
+        _, cls, _ = m1.enc(b1["cls_tok"].to(DEV), b1["input_txt"].to(DEV), b1["attn_mask"].to(DEV), b1["segment"].to(DEV),
+                           (b1["img_feats"].to(DEV), b1["img_pos"].to(DEV)), b1["sep_tok"].to(DEV))
+        result = m1.itm(cls)
+    assert float(np.abs(result.float().cpu().numpy() - z1["itm"]).max()) < tol
+    # a head on an input that did not come from the encoder (any [.., H] tensor), gradient w.r.t. that input
+    xin = torch.randn(5, cfg.hidden, device=DEV, requires_grad=True)
+    out = model.itm(xin)
+    W, bb = model.get_parameter("itm.linear.weight").detach(), model.get_parameter("itm.linear.bias").detach()
+    assert float((out.detach() - (xin.detach() @ W.t() + bb)).abs().max()) < tol
+    out[:, 1].sum().backward()
+    assert float((xin.grad - W[1].expand(5, -1)).abs().max()) < tol * float(W.abs().max()) + 1e-6
+
+
+def test_no_grad_forward_keeps_no_per_layer_activations():
+    """under torch.no_grad() (the retrieval / evaluation loops) nothing is saved for a backward -- every layer
+    reuses one scratch set -- and the results are those of the grad-mode forward."""
+    cfg = mv.ModelConfig(vocab_size=512, hidden=128, layers=4, heads=2, intermediate=512, max_pos=128)
+    b = mv.data.synthetic_batch(cfg.vocab_size, 4, 6, 40, "bar", seed=3, device=DEV)
+    args = (b["cls_tok"], b["input_txt"], b["attn_mask"], b["segment"], (b["img_feats"], b["img_pos"]), b["sep_tok"])
+    outs = []
+    for grad in (False, True):
+        torch.manual_seed(9)
+        m = mv.CXRBERT(cfg, None, dtype=torch.bfloat16, device=DEV)
+        m.eval()
+        with torch.set_grad_enabled(grad):
+            mlm, itm = m(*args)
+        torch.cuda.synchronize()
+        keys = set(m.engine._ws)
+        outs.append((mlm.clone(), itm.clone(), keys, sum(t.numel() * t.element_size() for t in m.engine._ws.values())))
+    (m0, i0, k0, bytes0), (m1, i1, k1, bytes1) = outs
+    assert torch.equal(m0, m1) and torch.equal(i0, i1)
+    per_layer = [k for k in k0 if any(k == f"{stem}{l}" or k.startswith(f"{stem}{l}_") for stem in ("qkv", "ctx", "lse", "i", "dgelu", "a")
+                                      for l in range(1, cfg.layers))]
+    assert not per_layer, per_layer
+    assert any(k.startswith("qkv1") for k in k1) and bytes0 < 0.45 * bytes1, (bytes0, bytes1)
+    with torch.no_grad():
+        m(*args)
+    with pytest.raises(RuntimeError):
+        m.engine.encoder_backward()
+
+
 def test_overlapped_optimizer_equals_the_plain_step():
     """TrainStep(overlap_optimizer=True): AdamW runs range by range on the side stream and the next forward waits per range.
     Elementwise the same arithmetic on the same gradients; the gradients themselves carry float-atomic sums, so two runs of the
@@ -535,7 +611,8 @@ def test_packing_is_refused_where_padding_is_visible():
 def test_trainer_derives_descriptors_from_reference_masks_and_verifies_them(family):
     """The reference Dataset ships materialised int64 masks (dataset_origin.py:138-176).  The drop-in trainer derives the
     {family, n2, vl} descriptors from them, runs on those (packed rows where padding is invisible) and checks every mask
-    entry on the device off the critical path; a mask outside the families makes the step fall back to the matrix."""
+    entry on the host (mv_mask_verify_host, one batch ahead of the step); a single deviating entry, or a mask outside the
+    families, makes the step run on the matrix itself."""
     from types import SimpleNamespace
     V, B, N, S = 2048, 4, 6, 41
     cfgd = dict(vocab_size=V, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=512,
@@ -564,7 +641,7 @@ def test_trainer_derives_descriptors_from_reference_masks_and_verifies_them(fami
         tr.recognise_masks = True
         tr.train_data = [tup(bad)]
         got_bad = tr._run_epoch(tr.train_data, 0, False)
-        assert tr.n_recognised == 2 and tr.model.engine.S["cu"] is None      # descriptors were derived, then rejected
+        assert tr.n_recognised == 2 and tr.n_rejected == 1 and tr.model.engine.S["cu"] is None      # descriptors derived, then rejected
         tr.recognise_masks = False
         ref_bad = tr._run_epoch(tr.train_data, 0, False)
         for k in ref_bad:            # same kernels on the same inputs (float atomics in the loss sums: last-bit differences)

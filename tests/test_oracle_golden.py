@@ -85,7 +85,7 @@ FWD_TOL = 2e-5   # fp32 CPU vs fp32 CPU, different op order only
 
 
 @pytest.mark.parametrize("name", ["c1_full", "c1_s2s", "c1_bar", "c1_noncross", "c1_1d", "c1v1k_full",
-                                  "c1v1k_bar_ragged"])
+                                  "c1v1k_bar_ragged", "c1v1k_nopos"])
 def test_forward_matches_reference(golden_dir, name):
     z, meta = _load(golden_dir, name + ".npz")
     cfg, P, b = _oracle_inputs(z, meta)
@@ -105,7 +105,7 @@ def test_forward_matches_reference(golden_dir, name):
     assert abs(float(ml) - float(z["mlm_loss"])) < 1e-5 and abs(float(il) - float(z["itm_loss"])) < 1e-5
 
 
-@pytest.mark.parametrize("name", ["c1_full", "c1_s2s", "c1v1k_full", "c1v1k_bar_ragged"])
+@pytest.mark.parametrize("name", ["c1_full", "c1_s2s", "c1v1k_full", "c1v1k_bar_ragged", "c1v1k_nopos"])
 def test_gradients_match_reference(golden_dir, name):
     z, meta = _load(golden_dir, name + ".npz")
     cfg, P, b = _oracle_inputs(z, meta)
