@@ -19,7 +19,8 @@
  *   - every call takes the hipStream_t to enqueue on (as void*) and never synchronises.
  *   - return 0 = ok; negative = invalid argument / unsupported shape (MV_E_*);
  *     positive = hipError_t of a failed launch.  Nothing throws.
- *   - re-entrant, no global mutable state except the two test hooks mv_set_impl() / mv_set_gemm_variant().
+ *   - re-entrant, no global mutable state except the test hooks mv_set_impl() / mv_set_gemm_variant() and the launch policy
+ *     mv_set_persistent_cus().
  *   - dtype: MV_F32 = exact fp32 path (plain VALU kernels; parity at 1e-3 and below),
  *            MV_BF16 / MV_F16 = 16-bit storage, fp32 accumulate, MFMA kernels (the fast path).
  *   - matrices are row-major; "ld*" are leading dimensions in ELEMENTS.
@@ -81,6 +82,13 @@ const char* mv_build_info(void);
 /* test hook for mv_gemm's MFMA tile choice: force = 0 auto / 1 the 128x128x64 kernel / 2 the 256-row
  * LDS-DMA kernel; nj = 0 auto / 3 (256x192 tile) / 4 (256x256 tile). */
 void mv_set_gemm_variant(int force, int nj);
+/* Compute-unit partitioning between the streams of a step (host policy, see Engine): the persistent GEMM kernels (weight gradients)
+ * launch at most n blocks (0 = one per CU), and mv_stream_create_cumask makes a HIP stream whose kernels run only on the CUs of
+ * `mask_words` (n_words x 32 bits; hipExtStreamCreateWithCUMask; on a multi-XCD device bit i is CU i / n_xcd of XCD i % n_xcd). */
+void mv_set_persistent_cus(int n);
+int mv_get_persistent_cus(void);
+int mv_stream_create_cumask(const uint32_t* mask_words, int n_words, void** stream_out);
+int mv_stream_destroy(void* stream);
 /* test / experiment hook for mv_layernorm_bwd: low byte 0 = prefetching kernel, 8 waves per block (default) / 1 = one row at a time, 4 waves / 2, 3 = prefetching, 4 / 16 waves; bits 8.. = grid cap (0 = default) */
 void mv_set_rowops_variant(int v);
 /* bits per uniform of the attention-dropout mask generator (mv_attn_dropmask): 16 (default), 12 or 8.  P(drop) = round(p * 2^n) / 2^n;

@@ -29,6 +29,10 @@ PROTOTYPES = {
     "mv_build_info": [],
     "mv_set_gemm_variant": [i32, i32],
     "mv_set_attn_planes": [i32],
+    "mv_set_persistent_cus": [i32],
+    "mv_get_persistent_cus": [],
+    "mv_stream_create_cumask": [vp, i32, C.POINTER(C.c_void_p)],
+    "mv_stream_destroy": [vp],
     "mv_set_rowops_variant": [i32],
     "mv_get_attn_planes": [],
     "mv_gemm": [i32, i32, i32, i32, i32, i32, vp, i32, vp, i32, vp, i32, i32, vp, i32, vp, i32, i32, vp, i32, vp, i32, i32,
@@ -71,7 +75,7 @@ PROTOTYPES = {
     "mv_count_nonfinite": [vp, sz, vp, vp],
     "mv_scaler_update": [vp, i32, f32, f32, f32, f32, vp],
 }
-_RESTYPE = {"mv_set_impl": None, "mv_set_gemm_variant": None, "mv_set_attn_planes": None, "mv_set_rowops_variant": None, "mv_build_info": C.c_char_p}
+_RESTYPE = {"mv_set_persistent_cus": None, "mv_set_impl": None, "mv_set_gemm_variant": None, "mv_set_attn_planes": None, "mv_set_rowops_variant": None, "mv_build_info": C.c_char_p}
 
 _lib = None
 

@@ -18,6 +18,38 @@
 // The VALU kernels below them are the exact-fp32 path and the on-GPU cross-check.
 #include "mv_common.h"
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// Timing experiments on the forward kernel (profiles/tools/attn_ablate.sh builds variant libraries with -DATT_ABL=<bits>; results are
+// WRONG by construction): 1 no per-tile barrier, 2 no exponentials, 4 dropout masks from constants instead of scalar loads,
+// 8 no cross-half maximum, 16 no P.V products, 32 no Q.K products, 64 no LDS-DMA (tiles never loaded).  0 in the product build.
+#ifndef ATT_ABL
+#define ATT_ABL 0
+#endif
+#ifndef ATT_EARLY_MASKS      // forward: 0 = the select masks are loaded where they are used, 1 = the first half's at the top of the tile, 2 = both
+#define ATT_EARLY_MASKS 0
+#endif
+// bit 4096: phase profile -- every wave reads the shader clock at the phase boundaries of its tile loop, thread 0 of each block adds the
+// phase totals to g_att_prof[kernel][phase] (0 prologue, 1 wait for the tile's LDS-DMA, 2 barrier, 3 tile body, 4 issue of the next tile,
+// 5 epilogue, 7 = number of blocks); mv_debug_attn_prof() returns and clears them (profiles/tools/attn_phase.py).
+#if ATT_ABL & 4096
+__device__ unsigned long long g_att_prof[3][8];
+__device__ unsigned long long g_att_tile[3][8];       // inside the tile body (forward: 0 score MFMAs, 1 row maximum + shuffle, 2 exponentials + sums, 3 dropout selects, 4 P.V)
+#define PROF_DECL unsigned long long pt_ = clock64(), pacc_[6] = {0, 0, 0, 0, 0, 0}; unsigned long long ptile_[6] = {0, 0, 0, 0, 0, 0}
+#define PROF_TILE_ARGS , unsigned long long (&ptile_)[6]
+#define PROF_TILE_PASS , ptile_
+#define PROF_T0 unsigned long long tt_ = clock64()
+#define PROF_T(i, dep) do { asm volatile("s_nop 0" ::"v"(dep)); const unsigned long long n_ = clock64(); ptile_[i] += n_ - tt_; tt_ = n_; } while (0)
+#define PROF_MARK(i) do { const unsigned long long n_ = clock64(); pacc_[i] += n_ - pt_; pt_ = n_; } while (0)
+#define PROF_FLUSH(k) do { if (threadIdx.x == 0) { for (int i_ = 0; i_ < 6; ++i_) { atomicAdd(&g_att_prof[k][i_], pacc_[i_]); atomicAdd(&g_att_tile[k][i_], ptile_[i_]); } atomicAdd(&g_att_prof[k][7], 1ull); } } while (0)
+#else
+#define PROF_DECL
+#define PROF_MARK(i)
+#define PROF_FLUSH(k)
+#define PROF_TILE_ARGS
+#define PROF_TILE_PASS
+#define PROF_T0
+#define PROF_T(i, dep)
+#endif
 #define LOG2E 1.4426950408889634f
 #define LN2 0.6931471805599453f
 #define MASK_ADD (-10000.0f)
@@ -310,6 +342,35 @@ __device__ __forceinline__ bf16x8 frag_tr(const char* tile, int cbase, int rb, i
   bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((MV_LDS bf16x4*)(tile + att_off(r + 8, col >> 3) + sub));
   return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
+// The same two fragment reads with the lane-dependent part of att_off() taken out of the tile loop.  Per lane and tile-invariant:
+//   rk = (lane&31)*128 + ((h ^ f0) << 4) + ((f >> 1) << 5)        f = att_f(lane & 31): bits 5-6 of rk ARE the chunk swizzle of s = 0
+//   tr = (4h' + q)*128 + ((q >> 1) << 6) + ((g & 1) << 5) + ((c0 ^ h') << 4) + 8 (li & 1)
+// so that, for a tile at LDS byte address T (a multiple of 8 KiB: no carry into the XORed bits),
+//   frag_row(T, base, s)      = ((T + rk) ^ (s << 5)) + 128 base                                 base = 0 / 32
+//   frag_tr (T, 32 dt, rb) lo = ((T + tr) ^ (dt << 6)) + 128 rb,   hi = (... ^ 32) + 128 rb + 1024
+// i.e. one add per tile and one XOR per (s) / (dt, half); everything else is an instruction immediate.  Before, hipcc rebuilt every
+// address from the (per tile opaque, see dkv_tile) lane index: ~6 VALU instructions per ds_read, a quarter of the forward's issue slots.
+struct FragLane { unsigned rk, tr; };
+__device__ __forceinline__ FragLane frag_lane(int lane) {
+  const int l31 = lane & 31, h = lane >> 5, f = att_f(l31);
+  const int li = lane & 15, g = lane >> 4, hh = g >> 1, q = li >> 2, c0 = (li & 3) >> 1;
+  FragLane o;
+  o.rk = (unsigned)(l31 * 128 + (((h ^ f) & 1) << 4) + ((f >> 1) << 5));
+  o.tr = (unsigned)((4 * hh + q) * 128 + ((q >> 1) << 6) + ((g & 1) << 5) + ((c0 ^ hh) << 4) + (li & 1) * 8);
+  return o;
+}
+__device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(uintptr_t)(MV_LDS const char*)p; }
+// tk = lds_addr(tile) + FragLane::rk
+__device__ __forceinline__ bf16x8 frag_row_x(unsigned tk, int base, int s) {
+  return *(MV_LDS const bf16x8*)(uintptr_t)((tk ^ (unsigned)(s << 5)) + 128u * base);
+}
+// tt = lds_addr(tile) + FragLane::tr
+__device__ __forceinline__ bf16x8 frag_tr_x(unsigned tt, int dt, int rb) {
+  const unsigned t = tt ^ (unsigned)(dt << 6);
+  bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((MV_LDS bf16x4*)(uintptr_t)(t + 128u * rb));
+  bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((MV_LDS bf16x4*)(uintptr_t)((t ^ 32u) + 128u * rb + 1024u));
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
 __device__ __forceinline__ bf16x8 pack8(const f32x16& v, int s2) {
   bf16x8 r;
 #pragma unroll
@@ -402,6 +463,160 @@ __device__ __forceinline__ void att_block(int& xb, int& head, int& b) {
   b = rem / gridDim.y;
   head = rem - b * gridDim.y;
 }
+// A wave's [32 rows][64 columns] 16-bit output tile leaves as WHOLE 128-byte row segments.  The tile sits in two 32x32 accumulators with
+// the rows on the lanes (lane (l31, h), register reg of acc[dt]: row l31, column 32 dt + acc_row(reg, h)), so a direct store writes 8 bytes of
+// 32 different rows per instruction and every 128-byte line of the output is written in eight pieces by eight instructions: measured on
+// the forward (profiles/r04_notes.txt) the epilogue alone cost 25 of the kernel's 100 us.  Here the tile goes through a private
+// 32 x 144-byte LDS patch (ds_write_b64 per 4 columns, ds_read_b128 per 8): 16 bytes per lane, 8 full rows per store instruction.
+// `rows_ok`: rows [0, rows_ok) of the tile exist in the output; `patch` is this wave's own 4608-byte region (callers barrier first).
+#define ATT_PATCH_BYTES 4608
+template <bool F16>
+__device__ __forceinline__ void store_rows_tile(char* patch, const f32x16 (&acc)[2], float scale, bool lane_ok, bf16_t* g_row0, size_t ld,
+                                                int rows_ok, int lane) {
+  const int l31 = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      f32x4 v = {acc[dt][4 * g] * scale, acc[dt][4 * g + 1] * scale, acc[dt][4 * g + 2] * scale, acc[dt][4 * g + 3] * scale};
+      if (!lane_ok) v = (f32x4){0.f, 0.f, 0.f, 0.f};        // (a select, not a product: the lane's accumulators may hold anything)
+      bf16_t* dst = (bf16_t*)(patch + l31 * 144) + 32 * dt + 8 * g + 4 * h;
+      if constexpr (F16) st4<f16_t>((f16_t*)dst, v);
+      else st4<bf16_t>(dst, v);
+    }
+  // (same wave writes and reads the patch: LDS operations of a wave complete in order, the compiler waits on lgkmcnt before the reads' use)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = (lane >> 3) + 8 * i, c = lane & 7;
+    const u32x4 v = *(const u32x4*)(patch + r * 144 + 16 * c);
+    if (r < rows_ok) *(u32x4*)(g_row0 + (size_t)r * ld + 8 * c) = v;
+  }
+}
+
+// One 64-key tile of the forward for a wave's 32 queries.  PLAIN: every entry of the tile is visible and inside the sample (class 1, no
+// ragged tail): no mask words, no bounds, the scale folded into the exponent's fma.  DROP: attention dropout on.  Compile-time, so each
+// variant is straight-line code (the run-time form merged its paths through 32 register copies per tile).
+template <bool PLAIN, bool DROP, bool F16>
+__device__ __forceinline__ void fwd_tile(const AttnArgs& a, unsigned tk, unsigned tv, const bf16x8 (&qf)[4], f32x16 (&o)[2], float& m2,
+                                         float& lsum, const uint32_t* myw, bool q_ok, int k0, int Lv, int cls, float c2, int h,
+                                         const unsigned long long* mp PROF_TILE_ARGS) {
+  PROF_T0;
+  // the 64 select masks of the tile (two scalar loads of 128 bytes per 32-key half) are requested FIRST: a scalar-cache miss costs a round
+  // trip to L2 / HBM (measured: 3,500 shader cycles per tile when requested where they are used), the score MFMAs and the softmax hide it
+  u64x8 dm[2][2];
+#if ATT_EARLY_MASKS
+  if (DROP) {
+#if !(ATT_ABL & 4)
+    sload_masks16(mp, dm[0][0], dm[0][1]);
+#if ATT_EARLY_MASKS >= 2
+    sload_masks16(mp + 16, dm[1][0], dm[1][1]);
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+  }
+#endif
+  f32x16 st[2];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) st[kk][i] = 0.f;
+#if ATT_ABL & 32
+#pragma unroll
+    for (int i = 0; i < 16; ++i) st[kk][i] = frag_elem<F16>(qf[i & 3], i >> 2) * (float)(k0 + i);
+#else
+#pragma unroll
+    for (int s = 0; s < 4; ++s) st[kk] = mma32<F16>(frag_row_x(tk, 32 * kk, s), qf[s], st[kk]);
+#endif
+  }
+  PROF_T(0, st[1][15]);
+  float mx = -INFINITY;
+  if (PLAIN) {
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[kk][r]);
+    mx *= c2;
+  } else {
+    const bool tail = (k0 + 64 > Lv);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      uint32_t w = 0xffffffffu;
+      if (cls != 1) { const int wi = (k0 >> 5) + kk; w = (q_ok && wi < a.W) ? myw[wi] : 0xffffffffu; }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int kr = acc_row(r, h);
+        float v = st[kk][r] * c2;
+        if (cls != 1) v += ((w >> kr) & 1u) ? 0.f : MASK_ADD * LOG2E;
+        if (tail && (k0 + 32 * kk + kr >= Lv)) v = -INFINITY;
+        st[kk][r] = v;
+        mx = fmaxf(mx, v);
+      }
+    }
+  }
+#if !(ATT_ABL & 8)
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+#endif
+  const float mn = fmaxf(m2, mx);
+  PROF_T(1, mn);
+  const float alpha = fexp2(m2 - mn);
+  m2 = mn;
+  f32x2 ps2 = {0.f, 0.f};            // two partial sums: v_pk_add_f32, half the add instructions
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+#if ATT_ABL & 2
+      const float p0 = fmaf(st[kk][r], c2, -mn), p1 = fmaf(st[kk][r + 1], c2, -mn);
+#else
+      const float p0 = PLAIN ? fexp2(fmaf(st[kk][r], c2, -mn)) : fexp2(st[kk][r] - mn);
+      const float p1 = PLAIN ? fexp2(fmaf(st[kk][r + 1], c2, -mn)) : fexp2(st[kk][r + 1] - mn);
+#endif
+      st[kk][r] = p0;
+      st[kk][r + 1] = p1;
+      ps2 += (f32x2){p0, p1};
+    }
+  const float ps = ps2[0] + ps2[1];
+  lsum = lsum * alpha + ps;          // the normaliser sums the UNdropped probabilities
+  PROF_T(2, lsum);
+  if (DROP) {
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      u64x8 m0 = dm[kk][0], m1 = dm[kk][1];
+#if !(ATT_ABL & 4)
+      if (ATT_EARLY_MASKS < 2 && (kk == 1 || !ATT_EARLY_MASKS)) sload_masks16(mp + 16 * kk, m0, m1);
+#endif
+#if ATT_ABL & 4
+#pragma unroll
+      for (int r = 0; r < 8; ++r) { m0[r] = 0xfff7ffffffffefffull ^ (unsigned long long)(k0 + r); m1[r] = ~m0[r] | 0xffff0000ffffull; }
+#endif
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {       // `ps` was computed from these values by compiler-scheduled adds: see sel_lane_after
+        st[kk][r] = sel_lane_after(st[kk][r], ps, m0[r]);
+        st[kk][8 + r] = sel_lane_after(st[kk][8 + r], ps, m1[r]);
+      }
+    }
+  }
+  PROF_T(3, st[1][15]);
+  // Unconditional: 16 packed multiplies.  Skipping them while the running maximum does not move (almost every tile) costs MORE -- the two
+  // paths leave the accumulators in different registers and hipcc pays the merge with 32-64 register copies on the skipping path.
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const bf16x8 pf = pack8t<F16>(st[kk], s2);
+#if ATT_ABL & 16
+      asm volatile("" ::"v"(pf));
+      (void)tv;
+#else
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) o[dt] = mma32<F16>(frag_tr_x(tv, dt, 32 * kk + 16 * s2), pf, o[dt]);
+#endif
+    }
+  PROF_T(4, o[1][15]);
+}
+
 #define FWD_NS 3      // 48 KiB of LDS per block: three blocks per CU
 template <bool F16>
 __global__ __launch_bounds__(256, 3) void attn_fwd_mfma_kernel(AttnArgs a) {
@@ -409,6 +624,10 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_mfma_kernel(AttnArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   int xb, head, b;
+  PROF_DECL;
+#if ATT_ABL & 256
+  if (a.B > 0) return;            // dispatch cost of the grid alone
+#endif
   att_block(xb, head, b);
   const int L = a.L, H = a.H, ld = 3 * a.H, T = a.T;
   const int qb0 = xb * 128, q0 = qb0 + wid * 32, q = q0 + l31;
@@ -439,8 +658,10 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_mfma_kernel(AttnArgs a) {
   int iss = cur, issued = 0, done = 0;
   auto issue = [&]() {
     char* st_ = smem + (issued % FWD_NS) * 16384;
+#if !(ATT_ABL & 64)
     tile_dma<4>(rsq, a.bytes_qkv, rowbase, iss * 64, Lv, ld, H + head * 64, st_, wid, lane);
     tile_dma<4>(rsq, a.bytes_qkv, rowbase, iss * 64, Lv, ld, 2 * H + head * 64, st_ + 8192, wid, lane);
+#endif
     ++issued;
     iss = next_tile(tmk.need, iss, nkt);
   };
@@ -448,120 +669,72 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_mfma_kernel(AttnArgs a) {
   for (int i = 0; i < FWD_NS - 1; ++i)
     if (iss < nkt) issue();
   const uint32_t* myw = a.bits + (lrow + (q_ok ? q : 0)) * a.W;
+  const FragLane fl = frag_lane(lane);            // two registers held across the loop: the lane's part of every fragment address
+  const unsigned smem_a = lds_addr(smem);
+#if ATT_ABL & 512
+  asm volatile("" ::"v"(qf[0]), "v"(qf[1]), "v"(qf[2]), "v"(qf[3]), "s"(tmk.need), "v"(fl.rk));
+  if (a.B > 0) { asm volatile("s_waitcnt vmcnt(0)"); return; }      // prologue only
+#endif
+#if ATT_ABL & 1024
+  asm volatile("" ::"v"(qf[0]), "v"(qf[1]), "v"(qf[2]), "v"(qf[3]), "s"(tmk.need), "v"(fl.rk));
+  asm volatile("s_waitcnt vmcnt(0)");
+  cur = nkt;                                      // prologue + epilogue, no tile loop
+#endif
+  PROF_MARK(0);
   while (cur < nkt) {
     att_wait_stage<4>(issued - done - 1);           // this wave's pieces of tile `cur` have landed ...
+    PROF_MARK(1);
+#if !(ATT_ABL & 1)
     __builtin_amdgcn_s_barrier();                   // ... and everybody's; everybody is done reading the slot refilled next
+#endif
+    PROF_MARK(2);
     __builtin_amdgcn_sched_barrier(0);
     if (!ATT_ISSUE_LATE && iss < nkt) issue();
-    const char* tK = smem + (done % FWD_NS) * 16384;
-    const char* tV = tK + 8192;
+    const unsigned tKa = smem_a + (unsigned)(done % FWD_NS) * 16384u;
     const int cls = !wave_on ? 0 : (((tmk.w_is1 >> cur) & 1) ? 1 : (((tmk.w_nz >> cur) & 1) ? 2 : 0));
     if (wave_on && cls != 0) {
       const int k0 = cur * 64;
-      // (lane index opaque per tile: the fragment offsets are recomputed instead of held in -- and spilled from -- registers; see dkv_tile)
-      int lane_o = lane;
-      asm volatile("" : "+v"(lane_o));
-      const int l31 = lane_o & 31, h = lane_o >> 5;
-      f32x16 st[2];
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) st[kk][i] = 0.f;
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-          st[kk] = mma32<F16>(frag_row(tK, 32 * kk, s, l31, h), qf[s], st[kk]);
+      // (the two lane words are made opaque per tile: hipcc otherwise hoists every derived address out of the loop and spills them)
+      unsigned rk_ = fl.rk, tr_ = fl.tr;
+      int h_ = h;                   // (also the half-wave index: the masked variants' 32 per-register bit masks derive from it)
+      asm volatile("" : "+v"(rk_), "+v"(tr_), "+v"(h_));
+      const unsigned tk = tKa + rk_, tv = tKa + 8192u + tr_;
+      const bool plain = (cls == 1) && (k0 + 64 <= Lv);
+      const unsigned long long* mp = a.drop_on ? (const unsigned long long*)a.dropbits + dbits_block(a, (size_t)b * a.A + head, q0 >> 5, cur) : nullptr;
+#define FWD_CALL(P_, D_) fwd_tile<P_, D_, F16>(a, tk, tv, qf, o, m2, lsum, myw, q_ok, k0, Lv, cls, c2, h_, mp PROF_TILE_PASS)
+      switch ((plain ? 0 : 1) | (a.drop_on ? 2 : 0)) {       // one wave-uniform dispatch per tile
+        case 0: FWD_CALL(true, false); break;
+        case 1: FWD_CALL(false, false); break;
+        case 2: FWD_CALL(true, true); break;
+        default: FWD_CALL(false, true); break;
       }
-      const bool tail = (k0 + 64 > Lv);
-      float mx = -INFINITY;
-      const bool plain = (cls == 1) && !tail;       // fully visible tile: no mask words, no bounds, scale folded into the exp
-      if (plain) {
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[kk][r]);
-        mx *= c2;
-      } else {
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-          uint32_t w = 0xffffffffu;
-          if (cls != 1) { const int wi = (k0 >> 5) + kk; w = (q_ok && wi < a.W) ? myw[wi] : 0xffffffffu; }
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int kr = acc_row(r, h);
-            float v = st[kk][r] * c2;
-            if (cls != 1) v += ((w >> kr) & 1u) ? 0.f : MASK_ADD * LOG2E;
-            if (tail && (k0 + 32 * kk + kr >= Lv)) v = -INFINITY;
-            st[kk][r] = v;
-            mx = fmaxf(mx, v);
-          }
-        }
-      }
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float mn = fmaxf(m2, mx);
-      const float alpha = fexp2(m2 - mn);
-      m2 = mn;
-      float ps = 0.f;
-      if (plain) {
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) { const float pv = fexp2(fmaf(st[kk][r], c2, -mn)); st[kk][r] = pv; ps += pv; }
-      } else {
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) { const float pv = fexp2(st[kk][r] - mn); st[kk][r] = pv; ps += pv; }
-      }
-      lsum = lsum * alpha + ps;          // the normaliser sums the UNdropped probabilities
-      if (a.drop_on) {
-        const unsigned long long* mp = (const unsigned long long*)a.dropbits + dbits_block(a, (size_t)b * a.A + head, q0 >> 5, cur);
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-          u64x8 m0, m1;
-          sload_masks16(mp + 16 * kk, m0, m1);
-#pragma unroll
-          for (int r = 0; r < 8; ++r) {       // `ps` was computed from these values by compiler-scheduled adds: see sel_lane_after
-            st[kk][r] = sel_lane_after(st[kk][r], ps, m0[r]);
-            st[kk][8 + r] = sel_lane_after(st[kk][8 + r], ps, m1[r]);
-          }
-        }
-      }
-      if (!__all(alpha == 1.0f)) {      // the running maximum rarely moves after the first tiles
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
-      }
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-          const bf16x8 pf = pack8t<F16>(st[kk], s2);
-#pragma unroll
-          for (int dt = 0; dt < 2; ++dt)
-            o[dt] = mma32<F16>(frag_tr(tV, 32 * dt, 32 * kk + 16 * s2, lane_o), pf, o[dt]);
-        }
+#undef FWD_CALL
     }
+#if ATT_ABL & 4096
+    asm volatile("s_nop 0" ::"v"(o[0][0]), "v"(o[1][15]));      // the tile's last MFMAs have delivered
+#endif
+    PROF_MARK(3);
     if (ATT_ISSUE_LATE && iss < nkt) issue();
     cur = next_tile(tmk.need, cur, nkt);
     ++done;
+    PROF_MARK(4);
   }
-  if (!q_ok) return;
+  // epilogue: whole rows through a per-wave LDS patch (every wave is past its last tile: the K / V stages are free)
+  __builtin_amdgcn_s_barrier();
   const float ltot = lsum + __shfl_xor(lsum, 32, 64);
   const float inv = (a.drop_on ? a.inv_keep : 1.0f) / ltot;
-  bf16_t* orow = a.out + (rowbase + q) * (size_t)H + head * 64;
-  bf16_t* orow2 = a.out2 ? a.out2 + (rowbase + q) * (size_t)H + head * 64 : nullptr;
-#pragma unroll
-  for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const f32x4 ov = {o[dt][4 * g] * inv, o[dt][4 * g + 1] * inv, o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv};
-      if constexpr (F16) {
-        st4<f16_t>((f16_t*)orow + 32 * dt + 8 * g + 4 * h, ov);
-        if (orow2) st4<bf16_t>(orow2 + 32 * dt + 8 * g + 4 * h, ov);
-      } else {
-        st4<bf16_t>(orow + 32 * dt + 8 * g + 4 * h, ov);
-      }
-    }
-  if (h == 0) a.lse[((size_t)b * a.A + head) * L + q] = (m2 + log2f(ltot)) * LN2;
+  const int rows_ok = Lq - q0;                      // (<= 0 for a wave without queries: nothing is stored)
+  char* patch = smem + wid * ATT_PATCH_BYTES;
+  store_rows_tile<F16>(patch, o, inv, q_ok, a.out + (rowbase + q0) * (size_t)H + head * 64, (size_t)H, rows_ok, lane);
+  if constexpr (F16) {
+    if (a.out2) store_rows_tile<false>(patch, o, inv, q_ok, a.out2 + (rowbase + q0) * (size_t)H + head * 64, (size_t)H, rows_ok, lane);
+  }
+  if (q_ok && h == 0) a.lse[((size_t)b * a.A + head) * L + q] = (m2 + log2f(ltot)) * LN2;
+#if ATT_ABL & 4096
+  asm volatile("s_waitcnt vmcnt(0)");
+#endif
+  PROF_MARK(5);
+  PROF_FLUSH(0);
 }
 
 // ---- backward: dQ ----------------------------------------------------------------------------
@@ -569,10 +742,10 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_mfma_kernel(AttnArgs a) {
 // TAIL tile is always run as masked), DROP: attention dropout is on -- compile-time, so the per-element loops are
 // straight-line code the scheduler can interleave with the MFMAs.
 template <bool MASKED, bool DROP, bool TAIL, bool F16>
-__device__ __forceinline__ void dq_tile(const AttnArgs& a, const char* tK, const char* tV, const bf16x8 (&qf)[4], const bf16x8 (&dof)[4],
+__device__ __forceinline__ void dq_tile(const AttnArgs& a, unsigned tk, unsigned tv, unsigned tkt, const bf16x8 (&qf)[4], const bf16x8 (&dof)[4],
                                         f32x16 (&dq)[2], const uint32_t* myw, bool q_ok, int q, int b, int head, int k0, int Lv,
-                                        float lse2, float dlt, float c2, int lane, const unsigned long long* mp) {
-  const int l31 = lane & 31, h = lane >> 5;
+                                        float lse2, float dlt, float c2, int h, const unsigned long long* mp) {
+  // tk / tv: row-read bases of the K / V tiles (lds address + FragLane::rk), tkt: transposed-read base of the K tile (+ FragLane::tr)
   const float dlt_s = dlt * a.scale;                          // ds = p * (dp' - delta) * scale, with the scale folded in
   const float dscale = DROP ? a.inv_keep * a.scale : a.scale;
 #pragma unroll
@@ -582,8 +755,8 @@ __device__ __forceinline__ void dq_tile(const AttnArgs& a, const char* tK, const
     for (int i = 0; i < 16; ++i) { st[i] = 0.f; dp[i] = 0.f; }
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      st = mma32<F16>(frag_row(tK, 32 * kk, s, l31, h), qf[s], st);
-      dp = mma32<F16>(frag_row(tV, 32 * kk, s, l31, h), dof[s], dp);
+      st = mma32<F16>(frag_row_x(tk, 32 * kk, s), qf[s], st);
+      dp = mma32<F16>(frag_row_x(tv, 32 * kk, s), dof[s], dp);
     }
     uint32_t w = 0xffffffffu;
     if (MASKED) { const int wi = (k0 >> 5) + kk; w = (q_ok && wi < a.W) ? myw[wi] : 0xffffffffu; }
@@ -611,7 +784,7 @@ __device__ __forceinline__ void dq_tile(const AttnArgs& a, const char* tK, const
       const bf16x8 dsf = pack8t<F16>(st, s2);
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt)
-        dq[dt] = mma32<F16>(frag_tr(tK, 32 * dt, 32 * kk + 16 * s2, lane), dsf, dq[dt]);
+        dq[dt] = mma32<F16>(frag_tr_x(tkt, dt, 32 * kk + 16 * s2), dsf, dq[dt]);
     }
   }
 }
@@ -626,6 +799,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_mfma_kernel(AttnArgs a) {
   att_block(xb, head, b);
   const int L = a.L, H = a.H, ld = 3 * a.H, T = a.T;
   const int qb0 = xb * 128, q0 = qb0 + wid * 32, q = q0 + l31;
+  PROF_DECL;
   const int Lv = a.cu ? a.cu[b + 1] - a.cu[b] : L;
   const int Lq = a.qlim ? min(Lv, a.qlim[b]) : Lv;
   if (qb0 >= Lv) return;
@@ -688,21 +862,30 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_mfma_kernel(AttnArgs a) {
   for (int i = 0; i < DQ_NS - 1; ++i)
     if (iss < nkt) issue();
   const uint32_t* myw = a.bits + (lrow + (q_ok ? q : 0)) * a.W;
+  const FragLane fl = frag_lane(lane);
+  const unsigned smem_a = lds_addr(smem);
+  PROF_MARK(0);
   while (cur < nkt) {
     att_wait_stage<4>(issued - done - 1);
+    PROF_MARK(1);
     __builtin_amdgcn_s_barrier();
+    PROF_MARK(2);
     __builtin_amdgcn_sched_barrier(0);
     if (!ATT_ISSUE_LATE && iss < nkt) issue();
-    const char* tK = smem + (done % DQ_NS) * 16384;
-    const char* tV = tK + 8192;
+    const unsigned tKa = smem_a + (unsigned)(done % DQ_NS) * 16384u;
     const int cls = !wave_on ? 0 : (((tmk.w_is1 >> cur) & 1) ? 1 : (((tmk.w_nz >> cur) & 1) ? 2 : 0));
     if (wave_on && cls != 0) {
       const int k0 = cur * 64;
       const bool tail = (k0 + 64 > Lv);
+      // fragment addresses: the lane's two words (opaque per tile: nothing derived from them is hoisted and spilled) + the tile's address
+      unsigned rk_ = fl.rk, tr_ = fl.tr;
+      int h_ = h;
+      asm volatile("" : "+v"(rk_), "+v"(tr_), "+v"(h_));
+      const unsigned tk = tKa + rk_, tv = tKa + 8192u + rk_, tkt = tKa + tr_;
       // one wave-uniform dispatch per tile: the element loops below contain no branches
       const unsigned long long* mp = a.drop_on ? (const unsigned long long*)a.dropbits + dbits_block(a, (size_t)b * a.A + head, q0 >> 5, cur) : nullptr;
       const int variant = (cls == 1 ? 0 : 1) | (tail ? 2 : 0) | (a.drop_on ? 4 : 0);
-#define DQ_CALL(M_, D_, T_) dq_tile<M_, D_, T_, F16>(a, tK, tV, qf, dof, dq, myw, q_ok, q, b, head, k0, Lv, lse2, dlt, c2, lane, mp)
+#define DQ_CALL(M_, D_, T_) dq_tile<M_, D_, T_, F16>(a, tk, tv, tkt, qf, dof, dq, myw, q_ok, q, b, head, k0, Lv, lse2, dlt, c2, h_, mp)
       switch (variant) {
         case 0: DQ_CALL(false, false, false); break;
         case 1: DQ_CALL(true, false, false); break;
@@ -713,19 +896,24 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_mfma_kernel(AttnArgs a) {
       }
 #undef DQ_CALL
     }
+#if ATT_ABL & 4096
+    asm volatile("s_nop 0" ::"v"(dq[0][0]), "v"(dq[1][15]));
+#endif
+    PROF_MARK(3);
     if (ATT_ISSUE_LATE && iss < nkt) issue();
     cur = next_tile(tmk.need, cur, nkt);
     ++done;
+    PROF_MARK(4);
   }
-  if (q >= Lv) return;
-  bf16_t* orow = a.dqkv + (rowbase + q) * (size_t)ld + head * 64;
-#pragma unroll
-  for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      if (q_ok) store4_16<F16>(orow + 32 * dt + 8 * g + 4 * h, dq[dt][4 * g], dq[dt][4 * g + 1], dq[dt][4 * g + 2], dq[dt][4 * g + 3]);
-      else store4_16<F16>(orow + 32 * dt + 8 * g + 4 * h, 0.f, 0.f, 0.f, 0.f);       // a key-only row inside a query tile (a.qlim)
-    }
+  // epilogue: whole rows through a per-wave LDS patch; a key-only row inside a query tile (a.qlim) gets a zero dQ row
+  __builtin_amdgcn_s_barrier();
+  store_rows_tile<F16>(smem + wid * ATT_PATCH_BYTES, dq, 1.0f, q_ok, a.dqkv + (rowbase + q0) * (size_t)ld + head * 64, (size_t)ld, Lv - q0,
+                       lane);
+#if ATT_ABL & 4096
+  asm volatile("s_waitcnt vmcnt(0)");
+#endif
+  PROF_MARK(5);
+  PROF_FLUSH(1);
 }
 
 // ---- backward: dK, dV --------------------------------------------------------------------------
@@ -736,14 +924,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_mfma_kernel(AttnArgs a) {
 template <bool MASKED, bool DROP, bool F16>
 __device__ __forceinline__ void dkv_tile(const AttnArgs& a, const char* tQ, const char* tD, const float* s_lse, const float* s_dl,
                                          const uint32_t* s_w, const bf16x8 (&kf)[4], const bf16x8 (&vf)[4], f32x16 (&dk)[2],
-                                         f32x16 (&dv)[2], int b, int head, int cur, int key, int wid, float c2, int lane_in, const uint32_t* s_db) {
+                                         f32x16 (&dv)[2], int b, int head, int cur, int key, int wid, float c2, int lane_in, const uint32_t* s_db,
+                                         const FragLane& fl) {
   // The lane index is made opaque per tile: hipcc otherwise hoists every lane-dependent LDS offset of the 48 fragment reads out of the tile
   // loop (a dozen registers), runs out at the 256-register cap of two waves per SIMD and SPILLS them -- each reload inside a tile body was a
   // scratch load whose `s_waitcnt vmcnt(0)` also drained the LDS-DMA ring (8-11 per tile; SQ_WAIT_ANY 50 % of the wave cycles).  Recomputing
   // the offsets costs a few VALU instructions per tile.
   int lane = lane_in;
-  asm volatile("" : "+v"(lane));
+  unsigned rk_ = fl.rk, tr_ = fl.tr;       // the lane's part of every fragment address (FragLane): two registers across the tile loop
+  asm volatile("" : "+v"(lane), "+v"(rk_), "+v"(tr_));
   const int l31 = lane & 31, h = lane >> 5;
+  const unsigned tq = lds_addr(tQ) + rk_, td = lds_addr(tD) + rk_, tqt = lds_addr(tQ) + tr_, tdt = lds_addr(tD) + tr_;
   const float dscale = DROP ? a.inv_keep * a.scale : a.scale;
 #pragma unroll
   for (int qq = 0; qq < 2; ++qq) {
@@ -753,11 +944,11 @@ __device__ __forceinline__ void dkv_tile(const AttnArgs& a, const char* tQ, cons
     {
       // the Q / dO fragments one step ahead of their MFMAs and no further: hipcc otherwise requests all eight up front (32 registers)
       // and spills elsewhere -- every reload of a spilled register is a scratch load whose `vmcnt(0)` also drains the LDS-DMA ring
-      bf16x8 qc = frag_row(tQ, 32 * qq, 0, l31, h), dc = frag_row(tD, 32 * qq, 0, l31, h);
+      bf16x8 qc = frag_row_x(tq, 32 * qq, 0), dc = frag_row_x(td, 32 * qq, 0);
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         bf16x8 qn = qc, dn = dc;
-        if (s + 1 < 4) { qn = frag_row(tQ, 32 * qq, s + 1, l31, h); dn = frag_row(tD, 32 * qq, s + 1, l31, h); }
+        if (s + 1 < 4) { qn = frag_row_x(tq, 32 * qq, s + 1); dn = frag_row_x(td, 32 * qq, s + 1); }
         __builtin_amdgcn_sched_barrier(0);
         sc = mma32<F16>(qc, kf[s], sc);
         dp = mma32<F16>(dc, vf[s], dp);
@@ -802,8 +993,8 @@ __device__ __forceinline__ void dkv_tile(const AttnArgs& a, const char* tQ, cons
       const bf16x8 dsf = pack8t<F16>(sc, s2);
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt) {
-        dv[dt] = mma32<F16>(frag_tr(tD, 32 * dt, 32 * qq + 16 * s2, lane), pf, dv[dt]);
-        dk[dt] = mma32<F16>(frag_tr(tQ, 32 * dt, 32 * qq + 16 * s2, lane), dsf, dk[dt]);
+        dv[dt] = mma32<F16>(frag_tr_x(tdt, dt, 32 * qq + 16 * s2), pf, dv[dt]);
+        dk[dt] = mma32<F16>(frag_tr_x(tqt, dt, 32 * qq + 16 * s2), dsf, dk[dt]);
       }
     }
   }
@@ -818,6 +1009,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_mfma_kernel(AttnArgs a) {
   att_block(xb, head, b);
   const int L = a.L, H = a.H, ld = 3 * a.H, T = a.T;
   const int kb0 = xb * 128, k0w = kb0 + wid * 32, key = k0w + l31;
+  PROF_DECL;
   const int Lv = a.cu ? a.cu[b + 1] - a.cu[b] : L;
   if (kb0 >= Lv) return;
   const bool wave_on = k0w < Lv, k_ok = key < Lv;
@@ -883,10 +1075,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_mfma_kernel(AttnArgs a) {
 #pragma unroll
   for (int i = 0; i < DKV_NS - 1; ++i)
     if (iss < nqt) issue();
+  const FragLane fl = frag_lane(lane);
+  PROF_MARK(0);
   while (cur < nqt) {
     if (use_db) att_wait_stage<7>(issued - done - 1);
     else att_wait_stage<6>(issued - done - 1);
+    PROF_MARK(1);
     __builtin_amdgcn_s_barrier();
+    PROF_MARK(2);
     __builtin_amdgcn_sched_barrier(0);
     if (!ATT_ISSUE_LATE && iss < nqt) issue();
     const char* st = smem + (done % DKV_NS) * KV_STAGE;
@@ -899,7 +1095,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_mfma_kernel(AttnArgs a) {
     const int cls = !wave_on ? 0 : (((tmk.w_is1 >> cur) & 1) ? 1 : (((tmk.w_nz >> cur) & 1) ? 2 : 0));
     if (wave_on && cls != 0) {
       const int variant = (cls == 1 ? 0 : 1) | (use_db ? 2 : 0);        // one wave-uniform dispatch per tile
-#define DKV_CALL(M_, D_) dkv_tile<M_, D_, F16>(a, tQ, tD, s_lse, s_dl, s_w, kf, vf, dk, dv, b, head, cur, key, wid, c2, lane, s_db)
+#define DKV_CALL(M_, D_) dkv_tile<M_, D_, F16>(a, tQ, tD, s_lse, s_dl, s_w, kf, vf, dk, dv, b, head, cur, key, wid, c2, lane, s_db, fl)
       switch (variant) {
         case 0: DKV_CALL(false, false); break;
         case 1: DKV_CALL(true, false); break;
@@ -908,21 +1104,36 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_mfma_kernel(AttnArgs a) {
       }
 #undef DKV_CALL
     }
+#if ATT_ABL & 4096
+    asm volatile("s_nop 0" ::"v"(dk[0][0]), "v"(dv[1][15]));
+#endif
+    PROF_MARK(3);
     if (ATT_ISSUE_LATE && iss < nqt) issue();
     cur = next_tile(tmk.need, cur, nqt);
     ++done;
+    PROF_MARK(4);
   }
-  if (!k_ok) return;
-  bf16_t* krow = a.dqkv + (rowbase + key) * (size_t)ld + H + head * 64;
-  bf16_t* vrow = krow + H;
-#pragma unroll
-  for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      store4_16<F16>(krow + 32 * dt + 8 * g + 4 * h, dk[dt][4 * g], dk[dt][4 * g + 1], dk[dt][4 * g + 2], dk[dt][4 * g + 3]);
-      store4_16<F16>(vrow + 32 * dt + 8 * g + 4 * h, dv[dt][4 * g], dv[dt][4 * g + 1], dv[dt][4 * g + 2], dv[dt][4 * g + 3]);
-    }
+  // epilogue: whole rows through a per-wave LDS patch (dK, then dV through the same patch)
+  __builtin_amdgcn_s_barrier();
+  bf16_t* krow0 = a.dqkv + (rowbase + k0w) * (size_t)ld + H + head * 64;
+  store_rows_tile<F16>(smem + wid * ATT_PATCH_BYTES, dk, 1.0f, k_ok, krow0, (size_t)ld, Lv - k0w, lane);
+  store_rows_tile<F16>(smem + wid * ATT_PATCH_BYTES, dv, 1.0f, k_ok, krow0 + H, (size_t)ld, Lv - k0w, lane);
+#if ATT_ABL & 4096
+  asm volatile("s_waitcnt vmcnt(0)");
+#endif
+  PROF_MARK(5);
+  PROF_FLUSH(2);
 }
+#if ATT_ABL & 4096
+extern "C" int mv_debug_attn_prof(unsigned long long* out48) {       // variant libraries only: totals since the last call, then cleared
+  unsigned long long z[24] = {0};
+  hipError_t e = hipMemcpyFromSymbol(out48, HIP_SYMBOL(g_att_prof), sizeof(z));
+  if (e == hipSuccess) e = hipMemcpyFromSymbol(out48 + 24, HIP_SYMBOL(g_att_tile), sizeof(z));
+  if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(g_att_prof), z, sizeof(z));
+  if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(g_att_tile), z, sizeof(z));
+  return (int)e;
+}
+#endif
 
 // =========================================================================================
 // plain VALU kernels (any dtype, dh <= 128): exact-fp32 path and cross-check

@@ -329,6 +329,7 @@ __global__ void splitk_reduce_kernel(GemmArgs p) {
 int g_mv_gemm_force = 0;   // test hook: 0 auto, 1 force the 128x128 kernel, 2 force the 256-row kernel
 int g_mv_gemm_nj = 0;      // test hook: 0 auto, 3 / 4 force the 192- / 256-column variant
 int g_mv_gemm_dbg = 0;
+extern int g_mv_persistent_cus;   // mv_api.hip
 extern "C" void mv_set_gemm_variant(int force, int nj) { g_mv_gemm_force = force & 0xff; g_mv_gemm_nj = nj; g_mv_gemm_dbg = force >> 8; }
 
 static inline bool aligned_to(const void* p, size_t a) { return p == nullptr || (((uintptr_t)p) % a) == 0; }
@@ -442,7 +443,9 @@ extern "C" int mv_gemm(int dtype, int ta, int tb, int M, int N, int K, const voi
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
         if (n_cu <= 0) n_cu = 256;
       }
-      const int rc_ring = mv_launch_ring(p, ta, tb, f16, variant, tiles, splitk, n_cu, stream);
+      // persistent kernels: at most g_mv_persistent_cus blocks when the host partitions the chip (mv_set_persistent_cus)
+      const int n_blk = (g_mv_persistent_cus > 0 && g_mv_persistent_cus < n_cu) ? g_mv_persistent_cus : n_cu;
+      const int rc_ring = mv_launch_ring(p, ta, tb, f16, variant, tiles, splitk, n_blk, stream);
       if (rc_ring != MV_OK) return rc_ring;
     } else {
       if (colsum_part) return MV_E_SHAPE;        // the 256x256 ring kernel only

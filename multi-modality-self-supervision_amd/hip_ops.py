@@ -404,5 +404,25 @@ def set_rowops_variant(v: int = 0):
     _lib().mv_set_rowops_variant(int(v))
 
 
+def set_persistent_cus(n: int = 0):
+    """The persistent (weight-gradient) GEMM kernels launch at most n blocks; 0 = one per CU."""
+    _lib().mv_set_persistent_cus(int(n))
+
+
+def stream_with_cus(n_cus: int, device, first: int = 0, total: int = 256, n_xcd: int = 8):
+    """torch stream whose kernels only run on `n_cus` compute units (a multiple of n_xcd: n_cus / n_xcd CUs of every XCD), starting at
+    CU `first` (also a multiple of n_xcd).  Bit i of the mask is CU i // n_xcd of XCD i % n_xcd (see mv_stream_create_cumask)."""
+    import ctypes
+    if n_cus % n_xcd or first % n_xcd or n_cus <= 0 or first + n_cus > total:
+        raise ValueError("n_cus and first must be multiples of the XCD count and fit the device")
+    words = (ctypes.c_uint32 * ((total + 31) // 32))()
+    for i in range(first, first + n_cus):
+        words[i // 32] |= 1 << (i % 32)
+    out = ctypes.c_void_p()
+    with torch.cuda.device(device):
+        L.check(_lib().mv_stream_create_cumask(words, len(words), ctypes.byref(out)), "mv_stream_create_cumask")
+    return torch.cuda.ExternalStream(out.value, device=device)
+
+
 def set_gemm_variant(force: int = 0, nj: int = 0):
     _lib().mv_set_gemm_variant(int(force), int(nj))

@@ -66,6 +66,33 @@ VARIANTS = {
            ("consumed rows only as queries (reordered rows, qlim)", lambda: setattr(model.engine, "tail_queries", True))],
     "tail": [("last layer on all rows", lambda: setattr(step, "tail_rows", False)), ("last layer on consumed rows", lambda: setattr(step, "tail_rows", True))],
 }
+def _side_plain():
+    from medvill_amd import engine as E
+    st = E._SHARED_STREAMS.get(("plain-side",))
+    if st is None:
+        st = E._SHARED_STREAMS[("plain-side",)] = torch.cuda.Stream(device=dev)
+    E._SHARED_STREAMS[(str(dev), "side")] = st
+    model.engine._side = st
+    mv.hip_ops.set_persistent_cus(0)
+
+
+def _side_masked(n, grid=None):
+    def f():
+        from medvill_amd import engine as E
+        key = ("masked-side", n)
+        st = E._SHARED_STREAMS.get(key)
+        if st is None:
+            st = E._SHARED_STREAMS[key] = mv.hip_ops.stream_with_cus(n, dev, first=256 - n)
+        E._SHARED_STREAMS[(str(dev), "side")] = st
+        model.engine._side = st
+        mv.hip_ops.set_persistent_cus(n if grid is None else grid)
+    return f
+
+
+VARIANTS["pcus"] = [(f"persistent dW kernels: {n} blocks" if n else "persistent dW kernels: one block per CU (256)",
+                     (lambda n=n: mv.hip_ops.set_persistent_cus(n))) for n in (0, 224, 192, 160, 128)]
+VARIANTS["cumask"] = [("side stream unmasked, 256 persistent blocks", _side_plain)] + \
+    [(f"side stream on {n} CUs ({n // 8} per XCD), {n} persistent blocks", _side_masked(n)) for n in (192, 128, 96, 64)]
 which = sys.argv[1] if len(sys.argv) > 1 else "pack"
 arms = VARIANTS[which]
 for _ in range(3):

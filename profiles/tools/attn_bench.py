@@ -24,7 +24,10 @@ def bench(fn, reps=10):
     return e0.elapsed_time(e1) / reps * 1e3
 
 
-for (N, S, fam) in ((36, 473, "full"), (36, 473, "s2s"), (36, 473, "noncross"), (100, 665, "s2s")):
+CASES = ((36, 473, "full"), (36, 473, "s2s"), (36, 473, "noncross"), (100, 665, "s2s"))
+if "full512" in sys.argv[1:]:
+    CASES = CASES[:1]
+for (N, S, fam) in CASES:
     L = N + S + 3
     H = A * dh
     g = torch.Generator().manual_seed(1)
