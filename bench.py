@@ -88,16 +88,18 @@ RIDGE_FLOP_PER_BYTE = PEAK_BF16_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)      # 312.
 
 
 def pmc_traffic(case):
-    """HBM bytes per launch of a kernel from the committed rocprofv3 PMC passes (profiles/r03_<case>_pmc.json, written by
-    profiles/tools/r03_condense.py from separate FETCH_SIZE / WRITE_SIZE runs of profiles/tools/dominant.py <case>): an offline
+    """HBM bytes per launch of a kernel from the committed rocprofv3 PMC passes (profiles/r04_<case>_pmc.json, written by
+    profiles/tools/r04_condense.py from separate FETCH_SIZE / WRITE_SIZE runs of profiles/tools/dominant.py <case>): an offline
     measurement of the same kernel on the same operands, not of this run.  None when the file is absent."""
-    p = os.path.join(ROOT, "profiles", f"r03_{case}_pmc.json")
-    try:
-        with open(p) as f:
-            d = json.load(f)
-        return float(d["hbm_bytes_per_launch"]), d.get("note", "")
-    except (OSError, KeyError, ValueError):
-        return None, "no committed PMC pass for this build"
+    for rnd in ("r04", "r03"):
+        p = os.path.join(ROOT, "profiles", f"{rnd}_{case}_pmc.json")
+        try:
+            with open(p) as f:
+                d = json.load(f)
+            return float(d["hbm_bytes_per_launch"]), d.get("note", "") + f" [profiles/{rnd}_{case}_pmc.json]"
+        except (OSError, KeyError, ValueError):
+            continue
+    return None, "no committed PMC pass for this kernel"
 
 
 def time_kernel_case(case):
@@ -112,10 +114,13 @@ def time_kernel_case(case):
     gbs = m["bytes"] / m["ms"] / 1e6
     ai = m["flop"] / m["bytes"]
     bound = "mfma" if ai >= RIDGE_FLOP_PER_BYTE else "hbm"
-    return dict(kernel=m["kernel"], ms=m["ms"], tflops=tfl, algorithmic_flop=m["flop"], algorithmic_bytes=m["bytes"],
-                arithmetic_intensity_flop_per_byte=ai, bound=bound, mfma_frac=tfl / PEAK_BF16_TFLOPS, hbm_frac=gbs / HBM_PEAK_GBS,
-                algorithmic_gb_per_s=gbs, hbm_traffic_pmc_bytes=traffic, traffic_note=note,
-                profile=f"profiles/r03_{case}_kernel_stats.txt")
+    prof = next((f"profiles/{r}_{case}_kernel_stats.txt" for r in ("r04", "r03")
+                 if os.path.exists(os.path.join(ROOT, "profiles", f"{r}_{case}_kernel_stats.txt"))), None)
+    n = dominant.LAUNCHES_PER_STEP.get(case) or dominant.GEMM_FAMILY[case][1]
+    return dict(name=case, kernel=m["kernel"], ms=m["ms"], us=m["ms"] * 1e3, tflops=tfl, algorithmic_flop=m["flop"], algorithmic_bytes=m["bytes"],
+                arithmetic_intensity_flop_per_byte=ai, bound=bound, mfma_frac=tfl / PEAK_BF16_TFLOPS, frac=tfl / PEAK_BF16_TFLOPS,
+                hbm_frac=gbs / HBM_PEAK_GBS, algorithmic_gb_per_s=gbs, hbm_traffic_pmc_bytes=traffic, traffic_note=note,
+                launches_per_step=n, ms_per_step_alone=n * m["ms"], profile=prof)
 
 
 def drop_in_user_timings(mv, model, step, cfg, dev, B, N, S, n):
@@ -195,6 +200,7 @@ def main():
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary timings (padded / BAR / non-cross / full-length / bf16 operands)")
+    ap.add_argument("--no-kernel-table", action="store_true", help="(internal) skip the stand-alone timing of the other kernel families")
     ap.add_argument("--dropin-only", action="store_true", help="(internal) print the drop-in user timings as one JSON line and exit: bench.py runs this "
                     "as a CHILD process, so that the trainer is measured in a process of its own like a user's (in a process that already holds "
                     "other models' streams the trainer's two streams can land on one hardware queue)")
@@ -315,6 +321,21 @@ def main():
                     extras.update(json.loads(r.stdout.strip().splitlines()[-1]))
                 except Exception as e:          # the secondary figure must never cost the headline line
                     print(f"[bench] drop-in timings unavailable: {e!r}", file=sys.stderr, flush=True)
+                # the data-parallel code path on this one GPU: a one-rank RCCL group with every collective issued (MV_DP_FORCE=1), as a child job
+                # under torch.distributed.run -- a regression of the exchange's stream handling shows here before a multi-GPU node sees it
+                try:
+                    env = dict(os.environ, MV_DP_FORCE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+                    port = 29500 + (os.getpid() + 7) % 2000
+                    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+                                        "--master-port", str(port), os.path.abspath(__file__), "--gpus", "1", "--batch", str(B), "--steps", str(args.steps),
+                                        "--warmup", str(args.warmup), "--config", args.config, "--no-extras", "--no-cpu-baseline", "--no-kernel-table"],
+                                       capture_output=True, text=True, timeout=900, env=env)
+                    d_ = json.loads(r.stdout.strip().splitlines()[-1])
+                    if d_["config"].get("dist_backend") == "nccl":
+                        extras["rccl_rehearsal_ms_per_step"] = d_["ms_per_step"]
+                        extras["rccl_rehearsal_exposed_ms"] = d_["config"].get("allreduce_exposed_ms")
+                except Exception as e:
+                    print(f"[bench] one-rank RCCL rehearsal unavailable: {e!r}", file=sys.stderr, flush=True)
                 c5 = CONFIGS["c5"]
                 cfg5 = mv.ModelConfig(max_pos=c5["max_pos"])
                 torch.manual_seed(1234)
@@ -349,6 +370,13 @@ def main():
         # The weight-gradient GEMM is reported beside it: its call is two kernels (split-K partials + reduction), timed together.
         kern = time_kernel_case("ffn1")
         kern_dw = time_kernel_case("dw")
+        # ... and every other MFMA kernel family of the step, each alone on the step's shapes (profiles/tools/dominant.py): attention (one
+        # layer's forward + dQ + dK/dV) and the ten other GEMM calls of a layer.  `coverage` = their stand-alone times x launches per step
+        # over the measured step (the two streams overlap, so the sum can exceed 1)
+        sys.path.insert(0, os.path.join(ROOT, "profiles", "tools"))
+        import dominant
+        kernels = [kern, kern_dw] + ([] if args.no_kernel_table else [time_kernel_case("attn")] + [time_kernel_case(c_) for c_ in dominant.GEMM_FAMILY])
+        alone_ms = sum(k_["ms_per_step_alone"] for k_ in kernels)
         eng = model.engine
         pps = lambda ms: (world * B / (ms / 1e3)) if ms else None
         out = {
@@ -392,6 +420,11 @@ def main():
                        "trainer_hostloader_bar_ms_per_step": extras.get("trainer_hostloader_bar_ms_per_step"),
                        "dropin_forward_backward_b16_ms": extras.get("dropin_forward_backward_b16_ms"),
                        "rccl_ranks": rccl_ranks, "dist_backend": backend, "allreduce_exposed_ms": exposed_ms,
+                       # the same step as a one-rank RCCL job with every collective issued (child process); at 8 ranks the model of DESIGN.md 7
+                       # expects 0.5-0.6 ms of exposed all-reduce (the embeddings bucket) on top
+                       "rccl_rehearsal_ms_per_step": extras.get("rccl_rehearsal_ms_per_step"),
+                       "rccl_rehearsal_exposed_ms": extras.get("rccl_rehearsal_exposed_ms"),
+                       "expected_exposed_allreduce_ms_at_8_ranks": "0.5-0.6 (model, DESIGN.md 7; unmeasured)",
                        "mlm_loss": float(st[0] / max(float(st[1]), 1.0)), "itm_loss": float(st[3] / max(float(st[4]), 1.0))},
             # dominant kernel (the FFN-up GEMM, largest single share of the step): algorithmic FLOPs per launch / its
             # average duration, HIP events around 20 launches on its own stream (time_dominant_kernel); traffic = HBM bytes
@@ -403,7 +436,11 @@ def main():
                          "frac": kern["mfma_frac"] if kern["bound"] == "mfma" else kern["hbm_frac"],
                          "traffic": kern["hbm_traffic_pmc_bytes"],
                          "ridge_flop_per_byte": RIDGE_FLOP_PER_BYTE,
-                         "kernel": kern, "weight_gradient_gemm": kern_dw,
+                         "kernel": kern, "weight_gradient_gemm": kern_dw, "attention": kernels[2] if len(kernels) > 2 else None,
+                         "kernels": kernels,
+                         "coverage": {"stand_alone_ms_per_step": alone_ms, "of_step": alone_ms / ms_per_step,
+                                      "note": "sum over the listed kernel families of (stand-alone time x launches per step) / measured step; the last "
+                                              "layer's calls run on fewer rows and the weight-gradient GEMMs overlap the main chain on a second stream"},
                          "step": {"achieved": executed, "frac": executed / PEAK_BF16_TFLOPS,
                                   "convention": "EXECUTED FLOPs of the whole step (valid rows, labelled rows) / dense 16-bit MFMA peak",
                                   "dense_tflops": dense, "dense_frac": dense / PEAK_BF16_TFLOPS, "flop_per_sample_dense": f_step,

@@ -631,6 +631,10 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_mfma_kernel(AttnArgs a) {
   att_block(xb, head, b);
   const int L = a.L, H = a.H, ld = 3 * a.H, T = a.T;
   const int qb0 = xb * 128, q0 = qb0 + wid * 32, q = q0 + l31;
+  // The tile classes depend on the block index alone: requested BEFORE the row plan (cu, qlim), not behind it -- a block's prologue is a chain
+  // of dependent memory round trips (arguments -> row plan -> Q rows / tile classes -> first K / V tiles: 12,600 shader cycles, a fifth of
+  // the block's life, profiles/r04_notes.txt), this takes one link out
+  const TileMasks tmk = load_tile_masks_q(a.info, b, T, qb0 >> 6, min(q0 >> 6, T - 1), lane);
   const int Lv = a.cu ? a.cu[b + 1] - a.cu[b] : L;             // positions of this sample that exist as rows
   const int Lq = a.qlim ? min(Lv, a.qlim[b]) : Lv;             // ... and those that are queries
   if (qb0 >= Lq) return;
@@ -651,8 +655,6 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_mfma_kernel(AttnArgs a) {
   for (int i = 0; i < 16; ++i) { o[0][i] = 0.f; o[1][i] = 0.f; }
 
   const int nkt = (Lv + 63) / 64;
-  const int ta = qb0 >> 6;
-  const TileMasks tmk = load_tile_masks_q(a.info, b, T, ta, min(q0 >> 6, T - 1), lane);
   // K/V ring: the needed key tiles (set bits of tmk.need) are requested FWD_NS - 1 ahead of the one being computed on
   int cur = next_tile(tmk.need, -1, nkt);
   int iss = cur, issued = 0, done = 0;
@@ -800,6 +802,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_mfma_kernel(AttnArgs a) {
   const int L = a.L, H = a.H, ld = 3 * a.H, T = a.T;
   const int qb0 = xb * 128, q0 = qb0 + wid * 32, q = q0 + l31;
   PROF_DECL;
+  const TileMasks tmk = load_tile_masks_q(a.info, b, T, qb0 >> 6, min(q0 >> 6, T - 1), lane);      // before the row plan: see the forward
   const int Lv = a.cu ? a.cu[b + 1] - a.cu[b] : L;
   const int Lq = a.qlim ? min(Lv, a.qlim[b]) : Lv;
   if (qb0 >= Lv) return;
@@ -847,8 +850,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_mfma_kernel(AttnArgs a) {
   for (int i = 0; i < 16; ++i) { dq[0][i] = 0.f; dq[1][i] = 0.f; }
 
   const int nkt = (Lv + 63) / 64;
-  const int ta = qb0 >> 6;
-  const TileMasks tmk = load_tile_masks_q(a.info, b, T, ta, min(q0 >> 6, T - 1), lane);
   int cur = next_tile(tmk.need, -1, nkt);
   int iss = cur, issued = 0, done = 0;
   auto issue = [&]() {
@@ -1010,6 +1011,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_mfma_kernel(AttnArgs a) {
   const int L = a.L, H = a.H, ld = 3 * a.H, T = a.T;
   const int kb0 = xb * 128, k0w = kb0 + wid * 32, key = k0w + l31;
   PROF_DECL;
+  const TileMasks tmk = load_tile_masks_k(a.info, b, T, kb0 >> 6, min(k0w >> 6, T - 1), lane);      // before the row plan: see the forward
   const int Lv = a.cu ? a.cu[b + 1] - a.cu[b] : L;
   if (kb0 >= Lv) return;
   const bool wave_on = k0w < Lv, k_ok = key < Lv;
@@ -1045,7 +1047,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_mfma_kernel(AttnArgs a) {
   // this lane's keep-bit dword inside a (32-query x 64-key) block: key half kk, then the accumulator order of the key (2*r + h)
   const int kq32 = (lane & 31), kkw = (k0w >> 5) & 1;
   const unsigned db_in_block = (unsigned)(kkw * 32 + 2 * (((kq32 >> 3) << 2) | (kq32 & 3)) + ((kq32 >> 2) & 1));
-  const TileMasks tmk = load_tile_masks_k(a.info, b, T, ka, min(k0w >> 6, T - 1), lane);
   int cur = next_tile(tmk.need, -1, nqt);
   int iss = cur, issued = 0, done = 0;
   auto issue = [&]() {

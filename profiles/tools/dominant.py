@@ -7,7 +7,8 @@ cases
          packed rows, f16 operands, f32 result un-scaled by 1/S -- the kernel symbol with the largest share of the step (46 launches)
   ffn1   the FFN-up projection (256x256 ring kernel, NT form): [32768, 768] x [3072, 768]^T + bias, GELU and GELU' epilogue, two f16 outputs
   attn   attention forward + backward (dQ, dK/dV) at B = 64, A = 12, L = 512, ragged packed rows, dropout 0.1 from keep-bits
-usage: python3 profiles/tools/dominant.py <case> [reps]"""
+  qkv wo ffn2 dz da dctx dxqkv dw2 dwqkv dwo   the other GEMM calls of an encoder layer (GEMM_FAMILY below)
+usage: python3 profiles/tools/dominant.py <case> [reps]   |   python3 profiles/tools/dominant.py all"""
 import os
 import sys
 
@@ -69,7 +70,65 @@ def make_case(name, dev="cuda"):
         fwd = 4.0 * A * dh * float((vl * vl).sum())
         return fn, dict(kernel=f"attn_dropmask + attn_fwd_mfma + attn_bwd_dq_mfma + attn_bwd_dkv_mfma, B={B} A={A} L={L} rows {M}, dropout 0.1",
                         symbol="attn_", flop=3.5 * fwd, bytes=2.0 * M * (3 * H + H) * 3)
+    if name in GEMM_FAMILY:
+        return _gemm_family(name, dev)
     raise ValueError(name)
+
+
+# The other GEMM calls of one encoder layer, exactly as Engine.encoder_forward / encoder_backward issue them at the bench shape (25,483 packed
+# rows, f16 operands, dropout 0.1): name -> (description, launches per step).  With `ffn1`, `dw` and `attn` they are the step's MFMA kernels:
+# bench.py times each alone and reports them as roofline.kernels (the line covers the step, not one launch in twelve).
+GEMM_FAMILY = {
+    "qkv": ("y = x.Wqkv^T + b: rows x 2304 x 768 (256x256 ring kernel)", 12),
+    "wo": ("attention output projection + bias + dropout + residual: rows x 768 x 768 (128x128 kernel)", 12),
+    "ffn2": ("FFN-down + bias + dropout + residual: rows x 768 x 3072 (128x128 kernel)", 12),
+    "dz": ("dz = (dy.W2) * gelu'(z) + per-tile column sums: rows x 3072 x 768 over the W2^T copy (256x256 ring kernel)", 12),
+    "da": ("da = dz.W1 + residual gradient: rows x 768 x 3072 (128x128 kernel, NN)", 12),
+    "dctx": ("dctx = dproj.Wo: rows x 768 x 768 (128x128 kernel, NN)", 12),
+    "dxqkv": ("dx = dqkv.Wqkv + residual gradient: rows x 768 x 2304 (128x128 kernel, NN)", 12),
+    "dw2": ("dW2 = dproj^T.gelu(z): 768 x 3072 over the rows (persistent 256x256 kernel, TN, split-K + reduction)", 12),
+    "dwqkv": ("dWqkv = dqkv^T.x: 2304 x 768 over the rows (persistent kernel, TN, split-K + reduction)", 12),
+    "dwo": ("dWo = dproj^T.ctx: 768 x 768 over the rows (persistent kernel, TN, split-K + reduction)", 12),
+}
+LAUNCHES_PER_STEP = {"ffn1": 12, "dw": 12, "attn": 12}
+
+
+def _gemm_family(name, dev):
+    from medvill_amd import hip_ops as ops
+    from medvill_amd._lib import EPI_BIAS, EPI_BIAS_RES, EPI_MUL, EPI_RES
+    M = ROWS_PACKED
+    f16 = torch.float16
+    e = lambda *shape: torch.empty(shape, device=dev, dtype=f16)
+    alpha = torch.tensor([1.0 / 32768.0], device=dev)
+    if name == "qkv":
+        x, w, b, o = _rnd((M, H), 1.0, 41, dev), _rnd((3 * H, H), 0.02, 42, dev), _rnd((3 * H,), 0.02, 43, dev, torch.float32), e(M, 3 * H)
+        fn, fl, by = (lambda: ops.gemm(x, w, o, M=M, N=3 * H, K=H, bias=b, epi=EPI_BIAS)), 2.0 * M * 3 * H * H, 2.0 * (M * H + 3 * H * H + M * 3 * H)
+    elif name in ("wo", "ffn2"):
+        K = H if name == "wo" else I
+        x, w, b, r, o = _rnd((M, K), 1.0, 44, dev), _rnd((H, K), 0.02, 45, dev), _rnd((H,), 0.02, 46, dev, torch.float32), _rnd((M, H), 1.0, 47, dev), e(M, H)
+        fn = lambda: ops.gemm(x, w, o, M=M, N=H, K=K, bias=b, epi=EPI_BIAS_RES, r=r, p_drop=0.1, drop_key=99)
+        fl, by = 2.0 * M * H * K, 2.0 * (M * K + H * K + 2 * M * H)
+    elif name == "dz":
+        dy, w2t, dg, o = _rnd((M, H), 0.1, 48, dev), _rnd((I, H), 0.02, 49, dev), _rnd((M, I), 0.5, 50, dev), e(M, I)
+        part = torch.empty((2 * ((M + 255) // 256), I), device=dev)
+        fn = lambda: ops.gemm(dy, w2t, o, M=M, N=I, K=H, epi=EPI_MUL, r=dg, colsum_part=part)
+        fl, by = 2.0 * M * I * H, 2.0 * (M * H + I * H + 2 * M * I)
+    elif name in ("da", "dctx", "dxqkv"):
+        K = {"da": I, "dctx": H, "dxqkv": 3 * H}[name]
+        dy, w, r, o = _rnd((M, K), 0.1, 51, dev), _rnd((K, H), 0.02, 52, dev), _rnd((M, H), 0.1, 53, dev), e(M, H)
+        if name == "dctx":
+            fn = lambda: ops.gemm(dy, w, o, tb=True, M=M, N=H, K=K)
+        else:
+            fn = lambda: ops.gemm(dy, w, o, tb=True, M=M, N=H, K=K, epi=EPI_RES, r=r)
+        fl, by = 2.0 * M * H * K, 2.0 * (M * K + H * K + M * H * (1 if name == "dctx" else 2))
+    else:
+        No, Ko = {"dw2": (H, I), "dwqkv": (3 * H, H), "dwo": (H, H)}[name]
+        dy, x = _rnd((M, No), 0.1, 54, dev), _rnd((M, Ko), 1.0, 55, dev)
+        g = torch.zeros((No, Ko), device=dev)
+        ws = torch.empty((32 if No * Ko <= 1024 * 1024 else 16) * No * Ko, device=dev)
+        fn = lambda: ops.gemm(dy, x, g, ta=True, tb=True, M=No, N=Ko, K=M, lda=No, ldb=Ko, splitk=0, ws=ws, alpha=alpha)
+        fl, by = 2.0 * M * No * Ko, 2.0 * M * (No + Ko) + 4.0 * No * Ko
+    return fn, dict(kernel=GEMM_FAMILY[name][0], symbol="gemm_", flop=fl, bytes=by)
 
 
 def time_case(name, reps=20, warm=3, dev="cuda"):
@@ -91,5 +150,14 @@ def time_case(name, reps=20, warm=3, dev="cuda"):
 if __name__ == "__main__":
     case = sys.argv[1] if len(sys.argv) > 1 else "dw"
     reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+    if case == "all":
+        tot = 0.0
+        for c in ["ffn1", "dw", "attn"] + list(GEMM_FAMILY):
+            m = time_case(c, reps=reps)
+            n = LAUNCHES_PER_STEP.get(c) or GEMM_FAMILY[c][1]
+            tot += n * m["ms"]
+            print(f"{c:6s} {m['ms'] * 1e3:7.1f} us  {m['flop'] / m['ms'] / 1e9:5.0f} TFLOP/s  x{n} = {n * m['ms']:.2f} ms per step   {m['kernel']}")
+        print(f"sum over a step (12 layers, stand-alone times): {tot:.2f} ms")
+        sys.exit(0)
     m = time_case(case, reps=reps)
     print(f"{case}: {m['ms'] * 1e3:.1f} us per call (HIP events) = {m['flop'] / m['ms'] / 1e9:.0f} TFLOP/s algorithmic; {m['kernel']}")
