@@ -185,7 +185,13 @@ def test_bert_base_against_reference_golden(golden_dir, name):
               f"mlm_loss {float(ml):.5f} vs {float(z['mlm_loss']):.5f}")
         assert d.max() < tol and dl.max() < tol and np.abs(itm.numpy() - z["itm"]).max() < tol
         assert abs(float(ml) - float(z["mlm_loss"])) < tol and abs(float(il) - float(z["itm_loss"])) < tol
-        assert (mlm.argmax(-1).numpy() == z["argmax"]).mean() > (0.9999 if dtype == torch.float32 else 0.995)
+        # arg-max: every logit is within `tol` of the reference's, so the logit at the REFERENCE's arg-max index can trail our maximum by
+        # at most 2 tol.  (Random-init logits have near-ties: on the 16-bit path 1-4 of the 512-1024 positions pick the other member of a
+        # pair whose gap is under 1.2e-3 -- which ones changes with any reordering of a sum -- hence no exact agreement rate beyond a sanity bound)
+        ref_idx = torch.from_numpy(z["argmax"].astype(np.int64))
+        at_ref = torch.gather(mlm, -1, ref_idx.unsqueeze(-1)).squeeze(-1)
+        assert float((mlm.max(-1).values - at_ref).max()) <= 2 * tol
+        assert (mlm.argmax(-1).numpy() == z["argmax"]).mean() > (0.9999 if dtype == torch.float32 else 0.98)
         del model
         torch.cuda.empty_cache()
 
