@@ -561,6 +561,7 @@ def test_embed_fwd_bwd(dt):
     sep_tok = torch.full((B,), 102, dtype=torch.int64, device=DEV)
     txt = torch.randint(0, V, (B, T), generator=g_).to(DEV)
     txt[:, -5:] = 0                                     # pads collide on row 0 (atomic contention path)
+    txt[:, 2:9] = 103                                   # [MASK]: the hot row the backward sums per block instead of row by row
     seg = torch.ones((B, T), dtype=torch.int64, device=DEV)
     pos = torch.sort(torch.randperm(256, generator=g_)[:N])[0].view(1, N).expand(B, N).contiguous().to(DEV)
     E, P, Ty = rnd((V, H), dt, 42, 0.05), rnd((maxpos, H), dt, 43, 0.05), rnd((2, H), dt, 44, 0.05)
@@ -589,6 +590,7 @@ def test_embed_fwd_bwd(dt):
     for got, want in ((dE, Ed.grad), (dP, Pd.grad), (dTy, Td.grad), (dg, gd.grad), (db, bd.grad), (dimg, Id.grad)):
         assert relerr(got, want) < tol
     assert float(dE[0].abs().max()) == 0.0          # no look-up gradient for the [PAD] row
+    assert relerr(dE[103], Ed.grad[103]) < tol and float(dE[103].abs().max()) > 0
 
 
 def test_embed_without_image_positions_and_with_its_own_image_dropout():
