@@ -93,7 +93,7 @@ for case in ("dw", "ffn1", "attn"):
                       open(os.path.join(out, f"r04_{case}_pmc.json"), "w"), indent=1)
 txt, _ = stats_table("bench_stats", top=30)
 with open(os.path.join(out, "r04_bench_kernel_stats.txt"), "w") as f:
-    f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras   (MI355X, round 4; 7 steps)\n")
+    f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras --no-kernel-table   (MI355X, round 4; 7 steps)\n")
     f.write("# side-stream kernels (weight gradients, reductions, column sums, keep-bit generator, AdamW) overlap the main chain: durations are\n# inflated by sharing the chip and their sum exceeds the wall time\n")
     f.write(txt)
 print("wrote", sorted(os.listdir(out)))

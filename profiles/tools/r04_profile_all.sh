@@ -14,5 +14,5 @@ for c in dw ffn1 attn; do
   rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum SQ_INSTS_MFMA SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU --output-format csv -d $O/${c}_tcc -- python3 $R/profiles/tools/dominant.py $c 5 > $O/${c}_tcc.log 2>&1
   echo "done $c"
 done
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench_stats -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras > $O/bench_stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench_stats -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras --no-kernel-table > $O/bench_stats.log 2>&1
 python3 $R/profiles/tools/r04_condense.py $O $R/gpurun_out/r4_summary

@@ -67,6 +67,11 @@ def main():
         for g_, a_, b_, at in sorted(gaps, reverse=True)[:14]:
             print(f"   {g_ / 1e3:7.1f} us at {at:6.2f} ms  after {a_[:44]:44s} before {b_[:44]}")
         print(f"   ({len(gaps)} gaps, {sum(g[0] for g in gaps) / 1e6:.2f} ms in total)")
+    if "--timeline" in sys.argv:
+        # every launch of the step in start order: start / end (ms from the step's first launch), queue, kernel -- where the two queues wait for each other
+        print("timeline (start ms, end ms, queue, workgroups, kernel):")
+        for s_, e_, q, n, g_ in sorted(step, key=lambda r: r[0]):
+            print(f"   {(s_ - t0) / 1e6:8.3f} {(e_ - t0) / 1e6:8.3f}  q{q:<3} {g_:6d}  {short(n)}")
     if "--small" in sys.argv:
         print("launches with fewer than 512 workgroups that run longer than 25 us (under-occupied kernels):")
         for s_, e_, q, n, g_ in sorted(step, key=lambda r: r[0] - r[1]):
