@@ -22,10 +22,11 @@ def t(fn, reps=20):
     return e0.elapsed_time(e1) / reps * 1e3
 
 
-for case in ("dw", "dw2", "dwqkv", "dwo", "wo", "dctx", "ffn2", "da", "dxqkv"):
+CASES = sys.argv[1:] or ["dw", "dw2", "dwqkv", "dwo", "wo", "dctx", "ffn2", "da", "dxqkv"]
+for case in CASES:
     fn, meta = make_case(case)
     res = []
-    for name, force, nj in (("default", 0, 0), ("128x128 kernel", 1, 0), ("256-row ring kernel", 2, 0), ("256x128 two blocks per CU", 2, 2)):
+    for name, force, nj in (("default", 0, 0), ("128x128 kernel", 1, 0), ("256-row ring kernel", 2, 0), ("256x128 two blocks per CU", 2, 2), ("256x192 ring", 2, 13)):
         ops.set_gemm_variant(force, nj)
         try:
             us = t(fn)
