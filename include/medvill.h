@@ -53,7 +53,9 @@ enum {
   MV_E_ARG = -1,      /* null pointer / non-positive size */
   MV_E_SHAPE = -2,    /* shape or alignment the kernels do not support */
   MV_E_DTYPE = -3,
-  MV_E_WORKSPACE = -4 /* workspace too small */
+  MV_E_WORKSPACE = -4, /* workspace too small */
+  MV_E_NO_RCCL = -5,   /* mv_comm_*: librccl could not be loaded at run time */
+  MV_E_COMM_BASE = 1000 /* mv_comm_*: 1000 + ncclResult_t of a failed RCCL call */
 };
 
 /* GEMM epilogues (mv_gemm `epi`) */
@@ -184,6 +186,23 @@ int mv_mlm_corrupt(const int64_t* ids, const int32_t* lengths, const float* u, c
  * ahead of the step on a worker thread: the descriptors it derives from probe entries are proven bit for bit on EVERY batch without
  * moving the 134 MB matrix over PCIe.  Both pointers are HOST pointers. */
 int mv_mask_verify_host(const int64_t* mask, int mask_ndim, const int32_t* desc, int B, int L, int threads, long long* first_mismatch);
+
+/* ---- gradient exchange: RCCL over xGMI (one process per GPU) -----------------------------------------------
+ * Replaces nn.DataParallel of models/train_origin.py:53-55 for a host that is not torch (medvill_amd itself reaches the SAME
+ * library through torch.distributed's nccl backend, dist.py: a torch process keeps one communicator).  RCCL is loaded at run time
+ * (dlopen): MV_E_NO_RCCL when it is absent; a failed RCCL call returns MV_E_COMM_BASE + ncclResult_t.
+ *   mv_comm_unique_id        rank 0 makes the 128-byte id, the caller hands it to every rank (any transport)
+ *   mv_comm_init             communicator of `world` ranks on the calling thread's current device
+ *   mv_comm_allreduce_async  in-place SUM all-reduce of `count` elements (MV_F32 / MV_F16 / MV_BF16), enqueued on `stream`:
+ *                            call it per gradient bucket as soon as the backward has finished the bucket, on a side stream
+ *   mv_comm_wait             `stream` (the compute stream, before the optimizer) waits -- on the device -- for every collective
+ *                            issued so far through this communicator; the host never blocks
+ *   mv_comm_destroy                                                                                                    */
+int mv_comm_unique_id(void* id128);
+int mv_comm_init(void** comm_out, int rank, int world, const void* id128);
+int mv_comm_allreduce_async(void* comm, void* buf, size_t count, int dtype, void* stream);
+int mv_comm_wait(void* comm, void* stream);
+int mv_comm_destroy(void* comm);
 
 /* ---- packed rows (padding removal) -------------------------------------------------------------------
  * In the full, seq2seq and 1-D mask families no valid query can see a position after the sample's text [SEP]

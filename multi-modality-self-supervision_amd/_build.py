@@ -17,7 +17,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libmedvill_hip.so")
 SOURCES = ["mv_gemm_ring_tn.hip", "mv_gemm_ring_tn4.hip", "mv_gemm_ring_nt.hip", "mv_gemm_ring_nn.hip", "mv_gemm_ring_tnn.hip", "mv_gemm.hip", "mv_attn.hip",
-           "mv_rowops.hip", "mv_batch.hip", "mv_conv.hip", "mv_hostpack.hip", "mv_api.hip"]      # slowest translation units first
+           "mv_rowops.hip", "mv_batch.hip", "mv_conv.hip", "mv_hostpack.hip", "mv_comm.hip", "mv_api.hip"]      # slowest translation units first
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
 
 

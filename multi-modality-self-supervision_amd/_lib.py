@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("MV_LIB_PATH") or os.path.join(HERE, "libmedvill_hip.s
 MV_F32, MV_BF16, MV_F16 = 0, 1, 2
 EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RES, EPI_DGELU, EPI_RES, EPI_BIAS_TANH, EPI_BIAS_GELU_D, EPI_MUL, EPI_BIAS_RELU, EPI_BIAS_RES_RELU = range(11)
 _ERR = {-1: "MV_E_ARG (null pointer / bad size)", -2: "MV_E_SHAPE (unsupported shape or alignment)",
-        -3: "MV_E_DTYPE", -4: "MV_E_WORKSPACE (workspace too small)"}
+        -3: "MV_E_DTYPE", -4: "MV_E_WORKSPACE (workspace too small)", -5: "MV_E_NO_RCCL (librccl could not be loaded)"}
 
 vp, i32, i64, f32, sz, u64 = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_size_t, C.c_ulonglong
 
@@ -35,6 +35,11 @@ PROTOTYPES = {
     "mv_stream_destroy": [vp],
     "mv_set_rowops_variant": [i32],
     "mv_get_attn_planes": [],
+    "mv_comm_unique_id": [vp],
+    "mv_comm_init": [C.POINTER(C.c_void_p), i32, i32, vp],
+    "mv_comm_allreduce_async": [vp, vp, sz, i32, vp],
+    "mv_comm_wait": [vp, vp],
+    "mv_comm_destroy": [vp],
     "mv_gemm": [i32, i32, i32, i32, i32, i32, vp, i32, vp, i32, vp, i32, i32, vp, i32, vp, i32, i32, vp, i32, vp, i32, i32,
                 i32, vp, sz, i32, f32, u64, vp, vp, vp],
     "mv_mask_pack": [vp, i32, i32, i32, vp, vp, vp],
@@ -109,6 +114,8 @@ def check(rc: int, what: str):
         return
     if rc < 0:
         raise RuntimeError(f"{what}: {_ERR.get(rc, rc)}")
+    if rc >= 1000:
+        raise RuntimeError(f"{what}: ncclResult_t {rc - 1000}")
     raise RuntimeError(f"{what}: hipError_t {rc}")
 
 

@@ -404,6 +404,46 @@ def set_rowops_variant(v: int = 0):
     _lib().mv_set_rowops_variant(int(v))
 
 
+class RcclComm:
+    """The C ABI's own RCCL communicator (mv_comm_*: include/medvill.h), for hosts that do not go through torch.distributed.
+    `medvill_amd.dist.GradAllReducer` (the product's exchange) uses torch's nccl backend instead -- the same library, one communicator
+    per process.  unique_id(): rank 0 makes the 128-byte id and hands it to the other ranks by any transport."""
+
+    def __init__(self, rank: int, world: int, unique_id: bytes):
+        import ctypes
+        if len(unique_id) != 128:
+            raise ValueError("unique_id: 128 bytes (RcclComm.unique_id() on rank 0)")
+        self._h = ctypes.c_void_p()
+        buf = ctypes.create_string_buffer(bytes(unique_id), 128)
+        L.check(_lib().mv_comm_init(ctypes.byref(self._h), int(rank), int(world), buf), "mv_comm_init")
+        self.rank, self.world = rank, world
+
+    @staticmethod
+    def unique_id() -> bytes:
+        import ctypes
+        buf = ctypes.create_string_buffer(128)
+        L.check(_lib().mv_comm_unique_id(buf), "mv_comm_unique_id")
+        return buf.raw
+
+    def allreduce_async(self, t, stream=None):
+        """In-place sum all-reduce of a contiguous f32 / f16 / bf16 device tensor, enqueued on `stream` (default: the current one)."""
+        L.require_cuda(t)
+        if not t.is_contiguous():
+            raise ValueError("allreduce_async: contiguous tensor")
+        st = (stream or torch.cuda.current_stream()).cuda_stream
+        L.check(_lib().mv_comm_allreduce_async(self._h, L.ptr(t), t.numel(), L.dt_of(t), st), "mv_comm_allreduce_async")
+
+    def wait(self, stream=None):
+        """`stream` (default: the current one) waits on the device for every collective issued so far."""
+        st = (stream or torch.cuda.current_stream()).cuda_stream
+        L.check(_lib().mv_comm_wait(self._h, st), "mv_comm_wait")
+
+    def destroy(self):
+        if self._h:
+            L.check(_lib().mv_comm_destroy(self._h), "mv_comm_destroy")
+            self._h = None
+
+
 def set_persistent_cus(n: int = 0):
     """The persistent (weight-gradient) GEMM kernels launch at most n blocks; 0 = one per CU."""
     _lib().mv_set_persistent_cus(int(n))

@@ -93,6 +93,25 @@ VARIANTS["pcus"] = [(f"persistent dW kernels: {n} blocks" if n else "persistent 
                      (lambda n=n: mv.hip_ops.set_persistent_cus(n))) for n in (0, 224, 192, 160, 128)]
 VARIANTS["cumask"] = [("side stream unmasked, 256 persistent blocks", _side_plain)] + \
     [(f"side stream on {n} CUs ({n // 8} per XCD), {n} persistent blocks", _side_masked(n)) for n in (192, 128, 96, 64)]
+_orig_dW = model.engine._dW
+
+
+def _dW_on(force, nj):
+    def f():
+        def dW(*a, **k):
+            mv.hip_ops.set_gemm_variant(force, nj)
+            try:
+                return _orig_dW(*a, **k)
+            finally:
+                mv.hip_ops.set_gemm_variant(0, 0)
+        model.engine._dW = dW if force else _orig_dW
+    return f
+
+
+VARIANTS["dwkernel"] = [("weight gradients: persistent 256x256 kernel (default)", _dW_on(0, 0)),
+                        ("weight gradients: 128x128 kernel, three blocks per CU (room for the main chain's blocks)", _dW_on(1, 0)),
+                        ("weight gradients: 256x256 ring kernel, one unit per block", _dW_on(2, 14)),
+                        ("weight gradients: 256x128 tiles, two blocks per CU", _dW_on(2, 2))]
 which = sys.argv[1] if len(sys.argv) > 1 else "pack"
 arms = VARIANTS[which]
 for _ in range(3):

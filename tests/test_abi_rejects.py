@@ -119,3 +119,16 @@ def test_host_mask_check_through_the_raw_abi(lib):
     assert lib.mv_mask_verify_host(m.ctypes.data, 4, d.ctypes.data, 2, 8, 1, C.byref(out)) == E_SHAPE
     d[1, 0] = 5
     assert lib.mv_mask_verify_host(m.ctypes.data, 3, d.ctypes.data, 2, 8, 1, C.byref(out)) == E_ARG
+
+
+def test_comm_rejects(lib):
+    """mv_comm_*: argument checks come before RCCL is even loaded (it is bound at run time: the library has no link-time dependency on it)."""
+    h = C.c_void_p()
+    assert lib.mv_comm_unique_id(None) == E_ARG
+    assert lib.mv_comm_init(None, 0, 1, P) == E_ARG and lib.mv_comm_init(C.byref(h), 0, 1, None) == E_ARG
+    assert lib.mv_comm_init(C.byref(h), 2, 2, P) == E_ARG and lib.mv_comm_init(C.byref(h), 0, 0, P) == E_ARG
+    assert lib.mv_comm_allreduce_async(None, P, 16, F32, None) == E_ARG and lib.mv_comm_wait(None, None) == E_ARG
+    assert lib.mv_comm_destroy(None) == E_ARG
+    import subprocess
+    out = subprocess.run(["bash", "-c", f"readelf -d {_lib.LIB_PATH} | grep NEEDED"], capture_output=True, text=True).stdout
+    assert "rccl" not in out and "nccl" not in out, out

@@ -228,3 +228,53 @@ def test_one_rank_failing_its_mask_check_changes_no_collective():
     assert torch.equal(p0, p1) and bool(torch.isfinite(p0).all())
     assert rej0 == 0 and rej1 == 2                     # the flipped batch, once per epoch
     assert rec0 == 2 * (3 + 1) and rec1 == 2 * (3 + 2)
+
+
+def _comm_abi_worker(rank, world, path, out):
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(rank)
+    import time
+    import medvill_amd as mv
+    if rank == 0:
+        uid = mv.hip_ops.RcclComm.unique_id()
+        with open(path + ".tmp", "wb") as f:
+            f.write(uid)
+        os.replace(path + ".tmp", path)
+    else:
+        for _ in range(600):
+            if os.path.exists(path):
+                break
+            time.sleep(0.05)
+        uid = open(path, "rb").read()
+    comm = mv.hip_ops.RcclComm(rank, world, uid)
+    dev = torch.device("cuda", rank)
+    side = torch.cuda.Stream(device=dev)
+    res = []
+    for dt in (torch.float32, torch.float16, torch.bfloat16):
+        t = (torch.arange(4096, device=dev, dtype=torch.float32) * (rank + 1) / 64.0).to(dt)
+        want = (torch.arange(4096, dtype=torch.float32) / 64.0).to(dt).float() * sum(r + 1 for r in range(world))
+        side.wait_stream(torch.cuda.current_stream())
+        comm.allreduce_async(t, stream=side)            # a bucket's exchange on the side stream ...
+        comm.wait()                                     # ... the compute stream waits on the device before it reads the sum
+        res.append(float((t.float().cpu() - want).abs().max() / want.abs().max()))
+    torch.cuda.synchronize()
+    comm.destroy()
+    out[rank] = res
+
+
+def test_c_abi_rccl_communicator_on_one_rank(tmp_path):
+    """mv_comm_* (SURVEY 8b's export list): the C ABI's own RCCL binding, bound at run time.  A one-rank communicator on this one-GPU box
+    (the sum over one rank is the identity) exercises id creation, init, asynchronous all-reduce on a side stream, the device-side wait and
+    destroy through RCCL itself; the two-rank form below runs wherever two GPUs are visible."""
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_comm_abi_worker, args=(1, str(tmp_path / "uid0"), out), nprocs=1, join=True)
+    assert max(out[0]) < 1e-6, out[0]
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one device per rank: runs on nodes with >= 2 GPUs")
+def test_c_abi_rccl_communicator_on_two_ranks(tmp_path):
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_comm_abi_worker, args=(2, str(tmp_path / "uid"), out), nprocs=2, join=True)
+    assert max(out[0]) < 1e-2 and max(out[1]) < 1e-2, dict(out)
