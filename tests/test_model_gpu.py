@@ -654,6 +654,27 @@ def test_trainer_derives_descriptors_from_reference_masks_and_verifies_them(fami
             assert abs(got_bad[k] - ref_bad[k]) < 1e-5, k
 
 
+@pytest.mark.parametrize("mode,rejected", [("full", 1), ("sampled", 1), ("off", 0)])
+def test_trainer_mask_verification_policies(mode, rejected):
+    """args.verify_masks: "full" (default) and the first batches of "sampled" check every entry and send a batch with one flipped entry to
+    the matrix; "off" trusts the probe lines (the flip is deep inside the matrix, so that batch runs on the closed form)."""
+    from types import SimpleNamespace
+    V, B, N, S = 2048, 4, 6, 41
+    cfgd = dict(vocab_size=V, hidden_size=128, num_hidden_layers=1, num_attention_heads=2, intermediate_size=512, max_position_embeddings=64)
+
+    def tup(seed, flip):
+        b = mv.data.synthetic_batch(V, B, N, S, "s2s", seed=seed, device="cpu")
+        m = b["attn_mask"].clone()
+        if flip:
+            m[3, N + 20, N + 7] ^= 1
+        return (b["cls_tok"], b["input_txt"], b["txt_labels"], m, (b["img_feats"], b["img_pos"]), b["segment"], b["is_aligned"], b["sep_tok"], torch.zeros(B))
+    args = SimpleNamespace(with_cuda=True, weight_load=False, bert_model="custom", lr=1e-3, log_freq=10, mlm_task=True, itm_task=True,
+                           cuda_devices=[0], dropout_prob=0.1, verify_masks=mode)
+    tr = mv.CXRBERT_Trainer(args, [tup(1, False), tup(2, True), tup(3, False)], None, config=cfgd, dtype=torch.bfloat16)
+    res = tr.train(0)
+    assert np.isfinite(res["avg_loss"]) and tr.n_recognised == 3 and tr.n_rejected == rejected
+
+
 def test_trainer_mirror_runs_an_epoch_and_saves(tmp_path):
     """CXRBERT_Trainer(args, train_dl, test_dl).train(epoch) / .save(epoch, path) as main_origin.py:57-62 drives it,
     fed with the reference's 9-tuple batches (dataset_origin.py:181) on the host."""
