@@ -87,10 +87,29 @@ HBM_PEAK_GBS = 8000.0           # MI355X HBM3E (MI355X_MICROARCH.md)
 RIDGE_FLOP_PER_BYTE = PEAK_BF16_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)      # 312.5: below it a kernel is HBM-bound by the roofline
 
 
+_PROFILE = None
+
+
+def committed_profile(case):
+    """profiles/r05_kernels.json[case] (profiles/tools/r05_profile_all.sh + r05_condense.py: HIP events, rocprofv3 --kernel-trace --stats and the
+    FETCH_SIZE / WRITE_SIZE passes of profiles/tools/dominant.py <case>, all in ONE lease on one box) or None."""
+    global _PROFILE
+    if _PROFILE is None:
+        try:
+            with open(os.path.join(ROOT, "profiles", "r05_kernels.json")) as f:
+                _PROFILE = json.load(f)
+        except (OSError, ValueError):
+            _PROFILE = {}
+    return _PROFILE.get(case)
+
+
 def pmc_traffic(case):
-    """HBM bytes per launch of a kernel from the committed rocprofv3 PMC passes (profiles/r04_<case>_pmc.json, written by
-    profiles/tools/r04_condense.py from separate FETCH_SIZE / WRITE_SIZE runs of profiles/tools/dominant.py <case>): an offline
-    measurement of the same kernel on the same operands, not of this run.  None when the file is absent."""
+    """HBM bytes per call of a kernel family from the committed rocprofv3 PMC passes (separate FETCH_SIZE / WRITE_SIZE runs of
+    profiles/tools/dominant.py <case>, gfx950 corrections per MI355X_MICROARCH.md): an offline measurement of the same kernel on the same
+    operands, not of this run."""
+    pr = committed_profile(case)
+    if pr and pr.get("hbm_bytes_per_call"):
+        return float(pr["hbm_bytes_per_call"]), pr.get("note", "") + " [profiles/r05_kernels.json]"
     for rnd in ("r04", "r03"):
         p = os.path.join(ROOT, "profiles", f"{rnd}_{case}_pmc.json")
         try:
@@ -103,23 +122,35 @@ def pmc_traffic(case):
 
 
 def time_kernel_case(case):
-    """One of the step's heaviest kernels alone: HIP events around 20 launches on the stream it is launched on, on the seeded
-    operands of profiles/tools/dominant.py -- the SAME definition the committed rocprofv3 summaries (profiles/r03_<case>_kernel_stats.txt)
-    were taken with, so `achieved` can be recomputed from that file's average duration."""
+    """One of the step's kernel families alone: HIP events on the stream it is launched on, 50 warm-up calls, then 200 timed calls in
+    batches of 10 -- MEDIAN batch (min / max beside it) -- on the seeded operands of profiles/tools/dominant.py: the SAME command the
+    committed rocprofv3 passes ran (profiles/r05_<case>_kernel_stats.txt, profiles/r05_kernels.json).  `profile` puts that lease's
+    rocprofv3 figure beside this run's: the two agree within 5 % on the same box; boxes of the pool differ by more (clock under load)."""
     sys.path.insert(0, os.path.join(ROOT, "profiles", "tools"))
     import dominant
-    m = dominant.time_case(case, reps=20)
+    m = dominant.time_case(case)
     traffic, note = pmc_traffic(case)
     tfl = m["flop"] / m["ms"] / 1e9
     gbs = m["bytes"] / m["ms"] / 1e6
     ai = m["flop"] / m["bytes"]
     bound = "mfma" if ai >= RIDGE_FLOP_PER_BYTE else "hbm"
-    prof = next((f"profiles/{r}_{case}_kernel_stats.txt" for r in ("r04", "r03")
-                 if os.path.exists(os.path.join(ROOT, "profiles", f"{r}_{case}_kernel_stats.txt"))), None)
+    pr = committed_profile(case)
+    prof = None
+    if pr and pr.get("rocprof_call_us_median_after_warmup"):
+        ref_us = float(pr["rocprof_call_us_median_after_warmup"])
+        prof = dict(file=f"profiles/r05_{case}_kernel_stats.txt (+ profiles/r05_kernels.json)",
+                    rocprof_us_median_after_warmup=ref_us, rocprof_us_avg_after_warmup=pr.get("rocprof_call_us_avg_after_warmup"),
+                    rocprof_us_avg_all_launches=pr.get("rocprof_call_us_avg_all_launches"),
+                    hip_event_us_median_same_lease=pr.get("hip_event_median_us"),
+                    tflops_from_profile=m["flop"] / ref_us / 1e6, frac_from_profile=m["flop"] / ref_us / 1e6 / PEAK_BF16_TFLOPS,
+                    this_run_over_profile=m["ms"] * 1e3 / ref_us, agrees_within_5pct=abs(m["ms"] * 1e3 / ref_us - 1.0) <= 0.05)
     n = dominant.LAUNCHES_PER_STEP.get(case) or dominant.GEMM_FAMILY[case][1]
-    return dict(name=case, kernel=m["kernel"], ms=m["ms"], us=m["ms"] * 1e3, tflops=tfl, algorithmic_flop=m["flop"], algorithmic_bytes=m["bytes"],
+    return dict(name=case, kernel=m["kernel"], ms=m["ms"], us=m["ms"] * 1e3, us_min=m["ms_min"] * 1e3, us_max=m["ms_max"] * 1e3,
+                timing=f"HIP events, median of {m['timed_calls'] // 10} batches of 10 calls after {m['warmup_calls']} warm-up calls",
+                tflops=tfl, algorithmic_flop=m["flop"], algorithmic_bytes=m["bytes"],
                 arithmetic_intensity_flop_per_byte=ai, bound=bound, mfma_frac=tfl / PEAK_BF16_TFLOPS, frac=tfl / PEAK_BF16_TFLOPS,
-                hbm_frac=gbs / HBM_PEAK_GBS, algorithmic_gb_per_s=gbs, hbm_traffic_pmc_bytes=traffic, traffic_note=note,
+                hbm_frac=gbs / HBM_PEAK_GBS, algorithmic_gb_per_s=gbs, hbm_traffic_pmc_bytes=traffic,
+                traffic_over_algorithmic=(traffic / m["bytes"]) if traffic else None, traffic_note=note,
                 launches_per_step=n, ms_per_step_alone=n * m["ms"], profile=prof)
 
 
@@ -427,14 +458,16 @@ def main():
                        "expected_exposed_allreduce_ms_at_8_ranks": "0.5-0.6 (model, DESIGN.md 7; unmeasured)",
                        "mlm_loss": float(st[0] / max(float(st[1]), 1.0)), "itm_loss": float(st[3] / max(float(st[4]), 1.0))},
             # dominant kernel (the FFN-up GEMM, largest single share of the step): algorithmic FLOPs per launch / its
-            # average duration, HIP events around 20 launches on its own stream (time_dominant_kernel); traffic = HBM bytes
-            # per launch from the committed rocprofv3 PMC passes of the same kernel and shape (profiles/), not of this run
+            # median duration, HIP events over 200 launches after 50 warm-up launches on its own stream (time_kernel_case); traffic = HBM
+            # bytes per launch from the committed rocprofv3 PMC passes of the same kernel and shape (profiles/), not of this run
             "roofline": {"bound": kern["bound"],
                          "achieved": kern["tflops"] if kern["bound"] == "mfma" else kern["algorithmic_gb_per_s"],
                          "peak": PEAK_BF16_TFLOPS if kern["bound"] == "mfma" else HBM_PEAK_GBS,
                          "unit": "TFLOP/s" if kern["bound"] == "mfma" else "GB/s",
                          "frac": kern["mfma_frac"] if kern["bound"] == "mfma" else kern["hbm_frac"],
                          "traffic": kern["hbm_traffic_pmc_bytes"],
+                         # the committed rocprofv3 pass of the same command (same-lease HIP events beside it): frac recomputed from it
+                         "profile": kern["profile"],
                          "ridge_flop_per_byte": RIDGE_FLOP_PER_BYTE,
                          "kernel": kern, "weight_gradient_gemm": kern_dw, "attention": kernels[2] if len(kernels) > 2 else None,
                          "kernels": kernels,

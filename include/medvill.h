@@ -19,8 +19,8 @@
  *   - every call takes the hipStream_t to enqueue on (as void*) and never synchronises.
  *   - return 0 = ok; negative = invalid argument / unsupported shape (MV_E_*);
  *     positive = hipError_t of a failed launch.  Nothing throws.
- *   - re-entrant, no global mutable state except the test hooks mv_set_impl() / mv_set_gemm_variant() and the launch policy
- *     mv_set_persistent_cus().
+ *   - re-entrant, no global mutable state: which kernel serves a call follows from the call's arguments alone.  (The kernel-forcing
+ *     knobs that tests and timing experiments use exist only in libmedvill_hip_dbg.so: include/medvill_debug.h.)
  *   - dtype: MV_F32 = exact fp32 path (plain VALU kernels; parity at 1e-3 and below),
  *            MV_BF16 / MV_F16 = 16-bit storage, fp32 accumulate, MFMA kernels (the fast path).
  *   - matrices are row-major; "ld*" are leading dimensions in ELEMENTS.
@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define MV_ABI_VERSION 5
+#define MV_ABI_VERSION 6
 
 /* MV_F16 is the encoding of the 16-bit path (weights' f16 shadow, stored activations, gradients): 11 significand bits
  * instead of bf16's 8 at the same MFMA rate.  At BERT-base depth bf16-encoded forward operands cannot meet the 1e-2 logit
@@ -55,7 +55,8 @@ enum {
   MV_E_DTYPE = -3,
   MV_E_WORKSPACE = -4, /* workspace too small */
   MV_E_NO_RCCL = -5,   /* mv_comm_*: librccl could not be loaded at run time */
-  MV_E_COMM_BASE = 1000 /* mv_comm_*: 1000 + ncclResult_t of a failed RCCL call */
+  MV_E_COMM_BASE = -1000 /* mv_comm_*: a failed RCCL call returns MV_E_COMM_BASE - ncclResult_t (-1001, -1002, ...): negative like every
+                            MV_E_* code, disjoint from hipError_t (positive, some of them above 1000) */
 };
 
 /* GEMM epilogues (mv_gemm `epi`) */
@@ -75,28 +76,12 @@ enum {
   MV_EPI_BIAS_RES_RELU = 10  /* C = max(A.B + bias[n] + R[m,n], 0)   ... + the bottleneck's identity branch                          */
 };
 
-/* implementation selector (test hook): 0 = auto (MFMA for bf16, VALU for f32), 1 = force the
- * plain VALU kernels for every dtype. */
 int mv_abi_version(void);
-void mv_set_impl(int impl);
-int mv_get_impl(void);
 const char* mv_build_info(void);
-/* test hook for mv_gemm's MFMA tile choice: force = 0 auto / 1 the 128x128x64 kernel / 2 the 256-row
- * LDS-DMA kernel; nj = 0 auto / 3 (256x192 tile) / 4 (256x256 tile). */
-void mv_set_gemm_variant(int force, int nj);
-/* Compute-unit partitioning between the streams of a step (host policy, see Engine): the persistent GEMM kernels (weight gradients)
- * launch at most n blocks (0 = one per CU), and mv_stream_create_cumask makes a HIP stream whose kernels run only on the CUs of
- * `mask_words` (n_words x 32 bits; hipExtStreamCreateWithCUMask; on a multi-XCD device bit i is CU i / n_xcd of XCD i % n_xcd). */
-void mv_set_persistent_cus(int n);
-int mv_get_persistent_cus(void);
+/* A HIP stream whose kernels run only on the CUs of `mask_words` (n_words x 32 bits; hipExtStreamCreateWithCUMask; on a multi-XCD
+ * device bit i is CU i / n_xcd of XCD i % n_xcd): lets a host partition the chip between the streams of a step. */
 int mv_stream_create_cumask(const uint32_t* mask_words, int n_words, void** stream_out);
 int mv_stream_destroy(void* stream);
-/* test / experiment hook for mv_layernorm_bwd: low byte 0 = prefetching kernel, 8 waves per block (default) / 1 = one row at a time, 4 waves / 2, 3 = prefetching, 4 / 16 waves; bits 8.. = grid cap (0 = default) */
-void mv_set_rowops_variant(int v);
-/* bits per uniform of the attention-dropout mask generator (mv_attn_dropmask): 16 (default), 12 or 8.  P(drop) = round(p * 2^n) / 2^n;
- * the generator's time is proportional to n.  Process-wide: set before the masks of a forward are generated. */
-void mv_set_attn_planes(int planes);
-int mv_get_attn_planes(void);
 
 /* ---- dense projections --------------------------------------------------------------------
  * Replaces every nn.Linear on the path and its autograd backward:
@@ -134,6 +119,17 @@ int mv_gemm(int dtype, int ta, int tb, int M, int N, int K,
             void* C3, int ldc3, int c3_dtype,
             int splitk, float* ws, size_t ws_bytes, int accumulate,
             float p_drop, unsigned long long drop_key, const float* alpha_dev, float* colsum_part, void* stream);
+
+/* Split-K workspace sizes (SURVEY 8b's mv_workspace_bytes): what a host needs to allocate without reading the dispatch code.
+ *   mv_gemm_workspace_bytes  bytes of `ws` with which mv_gemm(splitk = 0) takes the split-K choice it prefers for this product
+ *                            (slabs x M x N x 4; 0 = this call never splits: f32 data, a wide / large product, K < 2048).  A smaller
+ *                            workspace is legal: mv_gemm then takes as many slabs as fit.
+ *   mv_workspace_bytes       the largest such workspace any mv_gemm call of a pretraining step asks for at this geometry (weight
+ *                            gradients of the four encoder projections, of the MLM transform and of the image projection over
+ *                            `max_rows` / `max_label_rows` / `max_regions` rows; the tied decoder's input gradient over the
+ *                            vocabulary).  One workspace PER STREAM that issues split-K products concurrently.  Pure functions. */
+size_t mv_gemm_workspace_bytes(int dtype, int ta, int tb, int M, int N, int K);
+size_t mv_workspace_bytes(int hidden, int intermediate, int vocab, int img_hidden, int max_rows, int max_label_rows, int max_regions);
 
 /* ---- attention masks ----------------------------------------------------------------------
  * Replaces CXRBertEncoder.get_extended_attn_mask (cxrbert_origin.py:75-85): instead of an
@@ -251,7 +247,7 @@ int mv_attn_fwd(int dtype, const void* qkv, const uint32_t* bits, const uint8_t*
 /* The attention-probability dropout mask of one layer as keep-bits, laid out as the kernels' select masks:
  * dropbits uint32 [B*A][ceil(L/32)][ceil(L/64)][64] (64-byte aligned), i.e. per (head, 32-query block, 64-key tile) 32 x uint64;
  * word 16*kk + r, bit l <-> query 32*qb + (l & 31), key 64*kt + 32*kk + (r&3) + 8*(r>>2) + 4*(l>>5); bit = 1 keeps the entry.
- * Every entry is an independent Bernoulli draw with P(drop) = round(p_drop * 2^n) / 2^n (n = mv_get_attn_planes() = 16: 0.1 -> 0.100006), a counter-based
+ * Every entry is an independent Bernoulli draw with P(drop) = round(p_drop * 2^n) / 2^n (n = 16: 0.1 -> 0.100006; the debug library has a knob for 12 / 8), a counter-based
  * hash of (drop_key, word index): the same key reproduces the same mask.  Blocks whose queries or keys all lie beyond the
  * sample's packed length (cu, nullable) are not written and never read.  Depends on the key only: it can run ahead of the
  * forward on another stream.  */

@@ -193,6 +193,7 @@ struct AttnArgs {
   // lse of the other rows untouched, the backward writes zero dQ rows for them and ignores their dctx rows.  Used for the last encoder
   // layer, whose rows are reordered so that the rows the heads consume come first (mv_tail_perm).
   const int32_t* qlim;
+  int order;        // att_block(): block -> (row block, head, sample) order
 };
 // ---- precomputed dropout keep-bits -------------------------------------------------------------------------------------------
 typedef unsigned long long u64x8 __attribute__((ext_vector_type(8)));
@@ -345,7 +346,7 @@ __device__ __forceinline__ bf16x8 frag_tr(const char* tile, int cbase, int rb, i
 // The same two fragment reads with the lane-dependent part of att_off() taken out of the tile loop.  Per lane and tile-invariant:
 //   rk = (lane&31)*128 + ((h ^ f0) << 4) + ((f >> 1) << 5)        f = att_f(lane & 31): bits 5-6 of rk ARE the chunk swizzle of s = 0
 //   tr = (4h' + q)*128 + ((q >> 1) << 6) + ((g & 1) << 5) + ((c0 ^ h') << 4) + 8 (li & 1)
-// so that, for a tile at LDS byte address T (a multiple of 8 KiB: no carry into the XORed bits),
+// so that, for a tile at LDS byte address T (a multiple of 128 B -- the XORs touch bits 4-6 only, and T + rk / T + tr carry nothing into them),
 //   frag_row(T, base, s)      = ((T + rk) ^ (s << 5)) + 128 base                                 base = 0 / 32
 //   frag_tr (T, 32 dt, rb) lo = ((T + tr) ^ (dt << 6)) + 128 rb,   hi = (... ^ 32) + 128 rb + 1024
 // i.e. one add per tile and one XOR per (s) / (dt, half); everything else is an instruction immediate.  Before, hipcc rebuilt every
@@ -449,19 +450,44 @@ __device__ __forceinline__ int next_tile(unsigned long long need, int after, int
 }
 
 // ---- forward --------------------------------------------------------------------------------
-// Block -> (128-row block xb, head, sample).  Workgroups go to the 8 XCDs round-robin in dispatch order (x fastest).  With
-// (x, y, z) = (row block, head, sample) read off blockIdx directly, XCD k only ever saw row block k % 4 -- and in a packed or ragged batch
-// the LAST row block of most samples is nearly empty (390 of 512 rows on average): two XCDs idled while six did the work (found with the
-// query-limit sweep of profiles/tools/tailq_bench.py: a launch with one row block per head ran on 2 XCDs).  Here the row block is the SLOWEST
-// index of the dispatch order: every XCD gets every row block of its (head, sample) pairs -- which also share their K / V tiles in that
-// XCD's L2 -- and the nearly empty blocks come last.
-__device__ __forceinline__ void att_block(int& xb, int& head, int& b) {
+// Block -> (128-row block xb, head, sample).  Workgroups go to the 8 XCDs round-robin in dispatch order (x fastest), each XCD has its own
+// 4 MiB L2, and the row blocks of one (sample, head) pair all stream the SAME K / V rows (forward, dQ) or Q / dO rows (dK/dV): 128 KiB at
+// L = 512.  Three orders have existed:
+//   blockIdx as is (rounds 1-2): the row block is the fastest index, so the pair's four row blocks go to four DIFFERENT XCDs -- and XCD k
+//     only ever sees row block k % 4, nearly empty for the last block of a packed sample: two XCDs idled.
+//   order 0 (rounds 3-5, the default): the row block is the SLOWEST index.  Even load; the row blocks of a pair run a whole wave of ~768
+//     resident blocks apart, so every block fetches its K / V over the fabric (profiles/r04_attn_pmc.json: 2.97x the algorithmic
+//     bytes, L2 hit 16-28 %) -- which is NOT what bounds these kernels:
+//   order 1 (round 5 experiment, debug knob attn_order): flat = 8 * (group * nxb + xb) + x, pair = 8 * group + x.  The nxb row blocks of
+//     a pair are 8 apart in dispatch order -- consecutive blocks of ONE XCD, resident together -- so the pair's K / V is fetched into
+//     that L2 once.  Measured in one process against order 0 (profiles/tools/attn_order_ab.py, profiles/r05_notes.txt): bidirectional
+//     packed forward 82.5 -> 81.2 us, backward 257 -> 266 us; BAR forward 97 -> 116, backward 293 -> 353; seq2seq backward 190 -> 246; whole
+//     step 24.22 -> 24.36 ms.  With row-dependent masks the blocks resident together then differ in length by up to 4x and the launch
+//     ends on a tail of long blocks; with uniform masks nothing is gained either: the kernels wait on dependent latency inside a tile
+//     (DESIGN.md 8), not on fabric bandwidth.  Pairs beyond the last multiple of 8 fall back to the row-block-fastest walk.
+//   Placement is a speed matter only: nothing depends on it for correctness (outputs are bit-identical in both orders).
+__device__ __forceinline__ void att_block(const AttnArgs& a, int& xb, int& head, int& b) {
   const int flat = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-  const int nhb = gridDim.y * gridDim.z;
-  xb = flat / nhb;
-  const int rem = flat - xb * nhb;
-  b = rem / gridDim.y;
-  head = rem - b * gridDim.y;
+  const int nxb = gridDim.x, nhb = gridDim.y * gridDim.z;
+  int pair;
+  if (a.order == 0) {
+    xb = flat / nhb;
+    pair = flat - xb * nhb;
+  } else {
+    const int full = (nhb >> 3) << 3;               // pairs covered by whole groups of 8
+    if (flat < full * nxb) {
+      const int x = flat & 7, k = flat >> 3;
+      const int g = k / nxb;
+      xb = k - g * nxb;
+      pair = 8 * g + x;
+    } else {
+      const int r = flat - full * nxb;
+      pair = full + r / nxb;
+      xb = r - (pair - full) * nxb;
+    }
+  }
+  b = pair / gridDim.y;
+  head = pair - b * gridDim.y;
 }
 // A wave's [32 rows][64 columns] 16-bit output tile leaves as WHOLE 128-byte row segments.  The tile sits in two 32x32 accumulators with
 // the rows on the lanes (lane (l31, h), register reg of acc[dt]: row l31, column 32 dt + acc_row(reg, h)), so a direct store writes 8 bytes of
@@ -474,6 +500,13 @@ template <bool F16>
 __device__ __forceinline__ void store_rows_tile(char* patch, const f32x16 (&acc)[2], float scale, bool lane_ok, bf16_t* g_row0, size_t ld,
                                                 int rows_ok, int lane) {
   const int l31 = lane & 31, h = lane >> 5;
+  // The patch is written and read by ONE wave (different lanes touch the same bytes).  The hardware completes a wave's LDS operations in
+  // order; the COMPILER is told so explicitly -- a wavefront-scope fence pair around a wave barrier (no instruction: a scheduling and
+  // memory-ordering point) before the writes (a previous use of the same patch: dK then dV) and between the writes and the reads --
+  // instead of relying on it failing to prove the addresses disjoint.
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
   for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -484,7 +517,9 @@ __device__ __forceinline__ void store_rows_tile(char* patch, const f32x16 (&acc)
       if constexpr (F16) st4<f16_t>((f16_t*)dst, v);
       else st4<bf16_t>(dst, v);
     }
-  // (same wave writes and reads the patch: LDS operations of a wave complete in order, the compiler waits on lgkmcnt before the reads' use)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int r = (lane >> 3) + 8 * i, c = lane & 7;
@@ -620,7 +655,7 @@ __device__ __forceinline__ void fwd_tile(const AttnArgs& a, unsigned tk, unsigne
 #define FWD_NS 3      // 48 KiB of LDS per block: three blocks per CU
 template <bool F16>
 __global__ __launch_bounds__(256, 3) void attn_fwd_mfma_kernel(AttnArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // FWD_NS stages x (K 8 KiB + V 8 KiB)
+  extern __shared__ __attribute__((aligned(128))) char smem[];   // (fragment addressing XORs bits 4-6 of tile base + lane word: bases are multiples of 128)   // FWD_NS stages x (K 8 KiB + V 8 KiB)
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   int xb, head, b;
@@ -628,7 +663,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_mfma_kernel(AttnArgs a) {
 #if ATT_ABL & 256
   if (a.B > 0) return;            // dispatch cost of the grid alone
 #endif
-  att_block(xb, head, b);
+  att_block(a, xb, head, b);
   const int L = a.L, H = a.H, ld = 3 * a.H, T = a.T;
   const int qb0 = xb * 128, q0 = qb0 + wid * 32, q = q0 + l31;
   // The tile classes depend on the block index alone: requested BEFORE the row plan (cu, qlim), not behind it -- a block's prologue is a chain
@@ -739,6 +774,226 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_mfma_kernel(AttnArgs a) {
   PROF_FLUSH(0);
 }
 
+// ---- forward, two 32-query sub-tiles per wave (round 5) -----------------------------------------------------------------------
+// The one-sub-tile kernel above spends 5,200-5,800 cycles of wall time per tile body against ~1,700 cycles of its own issue: each wave is ONE
+// dependency chain (LDS reads -> score MFMAs -> row maximum -> exponentials -> conversions -> P.V MFMAs) and a SIMD holds two or three of
+// them (profiles/r04_notes.txt).  Here a wave owns 64 queries as TWO independent 32-query chains over the same K / V tile: every K and V
+// fragment is read from LDS once and feeds both chains' MFMAs (half the LDS fragment traffic per FLOP), and while one chain is in its
+// softmax arithmetic the other's MFMAs are in the matrix pipe -- from the SAME wave, so it does not depend on what the SIMD's other wave is
+// doing.  A block is 4 waves = 256 queries (a [256, 64] context tile), half as many blocks pay the 12.6 k-cycle prologue; ~200 registers,
+// two blocks per CU, a ring of four K / V stages (64 KiB).  Same arithmetic per element as attn_fwd_mfma_kernel in the same order: results
+// are bit-identical to it (tests/test_kernels_gpu.py).
+template <bool DROP, bool F16>
+__device__ __forceinline__ void fwd2_tile(const AttnArgs& a, unsigned tk, unsigned tv, unsigned tq, f32x16 (&o)[2][2], float (&m2)[2],
+                                          float (&lsum)[2], const uint32_t* const (&myw)[2], const bool (&q_ok)[2], int k0, int Lv, int cls, bool plain,
+                                          float c2, float neg, int h, const unsigned long long* const (&mp)[2]) {
+  f32x16 st[2][2];        // [sub-tile][32-key half]
+#pragma unroll
+  for (int qi = 0; qi < 2; ++qi)
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) st[qi][kk][i] = 0.f;
+  // scores of both sub-tiles: per 16-deep slice of dh two Q fragments (from the wave's own Q image in LDS: 32 registers of Q fragments
+  // held across the loop made hipcc spill them to scratch, and every reload's vmcnt wait drained the LDS-DMA ring) and two K fragments,
+  // four MFMAs -- every K fragment is read once for both sub-tiles
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const bf16x8 q0f = frag_row_x(tq, 0, s), q1f = frag_row_x(tq, 32, s);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const bf16x8 kf = frag_row_x(tk, 32 * kk, s);
+      st[0][kk] = mma32<F16>(kf, q0f, st[0][kk]);
+      st[1][kk] = mma32<F16>(kf, q1f, st[1][kk]);
+    }
+  }
+  // A tile that is not all-visible (class 2) or that holds the sample's ragged end gets its additive mask HERE, in place, in raw score
+  // units (neg = -10000 / scale, so that neg * scale * log2(e) is the reference's -10000 in the exponent's units; keys past the sample's
+  // end: -inf).  ONE tile body: with a body per tile class (as the one-sub-tile kernel has) the 128 accumulator registers of this kernel
+  // came out of the classes' code in different registers and hipcc paid the merge with 74 spilled registers.
+  if (!plain) {
+    const bool tail = (k0 + 64 > Lv);
+#pragma unroll
+    for (int qi = 0; qi < 2; ++qi)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        uint32_t w = 0xffffffffu;
+        if (cls != 1) { const int wi = (k0 >> 5) + kk; w = (q_ok[qi] && wi < a.W) ? myw[qi][wi] : 0xffffffffu; }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int kr = acc_row(r, h);
+          float v = st[qi][kk][r] + (((w >> kr) & 1u) ? 0.f : neg);
+          if (tail && (k0 + 32 * kk + kr >= Lv)) v = -INFINITY;
+          st[qi][kk][r] = v;
+        }
+      }
+  }
+  float alpha[2];
+#pragma unroll
+  for (int qi = 0; qi < 2; ++qi) {
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[qi][kk][r]);
+    mx *= c2;
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float mn = fmaxf(m2[qi], mx);
+    alpha[qi] = fexp2(m2[qi] - mn);
+    m2[qi] = mn;
+    f32x2 ps2 = {0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const float p0 = fexp2(fmaf(st[qi][kk][r], c2, -mn));
+        const float p1 = fexp2(fmaf(st[qi][kk][r + 1], c2, -mn));
+        st[qi][kk][r] = p0;
+        st[qi][kk][r + 1] = p1;
+        ps2 += (f32x2){p0, p1};
+      }
+    const float ps = ps2[0] + ps2[1];
+    lsum[qi] = lsum[qi] * alpha[qi] + ps;          // the normaliser sums the UNdropped probabilities
+    if (DROP) {
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        u64x8 m0, m1;
+        sload_masks16(mp[qi] + 16 * kk, m0, m1);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {       // `ps` was computed from these values by compiler-scheduled adds: see sel_lane_after
+          st[qi][kk][r] = sel_lane_after(st[qi][kk][r], ps, m0[r]);
+          st[qi][kk][8 + r] = sel_lane_after(st[qi][kk][8 + r], ps, m1[r]);
+        }
+        __builtin_amdgcn_sched_barrier(0);      // 32 mask SGPRs live at a time: hoisting the four loads of a tile spilled ~100 SGPRs
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { o[qi][0][i] *= alpha[qi]; o[qi][1][i] *= alpha[qi]; }
+  }
+  // P.V of both sub-tiles: one V fragment read, two MFMAs
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      bf16x8 pf[2];
+#pragma unroll
+      for (int qi = 0; qi < 2; ++qi) pf[qi] = pack8t<F16>(st[qi][kk], s2);
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        const bf16x8 vf = frag_tr_x(tv, dt, 32 * kk + 16 * s2);
+#pragma unroll
+        for (int qi = 0; qi < 2; ++qi) o[qi][dt] = mma32<F16>(vf, pf[qi], o[qi][dt]);
+      }
+    }
+}
+
+#define FWD2_LDS (FWD2_NS * 16384 + 4 * 8192)
+#define FWD2_NS 3      // 48 KiB of K / V stages + 32 KiB of Q images = 80 KiB of LDS per block: two blocks per CU
+template <bool F16, bool DROP>
+__global__ __launch_bounds__(256, 2) void attn_fwd2_mfma_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(128))) char smem[];   // FWD2_NS stages x (K 8 KiB + V 8 KiB) | 4 waves x Q image 8 KiB
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int xb, head, b;
+  att_block(a, xb, head, b);
+  const int L = a.L, H = a.H, ld = 3 * a.H, T = a.T;
+  const int qb0 = xb * 256, q0 = qb0 + wid * 64;
+  // tile classes of the block's four 64-row tiles (lane t holds key tile t), requested before the row plan like the kernel above
+  TileMasks tmk;
+  {
+    const int ta = qb0 >> 6, tw = min(q0 >> 6, T - 1);
+    uint8_t cw = 0;
+    bool any = false;
+    if (lane < T) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (ta + i < T) {
+          const uint8_t c = a.info[((size_t)b * T + ta + i) * T + lane];
+          any |= (c != 0);
+          if (ta + i == tw) cw = c;
+        }
+      }
+    }
+    tmk.need = __ballot(any);
+    tmk.w_nz = __ballot(cw != 0);
+    tmk.w_is1 = __ballot(cw == 1);
+  }
+  const int Lv = a.cu ? a.cu[b + 1] - a.cu[b] : L;             // positions of this sample that exist as rows
+  const int Lq = a.qlim ? min(Lv, a.qlim[b]) : Lv;             // ... and those that are queries
+  if (qb0 >= Lq) return;
+  const bool wave_on = q0 < Lq;
+  const int q[2] = {q0 + l31, q0 + 32 + l31};
+  const bool q_ok[2] = {q[0] < Lq, q[1] < Lq};
+  const size_t rowbase = a.cu ? (size_t)a.cu[b] : (size_t)b * L;
+  const size_t lrow = (size_t)b * L;                            // logical row base (mask words)
+  const dma_rsrc_t rsq = dma_rsrc(a.qkv, a.bytes_qkv);
+  // the wave's own [64 queries][64] Q image (rows past Lq zero-filled), by LDS-DMA: older than every K / V transfer of this wave, so the
+  // first counted wait of the tile loop covers it; only this wave reads it
+  char* const qimg = smem + FWD2_NS * 16384 + wid * 8192;
+  tile_dma<1>(rsq, a.bytes_qkv, rowbase, q0, Lq, ld, head * 64, qimg, 0, lane);
+
+  const float c2 = a.scale * LOG2E, neg = MASK_ADD / a.scale;
+  float m2[2] = {-INFINITY, -INFINITY}, lsum[2] = {0.f, 0.f};
+  f32x16 o[2][2];
+#pragma unroll
+  for (int qi = 0; qi < 2; ++qi)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { o[qi][0][i] = 0.f; o[qi][1][i] = 0.f; }
+
+  const int nkt = (Lv + 63) / 64;
+  int cur = next_tile(tmk.need, -1, nkt);
+  int iss = cur, issued = 0, done = 0;
+  auto issue = [&]() {
+    char* st_ = smem + (issued % FWD2_NS) * 16384;
+    tile_dma<4>(rsq, a.bytes_qkv, rowbase, iss * 64, Lv, ld, H + head * 64, st_, wid, lane);
+    tile_dma<4>(rsq, a.bytes_qkv, rowbase, iss * 64, Lv, ld, 2 * H + head * 64, st_ + 8192, wid, lane);
+    ++issued;
+    iss = next_tile(tmk.need, iss, nkt);
+  };
+#pragma unroll
+  for (int i = 0; i < FWD2_NS - 1; ++i)
+    if (iss < nkt) issue();
+  const uint32_t* const myw[2] = {a.bits + (lrow + (q_ok[0] ? q[0] : 0)) * a.W, a.bits + (lrow + (q_ok[1] ? q[1] : 0)) * a.W};
+  const FragLane fl = frag_lane(lane);            // two registers held across the loop: the lane's part of every fragment address
+  const unsigned smem_a = lds_addr(smem);
+  while (cur < nkt) {
+    att_wait_stage<4>(issued - done - 1);           // this wave's pieces of tile `cur` have landed ...
+    __builtin_amdgcn_s_barrier();                   // ... and everybody's; everybody is done reading the slot refilled next
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned tKa = smem_a + (unsigned)(done % FWD2_NS) * 16384u;
+    const int cls = !wave_on ? 0 : (((tmk.w_is1 >> cur) & 1) ? 1 : (((tmk.w_nz >> cur) & 1) ? 2 : 0));
+    if (wave_on && cls != 0) {
+      const int k0 = cur * 64;
+      // (the two lane words are made opaque per tile: hipcc otherwise hoists every derived address out of the loop and spills them)
+      unsigned rk_ = fl.rk, tr_ = fl.tr;
+      int h_ = h;
+      asm volatile("" : "+v"(rk_), "+v"(tr_), "+v"(h_));
+      const unsigned tk = tKa + rk_, tv = tKa + 8192u + tr_, tq = lds_addr(qimg) + rk_;
+      const bool plain = (cls == 1) && (k0 + 64 <= Lv);
+      const unsigned long long* db0 = DROP ? (const unsigned long long*)a.dropbits + dbits_block(a, (size_t)b * a.A + head, q0 >> 5, cur) : nullptr;
+      const unsigned long long* const mp[2] = {db0, DROP ? db0 + (size_t)a.NKT * 32 : nullptr};       // the next 32-query block of the same key tile
+      fwd2_tile<DROP, F16>(a, tk, tv, tq, o, m2, lsum, myw, q_ok, k0, Lv, cls, plain, c2, neg, h_, mp);
+    }
+    if (iss < nkt) issue();
+    cur = next_tile(tmk.need, cur, nkt);
+    ++done;
+  }
+  // epilogue: whole rows through a per-wave LDS patch (every wave is past its last tile: the K / V stages are free)
+  __builtin_amdgcn_s_barrier();
+  char* patch = smem + wid * ATT_PATCH_BYTES;
+#pragma unroll
+  for (int qi = 0; qi < 2; ++qi) {
+    const float ltot = lsum[qi] + __shfl_xor(lsum[qi], 32, 64);
+    const float inv = (DROP ? a.inv_keep : 1.0f) / ltot;
+    const int rows_ok = Lq - (q0 + 32 * qi);            // (<= 0 for a sub-tile without queries: nothing is stored)
+    store_rows_tile<F16>(patch, o[qi], inv, q_ok[qi], a.out + (rowbase + q0 + 32 * qi) * (size_t)H + head * 64, (size_t)H, rows_ok, lane);
+    if constexpr (F16) {
+      if (a.out2) store_rows_tile<false>(patch, o[qi], inv, q_ok[qi], a.out2 + (rowbase + q0 + 32 * qi) * (size_t)H + head * 64, (size_t)H, rows_ok, lane);
+    }
+    if (q_ok[qi] && h == 0) a.lse[((size_t)b * a.A + head) * L + q[qi]] = (m2[qi] + log2f(ltot)) * LN2;
+  }
+}
+
 // ---- backward: dQ ----------------------------------------------------------------------------
 // One 64-key tile of the dQ pass for a wave's 32 queries.  MASKED: the tile needs its mask words (class 2; a ragged
 // TAIL tile is always run as masked), DROP: attention dropout is on -- compile-time, so the per-element loops are
@@ -794,11 +1049,11 @@ __device__ __forceinline__ void dq_tile(const AttnArgs& a, unsigned tk, unsigned
 #define DQ_NS 4       // 64 KiB of LDS per block, two blocks per CU (register-limited)
 template <bool F16>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_mfma_kernel(AttnArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+  extern __shared__ __attribute__((aligned(128))) char smem[];   // (fragment addressing XORs bits 4-6 of tile base + lane word: bases are multiples of 128)
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   int xb, head, b;
-  att_block(xb, head, b);
+  att_block(a, xb, head, b);
   const int L = a.L, H = a.H, ld = 3 * a.H, T = a.T;
   const int qb0 = xb * 128, q0 = qb0 + wid * 32, q = q0 + l31;
   PROF_DECL;
@@ -920,6 +1175,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_mfma_kernel(AttnArgs a) {
 // ---- backward: dK, dV --------------------------------------------------------------------------
 // LDS stage layout: Q tile 8 KiB | dO tile 8 KiB | lse2[64] f32 | delta[64] f32 | words[64][4] u32
 #define KV_STAGE (8192 + 8192 + 256 + 256 + 1024 + 1024)     // ... | keep-bit dwords [4 waves][2 query halves][32 keys] u32
+static_assert(KV_STAGE % 128 == 0 && ATT_PATCH_BYTES % 128 == 0, "frag_row_x / frag_tr_x XOR bits 4-6 of (tile base + lane word): every tile base must be a multiple of 128 bytes");
 // One 64-query tile of the dK/dV pass for a wave's 32 keys (key on the lane).  MASKED: class-2 tile (mask words from LDS);
 // DROP: attention dropout on -- compile-time, so the element loops are branch-free.
 template <bool MASKED, bool DROP, bool F16>
@@ -1003,11 +1259,11 @@ __device__ __forceinline__ void dkv_tile(const AttnArgs& a, const char* tQ, cons
 #define DKV_NS 4      // 70 KiB of LDS per block, two blocks per CU (register-limited)
 template <bool F16>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_mfma_kernel(AttnArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+  extern __shared__ __attribute__((aligned(128))) char smem[];   // (fragment addressing XORs bits 4-6 of tile base + lane word: bases are multiples of 128)
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   int xb, head, b;
-  att_block(xb, head, b);
+  att_block(a, xb, head, b);
   const int L = a.L, H = a.H, ld = 3 * a.H, T = a.T;
   const int kb0 = xb * 128, k0w = kb0 + wid * 32, key = k0w + l31;
   PROF_DECL;
@@ -1324,9 +1580,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_simple_kernel(SArgs<T> a) {
 static inline size_t dropbits_words(int B, int L, int A) { return (size_t)B * A * ((L + 31) / 32) * ((L + 63) / 64) * 64; }   // uint32 count
 // bits per uniform of mv_attn_dropmask (8, 12 or 16): P(drop) = thr / 2^planes with thr = round(p * 2^planes); survivors are scaled
 // by 2^planes / (2^planes - thr).  p = 0.1: 16 -> 0.100006, 12 -> 0.100098, 8 -> 0.101563.
-int g_mv_attn_planes = 16;
-extern "C" void mv_set_attn_planes(int planes) { g_mv_attn_planes = (planes == 8 || planes == 12) ? planes : 16; }
-extern "C" int mv_get_attn_planes(void) { return g_mv_attn_planes; }
+#define g_mv_attn_planes (mv_knob(MV_KNOB_ATTN_PLANES))
 static inline unsigned attn_thr16(float p) {          // threshold at the current plane count
   const int full = 1 << g_mv_attn_planes;
   int t = (int)(p * (float)full + 0.5f);
@@ -1394,7 +1648,7 @@ extern "C" int mv_attn_fwd(int dtype, const void* qkv, const uint32_t* bits, con
     const size_t bq = nrow * 3 * H * 2;
     if (bq >= 0x7fffffffULL || (((uintptr_t)qkv) & 15) || (((uintptr_t)ctx) & 7) || (((uintptr_t)ctx_bf16) & 7)) return MV_E_SHAPE;
     AttnArgs a{};
-    a.cu = cu; a.qlim = qlim;
+    a.cu = cu; a.qlim = qlim; a.order = mv_knob(MV_KNOB_ATTN_ORDER);
     a.qkv = (const bf16_t*)qkv; a.out = (bf16_t*)ctx; a.out2 = (bf16_t*)ctx_bf16; a.bits = bits; a.info = tileinfo; a.lse = lse;
     a.B = B; a.L = L; a.A = A; a.H = H; a.W = (L + 31) / 32; a.T = (L + 63) / 64;
     a.scale = 1.0f / sqrtf((float)dh);
@@ -1406,7 +1660,23 @@ extern "C" int mv_attn_fwd(int dtype, const void* qkv, const uint32_t* bits, con
     if (!attr) {
       (void)hipFuncSetAttribute((const void*)attn_fwd_mfma_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, FWD_NS * 16384);
       (void)hipFuncSetAttribute((const void*)attn_fwd_mfma_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, FWD_NS * 16384);
+      (void)hipFuncSetAttribute((const void*)attn_fwd2_mfma_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, FWD2_LDS);
+      (void)hipFuncSetAttribute((const void*)attn_fwd2_mfma_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, FWD2_LDS);
+      (void)hipFuncSetAttribute((const void*)attn_fwd2_mfma_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, FWD2_LDS);
+      (void)hipFuncSetAttribute((const void*)attn_fwd2_mfma_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, FWD2_LDS);
       attr = true;
+    }
+    if (mv_knob(MV_KNOB_ATTN_FWD) == 1) {        // two 32-query sub-tiles per wave, 256-query blocks
+      const dim3 g2((L + 255) / 256, A, B);
+      if (dtype == MV_F16) {
+        if (a.drop_on) hipLaunchKernelGGL((attn_fwd2_mfma_kernel<true, true>), g2, dim3(256), FWD2_LDS, stream, a);
+        else hipLaunchKernelGGL((attn_fwd2_mfma_kernel<true, false>), g2, dim3(256), FWD2_LDS, stream, a);
+      } else {
+        if (a.drop_on) hipLaunchKernelGGL((attn_fwd2_mfma_kernel<false, true>), g2, dim3(256), FWD2_LDS, stream, a);
+        else hipLaunchKernelGGL((attn_fwd2_mfma_kernel<false, false>), g2, dim3(256), FWD2_LDS, stream, a);
+      }
+      MV_CHECK_LAUNCH();
+      return MV_OK;
     }
     if (dtype == MV_F16) hipLaunchKernelGGL(attn_fwd_mfma_kernel<true>, dim3((L + 127) / 128, A, B), dim3(256), FWD_NS * 16384, stream, a);
     else hipLaunchKernelGGL(attn_fwd_mfma_kernel<false>, dim3((L + 127) / 128, A, B), dim3(256), FWD_NS * 16384, stream, a);
@@ -1460,7 +1730,7 @@ extern "C" int mv_attn_bwd(int dtype, const void* qkv, const void* ctx, const vo
     const size_t bq = nrow * 3 * H * 2, bc = nrow * H * 2;
     if (bq >= 0x7fffffffULL || (((uintptr_t)qkv) & 15) || (((uintptr_t)dctx) & 15) || (((uintptr_t)dqkv) & 7)) return MV_E_SHAPE;
     AttnArgs a{};
-    a.cu = cu; a.qlim = qlim;
+    a.cu = cu; a.qlim = qlim; a.order = mv_knob(MV_KNOB_ATTN_ORDER);
     a.qkv = (const bf16_t*)qkv; a.ctx = (const bf16_t*)ctx; a.dctx = (const bf16_t*)dctx; a.dqkv = (bf16_t*)dqkv;
     a.bits = bits; a.info = tileinfo; a.lse_in = lse; a.delta = delta; a.delta_out = delta;
     a.B = B; a.L = L; a.A = A; a.H = H; a.W = (L + 31) / 32; a.T = (L + 63) / 64;

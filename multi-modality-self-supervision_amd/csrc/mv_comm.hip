@@ -6,8 +6,20 @@
 // never calls mv_comm_* never loads it.  Host code only.
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
-#include <rccl/rccl.h>
+#include <mutex>
+#include <vector>
 #include "../../include/medvill.h"
+// RCCL's types: from its header where the ROCm install has one, else the handful this file needs, declared here with RCCL's published
+// values (the entry points are bound by name at run time either way: a ROCm without the RCCL development files still builds this library)
+#if __has_include(<rccl/rccl.h>)
+#include <rccl/rccl.h>
+#else
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclSum = 0 } ncclRedOp_t;
+typedef enum { ncclFloat16 = 6, ncclFloat32 = 7, ncclBfloat16 = 9 } ncclDataType_t;
+#endif
 
 namespace {
 
@@ -20,11 +32,8 @@ struct Rccl {
   bool ok = false;
 };
 
-Rccl& rccl() {
-  static Rccl r;
-  static bool tried = false;
-  if (tried) return r;
-  tried = true;
+Rccl load_rccl() {
+  Rccl r;
   for (const char* name : {"librccl.so.1", "librccl.so"}) {
     r.so = dlopen(name, RTLD_NOW | RTLD_LOCAL);
     if (r.so) break;
@@ -37,28 +46,39 @@ Rccl& rccl() {
   r.ok = r.GetUniqueId && r.CommInitRank && r.AllReduce && r.CommDestroy;
   return r;
 }
+// the function table is filled exactly once, by whichever thread gets here first (C++11 function-local static: concurrent first
+// callers block until it is complete; it is immutable afterwards)
+const Rccl& rccl() {
+  static const Rccl r = load_rccl();
+  return r;
+}
 
+// One event per DISTINCT stream a collective was issued on since the last wait: a host that issues buckets from two streams gets its
+// compute stream ordered behind BOTH (round 4 kept one event, re-recorded on whichever stream issued last).
 struct Comm {
   ncclComm_t comm = nullptr;
-  hipEvent_t done = nullptr;      // recorded behind the collective issued last
   int rank = 0, world = 1;
-  bool pending = false;
+  std::mutex mu;
+  struct Pending { hipStream_t stream; hipEvent_t done; bool live; };
+  std::vector<Pending> pending;      // entries are reused (events are created once per distinct stream)
 };
 
-inline int rc_of(ncclResult_t e) { return e == ncclSuccess ? MV_OK : MV_E_COMM_BASE + (int)e; }
+// RCCL failures: MV_E_COMM_BASE - ncclResult_t, i.e. -1001, -1002, ... -- negative like every MV_E_* code, and outside hipError_t's range
+// (hipErrorRuntimeMemory = 1052 etc. are POSITIVE values above 1000, which the round-4 encoding 1000 + e collided with)
+inline int rc_of(ncclResult_t e) { return e == ncclSuccess ? MV_OK : MV_E_COMM_BASE - (int)e; }
 
 }  // namespace
 
 extern "C" int mv_comm_unique_id(void* id128) {
   if (!id128) return MV_E_ARG;
-  Rccl& r = rccl();
+  const Rccl& r = rccl();
   if (!r.ok) return MV_E_NO_RCCL;
   return rc_of(r.GetUniqueId((ncclUniqueId*)id128));
 }
 
 extern "C" int mv_comm_init(void** comm_out, int rank, int world, const void* id128) {
   if (!comm_out || !id128 || world <= 0 || rank < 0 || rank >= world) return MV_E_ARG;
-  Rccl& r = rccl();
+  const Rccl& r = rccl();
   if (!r.ok) return MV_E_NO_RCCL;
   Comm* c = new Comm();
   c->rank = rank; c->world = world;
@@ -66,8 +86,6 @@ extern "C" int mv_comm_init(void** comm_out, int rank, int world, const void* id
   __builtin_memcpy(&id, id128, sizeof(id));
   const ncclResult_t e = r.CommInitRank(&c->comm, world, id, rank);           // on the calling thread's current device
   if (e != ncclSuccess) { delete c; return rc_of(e); }
-  const hipError_t he = hipEventCreateWithFlags(&c->done, hipEventDisableTiming);
-  if (he != hipSuccess) { r.CommDestroy(c->comm); delete c; return (int)he; }
   *comm_out = c;
   return MV_OK;
 }
@@ -81,27 +99,43 @@ extern "C" int mv_comm_allreduce_async(void* comm, void* buf, size_t count, int 
   else if (dtype == MV_BF16) dt = ncclBfloat16;
   else return MV_E_DTYPE;
   hipStream_t stream = (hipStream_t)stream_;
+  std::lock_guard<std::mutex> lock(c->mu);        // RCCL wants the collectives of one communicator issued in one order on every rank
   const ncclResult_t e = rccl().AllReduce(buf, buf, count, dt, ncclSum, c->comm, stream);      // in place; RCCL's kernels run on `stream`
   if (e != ncclSuccess) return rc_of(e);
-  const hipError_t he = hipEventRecord(c->done, stream);
+  Comm::Pending* slot = nullptr;
+  for (auto& p : c->pending)
+    if (p.stream == stream) { slot = &p; break; }
+  if (!slot) {
+    hipEvent_t ev = nullptr;
+    const hipError_t hc = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    if (hc != hipSuccess) return (int)hc;
+    c->pending.push_back({stream, ev, false});
+    slot = &c->pending.back();
+  }
+  const hipError_t he = hipEventRecord(slot->done, stream);      // behind the collective issued last ON THIS STREAM
   if (he != hipSuccess) return (int)he;
-  c->pending = true;
+  slot->live = true;
   return MV_OK;
 }
 
 extern "C" int mv_comm_wait(void* comm, void* stream_) {
   if (!comm) return MV_E_ARG;
   Comm* c = (Comm*)comm;
-  if (!c->pending) return MV_OK;
-  const hipError_t he = hipStreamWaitEvent((hipStream_t)stream_, c->done, 0);      // device-side: the host does not block
-  return he == hipSuccess ? MV_OK : (int)he;
+  std::lock_guard<std::mutex> lock(c->mu);
+  for (auto& p : c->pending) {        // every stream that issued a collective since the last wait
+    if (!p.live) continue;
+    const hipError_t he = hipStreamWaitEvent((hipStream_t)stream_, p.done, 0);      // device-side: the host does not block
+    if (he != hipSuccess) return (int)he;
+    p.live = false;
+  }
+  return MV_OK;
 }
 
 extern "C" int mv_comm_destroy(void* comm) {
   if (!comm) return MV_E_ARG;
   Comm* c = (Comm*)comm;
   int rc = MV_OK;
-  if (c->done) (void)hipEventDestroy(c->done);
+  for (auto& p : c->pending) (void)hipEventDestroy(p.done);
   if (c->comm) rc = rc_of(rccl().CommDestroy(c->comm));
   delete c;
   return rc;

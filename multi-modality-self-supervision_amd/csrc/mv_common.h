@@ -22,7 +22,23 @@ typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
 
 #define MV_LDS __attribute__((address_space(3)))
 
-extern int g_mv_impl;
+// Kernel-selection knobs (test / experiment hooks).  The PRODUCT library has no mutable state: mv_knob() returns compile-time
+// defaults there and nothing can change them.  Only the debug build of mv_api.hip (-DMV_DEBUG_KNOBS -> libmedvill_hip_dbg.so,
+// include/medvill_debug.h) holds a table that mv_debug_set_knob() writes; every other translation unit is shared by both libraries.
+enum {
+  MV_KNOB_IMPL = 0,            // 0 auto (MFMA for 16-bit, VALU for f32) | 1 plain VALU kernels for every dtype
+  MV_KNOB_GEMM_FORCE = 1,      // 0 auto | 1 the 128x128x64 kernel | 2 the 256-row LDS-DMA kernel
+  MV_KNOB_GEMM_NJ = 2,         // 0 auto | kernel variant (mv_gemm.hip)
+  MV_KNOB_GEMM_DBG = 3,        // timing-experiment bits of the ring kernels (results wrong by construction)
+  MV_KNOB_ATTN_PLANES = 4,     // bits per uniform of the attention-dropout generator: 16 | 12 | 8
+  MV_KNOB_PERSISTENT_CUS = 5,  // persistent GEMM kernels launch at most n blocks (0 = one per CU)
+  MV_KNOB_ROWOPS_VARIANT = 6,  // mv_layernorm_bwd kernel form
+  MV_KNOB_ATTN_ORDER = 7,      // attention block -> (row block, head, sample) order: 0 row block slowest (default) | 1 a pair's row blocks adjacent on one XCD
+  MV_KNOB_ATTN_FWD = 8,        // attention forward kernel: 0 one 32-query sub-tile per wave (128-query blocks) | 1 two sub-tiles per wave (256-query blocks)
+  MV_KNOB_COUNT = 9
+};
+__attribute__((visibility("hidden"))) int mv_knob(int id);
+#define g_mv_impl (mv_knob(MV_KNOB_IMPL))
 
 #define MV_CHECK_LAUNCH()                           \
   do {                                              \

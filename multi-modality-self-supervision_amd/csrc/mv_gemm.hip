@@ -326,13 +326,73 @@ __global__ void splitk_reduce_kernel(GemmArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------
-int g_mv_gemm_force = 0;   // test hook: 0 auto, 1 force the 128x128 kernel, 2 force the 256-row kernel
-int g_mv_gemm_nj = 0;      // test hook: 0 auto, 3 / 4 force the 192- / 256-column variant
-int g_mv_gemm_dbg = 0;
-extern int g_mv_persistent_cus;   // mv_api.hip
-extern "C" void mv_set_gemm_variant(int force, int nj) { g_mv_gemm_force = force & 0xff; g_mv_gemm_nj = nj; g_mv_gemm_dbg = force >> 8; }
+// test / experiment hooks (constants in the product library: mv_common.h)
+#define g_mv_gemm_force (mv_knob(MV_KNOB_GEMM_FORCE))        // 0 auto, 1 force the 128x128 kernel, 2 force the 256-row kernel
+#define g_mv_gemm_nj (mv_knob(MV_KNOB_GEMM_NJ))              // 0 auto, kernel variant
+#define g_mv_gemm_dbg (mv_knob(MV_KNOB_GEMM_DBG))
+#define g_mv_persistent_cus (mv_knob(MV_KNOB_PERSISTENT_CUS))
 
 static inline bool aligned_to(const void* p, size_t a) { return p == nullptr || (((uintptr_t)p) % a) == 0; }
+
+// Which kernel serves a 16-bit MFMA product and how many split-K slabs it would like when the caller leaves the choice to the library
+// (splitk = 0) -- ONE definition, used by mv_gemm itself and by mv_gemm_workspace_bytes / mv_workspace_bytes, so that a host that is not
+// hip_ops.py can size the workspace without re-deriving this from the source.
+struct GemmRoute {
+  bool big;            // the 256-row ring kernels (else the 128x128 kernel)
+  int variant;         // ring variant: 14 = 256x256x64 two stages, 24 = its persistent form, 2 = 256x128
+  long long tiles;     // output tiles of the chosen kernel
+  long long sk_auto;   // split-K slabs wanted at splitk = 0 with an unlimited workspace (1 = none)
+};
+static GemmRoute gemm_route(int ta, int tb, int M, int N, int K, int splitk) {
+  GemmRoute r;
+  const int tm2 = (M + 255) / 256;
+  const long long t256 = (long long)tm2 * ((N + 255) / 256), t128 = (long long)tm2 * ((N + 127) / 128);
+  // measured on the model's shapes (profiles/r01_gemm_variants.txt): the ring kernels win for y = x.W^T with wide outputs and for
+  // dW = dy^T.x, the 128x128 register-staged kernel for dx = dy.W and for 768-column outputs (three blocks per CU), also for long contractions
+  const bool wide_nt = !ta && !tb && N >= 1024;
+  r.big = (g_mv_gemm_force == 2) || (g_mv_gemm_force == 0 && M >= 256 && N >= 128 && ((K & 7) == 0 || (ta && tb)) && (wide_nt || ta) &&
+                                     (t128 >= 128 || (K >= 4096 && splitk != 1)));
+  r.variant = 0;
+  r.sk_auto = 1;
+  if (r.big) {
+    // 256x256 with 64-deep stages (whole 128-B lines per LDS-DMA row): best measured.  Weight gradients (split-K units, f32 partial
+    // tiles) gain 5-8 % from the persistent form; y = x.W^T does not (profiles/r01_gemm_variants.txt)
+    r.variant = g_mv_gemm_nj ? g_mv_gemm_nj : (ta ? 24 : 14);        // (knob: 14, 24 or 2 = 256x128 tiles, 4 waves, two blocks per CU)
+    const bool v128 = r.variant == 2;
+    r.tiles = v128 ? t128 : t256;
+    const long long slots = v128 ? 512 : 256;
+    // enough slabs to give every CU a unit, each at least 1024 deep; at most 32
+    if (r.tiles < slots && K >= 2048) { long long sk = slots / r.tiles; if (sk > K / 1024) sk = K / 1024; if (sk > 32) sk = 32; if (sk < 1) sk = 1; r.sk_auto = sk; }
+  } else {
+    r.tiles = (long long)((M + GT_BM - 1) / GT_BM) * ((N + GT_BN - 1) / GT_BN);
+    if (r.tiles < 512 && K >= 2048) { long long sk = 768 / r.tiles; if (sk > K / 1024) sk = K / 1024; if (sk > 16) sk = 16; if (sk < 1) sk = 1; r.sk_auto = sk; }
+  }
+  return r;
+}
+
+extern "C" size_t mv_gemm_workspace_bytes(int dtype, int ta, int tb, int M, int N, int K) {
+  if (M <= 0 || N <= 0 || K <= 0 || !mv_is16(dtype) || g_mv_impl != 0) return 0;      // split-K is chosen on the MFMA kernels only
+  const GemmRoute r = gemm_route(ta, tb, M, N, K, 0);
+  return r.sk_auto > 1 ? (size_t)r.sk_auto * (size_t)M * (size_t)N * sizeof(float) : 0;
+}
+
+extern "C" size_t mv_workspace_bytes(int hidden, int intermediate, int vocab, int img_hidden, int max_rows, int max_label_rows, int max_regions) {
+  if (hidden <= 0 || intermediate <= 0 || vocab <= 0 || max_rows <= 0) return 0;
+  const int H = hidden, I = intermediate, R = max_label_rows > 0 ? max_label_rows : 1;
+  size_t w = 0;
+  auto upd = [&](size_t b) { if (b > w) w = b; };
+  // the weight gradients dW[No, Ko] = dy^T . x over the rows (Engine._dW): FFN-up / FFN-down / fused QKV / attention output projection ...
+  upd(mv_gemm_workspace_bytes(MV_F16, 1, 1, I, H, max_rows));
+  upd(mv_gemm_workspace_bytes(MV_F16, 1, 1, H, I, max_rows));
+  upd(mv_gemm_workspace_bytes(MV_F16, 1, 1, 3 * H, H, max_rows));
+  upd(mv_gemm_workspace_bytes(MV_F16, 1, 1, H, H, max_rows));
+  // ... the MLM transform's and the image projection's
+  upd(mv_gemm_workspace_bytes(MV_F16, 1, 1, H, H, R));
+  if (img_hidden > 0 && max_regions > 0) upd(mv_gemm_workspace_bytes(MV_F16, 1, 1, H, img_hidden, max_regions));
+  // the tied decoder's input gradient dt[R, H] = dlogits . E contracts over the vocabulary
+  upd(mv_gemm_workspace_bytes(MV_F16, 0, 1, R, H, vocab));
+  return w;
+}
 
 extern "C" int mv_gemm(int dtype, int ta, int tb, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
                        void* C, int ldc, int c_dtype, const float* bias, int epi, const void* R, int ldr, int r_dtype,
@@ -393,38 +453,21 @@ extern "C" int mv_gemm(int dtype, int ta, int tb, int M, int N, int K, const voi
     const size_t bytesB = ((size_t)((tb ? K : N) - 1) * ldb + (size_t)(((tb ? N : K) + 7) & ~7)) * 2;
     if (bytesA >= 0x7fffffffULL || bytesB >= 0x7fffffffULL) return MV_E_SHAPE;
     p.bytesA = (unsigned)bytesA; p.bytesB = (unsigned)bytesB;
-    // tile choice: a 256-row ring kernel when it fills the chip, in the column width (256 / 192 / 128) that needs
-    // the least MFMA time over whole rounds of CUs; the 128x128 kernel for small problems
-    const int tm2 = (M + 255) / 256;
-    const long long t256 = (long long)tm2 * ((N + 255) / 256), t192 = (long long)tm2 * ((N + 191) / 192),
-                    t128 = (long long)tm2 * ((N + 127) / 128);
-    // measured on the model's shapes (profiles/r01_gemm_variants.txt): the ring kernels win for y = x.W^T and
-    // dW = dy^T.x, the 128x128 register-staged kernel for dx = dy.W
-    // (ring kernel with 64-deep stages for wide outputs and for dW; 128x128 register-staged for N <= 1024 and dX)
-    // (768-column outputs: the 128x128 kernel at three blocks per CU wins in every layout, also for long contractions)
-    const bool wide_nt = !ta && !tb && N >= 1024;
-    const bool big = (g_mv_gemm_force == 2) || (g_mv_gemm_force == 0 && M >= 256 && N >= 128 && ((K & 7) == 0 || (ta && tb)) && (wide_nt || ta) &&
-                                               (t128 >= 128 || (K >= 4096 && splitk != 1)));
+    // tile choice (gemm_route): a 256-row ring kernel when it fills the chip, the 128x128 kernel for small problems, dx and 768-column outputs
+    const GemmRoute route = gemm_route(ta, tb, M, N, K, splitk);
+    const bool big = route.big;
     if (big) {
-      int variant = g_mv_gemm_nj;           // test / experiment hook: 14, 24 (below) or 2 = 256x128 tiles, 4 waves, two blocks per CU
-      if (variant == 0) {
-        // 256x256 with 64-deep stages (whole 128-B lines per LDS-DMA row): best measured.  Weight gradients (split-K
-        // units, f32 partial tiles) gain 5-8 % from the persistent form; y = x.W^T does not (profiles/r01_gemm_variants.txt)
-        variant = ta ? 24 : 14;
-      }
+      const int variant = route.variant;
       const bool v128 = variant == 2;
-      const long long tiles_v = v128 ? t128 : t256, slots = v128 ? 512 : 256;
+      const long long tiles_v = route.tiles;
       long long sk = splitk;
       if (splitk > 1 || splitk == 0) {      // 0 = auto
-        const long long tiles = tiles_v;
-        sk = 1;
-        // enough slabs to give every CU a unit, each at least 1024 deep; at most 32 and as many as the workspace holds
-        if (tiles < slots && K >= 2048) { sk = slots / tiles; if (sk > K / 1024) sk = K / 1024; if (sk > 32) sk = 32; if (sk < 1) sk = 1; }
+        sk = route.sk_auto;
         if (splitk > 1 && sk > splitk) sk = splitk;
         if (sk > 1 && ws) { const long long fit = (long long)(ws_bytes / ((size_t)M * N * sizeof(float))); if (sk > fit) sk = fit < 1 ? 1 : fit; }
         if (sk > 1 && (!ws || epi != MV_EPI_NONE || c_dtype != MV_F32)) sk = 1;
       }
-      (void)t192;
+      (void)v128;
       int kchunk = (int)((K + sk - 1) / sk);
       kchunk = (kchunk + 63) / 64 * 64;
       p.kchunk = kchunk;
@@ -450,10 +493,9 @@ extern "C" int mv_gemm(int dtype, int ta, int tb, int M, int N, int K, const voi
     } else {
       if (colsum_part) return MV_E_SHAPE;        // the 256x256 ring kernel only
       if (splitk == 0) {
-        const int tiles = ((M + GT_BM - 1) / GT_BM) * ((N + GT_BN - 1) / GT_BN);
         splitk = 1;
-        if (tiles < 512 && K >= 2048 && ws && epi == MV_EPI_NONE && c_dtype == MV_F32) {
-          splitk = 768 / tiles; if (splitk > K / 1024) splitk = K / 1024; if (splitk > 16) splitk = 16; if (splitk < 1) splitk = 1;
+        if (route.sk_auto > 1 && ws && epi == MV_EPI_NONE && c_dtype == MV_F32) {
+          splitk = (int)route.sk_auto;
           if (ws_bytes < (size_t)splitk * M * N * sizeof(float)) splitk = 1;
         }
       }

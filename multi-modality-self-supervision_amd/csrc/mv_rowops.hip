@@ -254,8 +254,7 @@ __global__ __launch_bounds__(64 * WPB) void ln_bwd_pf_kernel(const TD* __restric
   }
 }
 
-int g_mv_ln_bwd_variant = 0;     // test / experiment hook, see mv_layernorm_bwd; grid cap in bits 8..
-extern "C" void mv_set_rowops_variant(int v) { g_mv_ln_bwd_variant = v; }
+#define g_mv_ln_bwd_variant (mv_knob(MV_KNOB_ROWOPS_VARIANT))     // test / experiment hook, see mv_layernorm_bwd; grid cap in bits 8..
 
 extern "C" int mv_layernorm_fwd(int dtype, const void* x, int x_dtype, const float* gamma, const float* beta, void* y, void* y_bf16,
                                 float* mean, float* rstd, int M, int H, float eps, void* stream_) {

@@ -172,13 +172,15 @@ class _HeadFn(torch.autograd.Function):
         if not hasattr(eng, "S"):
             eng.S = {}
         logits = eng._mlm_forward(xf, xb, R, "hm_", pad=False)
-        ctx.hs = eng.S["hm_"]
+        # The engine's scratch buffers are cached by name: a second model.mlm(...) before this call's backward would overwrite what this
+        # call saved.  The reference's nn.Module heads are re-entrant (two calls in one graph, gradient accumulation over two forwards),
+        # so every call keeps its OWN copies of the saved activations ([R, H] each: small beside the [R, V] logits it returns).
+        ctx.hs = {k: (v.clone() if (torch.is_tensor(v) and k != "logits") else v) for k, v in eng.S["hm_"].items() if k != "logits"}
         return logits.view(*x.shape[:-1], V)
 
     @staticmethod
     def backward(ctx, g):
         from . import hip_ops as ops
-        from .dist import bucket_ranges
         model, kind, R = ctx.model, ctx.kind, ctx.R
         eng = model.engine
         H, V = eng.cfg.hidden, eng.cfg.vocab_size
@@ -209,12 +211,12 @@ class _HeadFn(torch.autograd.Function):
             return None, None, dx.view(*g.shape[:-1], H).to(ctx.in_dtype), gW, gb
 
         Vp = (V + 7) // 8 * 8
-        s_, e_ = bucket_ranges(eng.layout, eng.n_flat, eng.cfg.layers)["heads"]
 
         def run():
             eng.S["hm_"] = ctx.hs
             ctx.hs["Vp"] = Vp
-            eng.flat_g[s_:e_].zero_()
+            for n in _MLM_PARAMS[:-1]:        # this head's own gradients only (the tied matrix's is overwritten, not accumulated);
+                eng.g[n].zero_()              # the pooler's / ITM head's gradients in the same bucket are somebody else's
             dl = torch.empty((R, Vp), dtype=adt, device=dev)
             ops.cast2d(scaled(g32.view(R, V)), V, dl, Vp, R, V)
             dxr = eng._mlm_backward(dl, "hm_")

@@ -420,7 +420,10 @@ class Engine:
         # split-K is chosen by the library (splitk=0) from the tile grid and the workspace: up to 32 partial slabs for the small
         # [H, H] gradients (9 tiles of 256x256 need ~24 slabs to occupy the chip), 16 for the large ones
         auto = self.is16 and Mtok >= 2048 and No * Ko <= 4 * 1024 * 1024
-        ws = self._gemm_workspace((32 if No * Ko <= 1024 * 1024 else 16) * No * Ko) if auto else None
+        # the library says how much workspace its own split-K choice for this product wants (mv_gemm_workspace_bytes)
+        wb = ops.gemm_workspace_bytes(self.adt, True, True, No, Ko, Mtok) if auto else 0
+        auto = auto and wb > 0
+        ws = self._gemm_workspace(wb // 4) if auto else None
         # f16 gradients are loss-scaled: the weight gradient is un-scaled where it is written (alpha = 1 / S from the device)
         ops.gemm(dy, x, gW, ta=True, tb=True, M=No, N=Ko, K=Mtok, lda=lda, ldb=ldb, ldc=ldc, splitk=self.dw_splitk if auto else 1, ws=ws,
                  alpha=self.unscale_dev)
@@ -715,13 +718,14 @@ class Engine:
         if side is not main:
             dlogits.record_stream(side)     # a per-step allocation of the caller: not to be reused before the side stream has read it
         dt_ = self._buf(tag + "dt", (R, H), self.adt)
-        if self.is16 and self.head_splitk and R * H <= 4 * 1024 * 1024:
+        wb = ops.gemm_workspace_bytes(self.adt, False, True, R, H, V) if (self.is16 and self.head_splitk and R * H <= 4 * 1024 * 1024) else 0
+        if wb > 0:
             # dt = dlogits . E contracts over the vocabulary (K = 30,522) into a [R, 768] result: 156 tiles of 128x128 for the
             # ~3,300 labelled rows -- a fifth of the chip's tile slots, 477 K-steps each.  Split-K (partial sums in f32, one
             # reduction, one cast) spreads it over the whole chip.
             dt32 = self._buf(tag + "dt32", (R, H), torch.float32)
             ops.gemm(dlogits, self.w["enc.txt_embeddings.word_embeddings.weight"], dt32, tb=True, M=R, N=H, K=V, lda=Vp, ldb=H,
-                     splitk=0, ws=self._gemm_workspace(8 * R * H))
+                     splitk=0, ws=self._gemm_workspace(wb // 4))
             ops.cast(dt32, dt_, R * H)
         else:
             ops.gemm(dlogits, self.w["enc.txt_embeddings.word_embeddings.weight"], dt_, tb=True, M=R, N=H, K=V, lda=Vp, ldb=H)

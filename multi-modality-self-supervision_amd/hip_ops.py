@@ -380,28 +380,40 @@ def dropout_mask(p_drop, drop_key, n, device):
     return keep, float(sc.value)
 
 
+# ---- kernel-forcing knobs: tests and timing experiments only (include/medvill_debug.h).  The product library has none of this state;
+# a knob off its default routes the process's calls through libmedvill_hip_dbg.so (medvill_amd._lib.set_knob). ----
 def set_impl(impl: int):
-    _lib().mv_set_impl(int(impl))
+    L.set_knob("impl", 1 if impl else 0)
 
 
 def get_impl() -> int:
-    return int(_lib().mv_get_impl())
+    return L.get_knob("impl")
 
 
 def set_attn_planes(planes: int):
-    """Bits per uniform of the attention-dropout mask generator (16, 12 or 8); see mv_set_attn_planes."""
-    _lib().mv_set_attn_planes(int(planes))
+    """Bits per uniform of the attention-dropout mask generator (16, 12 or 8)."""
+    L.set_knob("attn_planes", planes if planes in (8, 12) else 16)
 
 
 def attn_drop_prob(p_drop: float) -> float:
     """The drop probability attn_dropmask realises for p_drop at the current plane count."""
-    n = int(_lib().mv_get_attn_planes())
+    n = L.get_knob("attn_planes")
     return round(p_drop * (1 << n)) / float(1 << n)
 
 
 def set_rowops_variant(v: int = 0):
-    """Experiment hook of mv_layernorm_bwd (see include/medvill.h)."""
-    _lib().mv_set_rowops_variant(int(v))
+    """Experiment hook of mv_layernorm_bwd (see include/medvill_debug.h)."""
+    L.set_knob("rowops_variant", v)
+
+
+def set_attn_fwd(variant: int = 0):
+    """Attention forward kernel: 0 one 32-query sub-tile per wave, 1 two sub-tiles per wave (csrc/mv_attn.hip)."""
+    L.set_knob("attn_fwd", variant)
+
+
+def set_attn_order(order: int = 0):
+    """Attention block order (see att_block in csrc/mv_attn.hip): 0 row block slowest, 1 a pair's row blocks adjacent on one XCD."""
+    L.set_knob("attn_order", order)
 
 
 class RcclComm:
@@ -446,7 +458,7 @@ class RcclComm:
 
 def set_persistent_cus(n: int = 0):
     """The persistent (weight-gradient) GEMM kernels launch at most n blocks; 0 = one per CU."""
-    _lib().mv_set_persistent_cus(int(n))
+    L.set_knob("persistent_cus", max(int(n), 0))
 
 
 def stream_with_cus(n_cus: int, device, first: int = 0, total: int = 256, n_xcd: int = 8):
@@ -464,5 +476,18 @@ def stream_with_cus(n_cus: int, device, first: int = 0, total: int = 256, n_xcd:
     return torch.cuda.ExternalStream(out.value, device=device)
 
 
+def gemm_workspace_bytes(dtype, ta, tb, M, N, K) -> int:
+    """Bytes of split-K workspace mv_gemm(splitk=0) would like for this product (0: it never splits); see include/medvill.h."""
+    dt = dtype if isinstance(dtype, int) else {torch.float32: MV_F32, torch.bfloat16: MV_BF16, torch.float16: MV_F16}[dtype]
+    return int(_lib().mv_gemm_workspace_bytes(dt, int(ta), int(tb), int(M), int(N), int(K)))
+
+
+def workspace_bytes(hidden, intermediate, vocab, img_hidden, max_rows, max_label_rows, max_regions) -> int:
+    """The largest split-K workspace any GEMM of a pretraining step asks for at this geometry (mv_workspace_bytes)."""
+    return int(_lib().mv_workspace_bytes(int(hidden), int(intermediate), int(vocab), int(img_hidden), int(max_rows), int(max_label_rows), int(max_regions)))
+
+
 def set_gemm_variant(force: int = 0, nj: int = 0):
-    _lib().mv_set_gemm_variant(int(force), int(nj))
+    L.set_knob("gemm_force", int(force) & 0xff)
+    L.set_knob("gemm_nj", int(nj))
+    L.set_knob("gemm_dbg", int(force) >> 8)

@@ -37,9 +37,13 @@ class CXRBertForRetrieval(nn.Module):
         eng = self.bert.engine
         if isinstance(attn_mask, MaskDesc) and eng.is16 and attn_mask.packable():
             feats, pos = self.bert._regions(input_img)
+            prev = (eng.training, eng.keep_acts)
             eng.training, eng.keep_acts = False, False
-            eng.encoder_forward(cls_tok, input_txt, attn_mask, segment, feats, pos, sep_tok, pack=True)
-            logits = eng._itm_forward().clone()
+            try:
+                eng.encoder_forward(cls_tok, input_txt, attn_mask, segment, feats, pos, sep_tok, pack=True)
+                logits = eng._itm_forward().clone()
+            finally:                # sticky engine state: a later direct Engine user must find what it left
+                eng.training, eng.keep_acts = prev
         else:
             logits = self.forward(cls_tok, input_txt, attn_mask, segment, input_img, sep_tok)
         return torch.softmax(logits.float(), dim=-1)[:, 1]

@@ -152,9 +152,13 @@ class CXRBERT_Trainer:
             self.model = CXRBERT.from_pretrained(args.pre_trained_model_path, args=args, dtype=dtype, device=self.device, img_encoder=cnn)
             print("training restart with mid epoch")
         else:
+            init_sd = None
             if config is None:
-                config = BERT_CONFIGS.get(getattr(args, "bert_model", "bert-base-scratch"), BERT_CONFIGS["bert-base-scratch"])
+                name = getattr(args, "bert_model", "bert-base-scratch")
+                config, init_sd = resolve_bert_model(args, name)
             self.model = CXRBERT(config, args, dtype=dtype, device=self.device, img_encoder=cnn)
+            if init_sd is not None:
+                load_pretrained_bert(self.model, init_sd)
             tv = getattr(args, "resnet50_weights", None)       # path to torchvision's resnet50 state dict (no network here)
             if want_cnn and tv:
                 self.model.img_encoder.load_torchvision_state_dict(torch.load(tv, map_location="cpu"))
@@ -467,6 +471,73 @@ class CXRBERT_Trainer:
             os.chmod(save_path_per_ep + "/pytorch_model.bin", 0o777)
         if self.distributed:
             torch.distributed.barrier()
+
+
+SCRATCH_MODELS = ("bert-base-scratch", "bert-small-scratch")      # the two --bert_model values that mean "random init" (cxrbert_origin.py:49-54)
+
+
+def resolve_bert_model(args, name):
+    """train_origin.py:36-49 + cxrbert_origin.py:41-55.  -> (config dict, HF-BERT state dict or None).
+    `bert-*-scratch` build a randomly initialised BertModel in the reference, and so here.  EVERY other name makes the reference load
+    PRETRAINED text-encoder weights (`BertModel/AutoModel.from_pretrained(args.bert_model)`, a download); there is no network here, so
+    the weights must be handed over -- `args.init_state_dict` (a HF BertModel / BertForPreTraining state dict) or `args.init_checkpoint`
+    (a `pytorch_model.bin` or a directory holding one; `args.bert_model` itself may be such a directory, with its config.json).
+    Without them this RAISES: a run the reference would start from pretrained weights must not silently start from noise.
+    `args.allow_random_init = True` is the explicit opt-out (geometry only)."""
+    import json
+    if name == "albert-base-v2":
+        raise NotImplementedError("--bert_model albert-base-v2: ALBERT (cross-layer parameter sharing, factorised embeddings) is not mirrored")
+    if name == "load_pretrained_model":
+        raise ValueError("--bert_model load_pretrained_model goes with --weight_load and --pre_trained_model_path (train_origin.py:28-34)")
+    config = BERT_CONFIGS.get(name)
+    if name in SCRATCH_MODELS:
+        return config, None
+    sd = getattr(args, "init_state_dict", None)
+    path = getattr(args, "init_checkpoint", None) or (name if os.path.isdir(str(name)) else None)
+    if sd is None and path is not None:
+        f = os.path.join(path, "pytorch_model.bin") if os.path.isdir(path) else path
+        sd = torch.load(f, map_location="cpu")
+        cj = os.path.join(os.path.dirname(f), "config.json")
+        if config is None and os.path.exists(cj):
+            with open(cj) as fh:
+                config = json.load(fh)
+    if config is None:
+        raise ValueError(f"--bert_model {name!r}: unknown geometry (no offline config for it and no config.json beside the checkpoint)")
+    if sd is None:
+        if getattr(args, "allow_random_init", False):
+            import warnings
+            warnings.warn(f"--bert_model {name!r}: args.allow_random_init is set -- training starts from RANDOM weights where the reference "
+                          "would load the pretrained text encoder", RuntimeWarning, stacklevel=3)
+            return config, None
+        raise RuntimeError(
+            f"--bert_model {name!r} means PRETRAINED text-encoder weights in the reference (cxrbert_origin.py:43-48,55: "
+            "BertModel/AutoModel.from_pretrained) and they cannot be downloaded here. Pass args.init_state_dict (a HF BertModel state "
+            "dict) or args.init_checkpoint (a pytorch_model.bin / a directory with one), use --bert_model bert-base-scratch for a "
+            "from-scratch run, or set args.allow_random_init = True to take the geometry only.")
+    return config, sd
+
+
+def load_pretrained_bert(model, hf_state_dict):
+    """Copies a HF BERT checkpoint into the text embeddings / encoder / pooler (the modules cxrbert_origin.py:56-57,72-73 takes from it).
+    The tied MLM decoder and the image embeddings' shared position / type / LayerNorm tensors follow (same storage); the heads' own
+    parameters and the image projection keep their initialisation, as in the reference.  Strict on the encoder side."""
+    from .checkpoint import from_hf_bert_keys
+    mapped = from_hf_bert_keys(hf_state_dict)
+    want = [n for n in model._param_names if n.startswith(("enc.txt_embeddings.", "enc.encoder.", "enc.pooler."))]
+    missing = [n for n in want if n not in mapped]
+    if missing:
+        raise RuntimeError(f"pretrained BERT checkpoint lacks {len(missing)} encoder tensors, e.g. {missing[:3]}")
+    eng = model.engine
+    bad = [n for n in want if tuple(mapped[n].shape) != tuple(eng.p[n].shape)]
+    if bad:
+        raise RuntimeError(f"pretrained BERT checkpoint does not match the model geometry, e.g. {bad[0]}: "
+                           f"{tuple(mapped[bad[0]].shape)} vs {tuple(eng.p[bad[0]].shape)}")
+    eng.wait_optimizer()
+    with torch.no_grad():
+        for n in want:
+            eng.p[n].copy_(mapped[n].to(eng.device, torch.float32))
+    eng.shadow_dirty = True
+    return len(want)
 
 
 BERT_CONFIGS = {   # offline stand-ins for BertConfig.from_pretrained(...) at train_origin.py:36-47

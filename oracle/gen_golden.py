@@ -20,11 +20,14 @@ Fixtures:
   c1v1k_nopos.npz  the same with args.img_postion = False (no position embedding on the image rows), full logits + gradients
   base_s2s.npz   BERT-base L=512 B=1: losses, ITM logits, logit summaries
   base_full.npz  BERT-base L=512 B=2 ragged, bidirectional (BASELINE config 2's family) + gradients of every parameter
+  base_full_b4.npz   the same at B=4 (the benchmarked path's form: the samples pack), + the LABELLED rows' logits (1,009 sampled columns of
+                 each, the logit at the label; logsumexp / arg-max / maximum over all columns for every position)
   base_noncross.npz  BERT-base L=512 B=1, non-cross modality mask (config 4; n2 = 38 is not tile-aligned)
   base768_s2s.npz    BERT-base L=768 (100 regions + 665 text, max_position_embeddings 768) B=1, seq2seq (config 5)
 
     python oracle/gen_golden.py --only base_full,base_noncross     # regenerate a subset
   adamw.npz      3-step HF-AdamW known-answer test computed with python floats
+  state_manifest.json  key -> [shape, dtype] of the reference CXRBERT.state_dict() at BERT-base (`--only manifest`)
 """
 from __future__ import annotations
 
@@ -109,7 +112,7 @@ def install_shims():
     return cx, OfflineBertConfig
 
 
-def build_reference_model(cx, CfgCls, cfg: O.OracleConfig, N: int, params):
+def build_reference_model(cx, CfgCls, cfg: O.OracleConfig, N: int, params, manifest=None):
     CfgCls._local = dict(vocab_size=cfg.vocab_size, hidden_size=cfg.hidden, num_hidden_layers=cfg.layers,
                          num_attention_heads=cfg.heads, intermediate_size=cfg.intermediate,
                          max_position_embeddings=cfg.max_pos, hidden_dropout_prob=0.1,
@@ -120,6 +123,8 @@ def build_reference_model(cx, CfgCls, cfg: O.OracleConfig, N: int, params):
                                  img_postion=cfg.img_position, img_encoder="random-pixel", img_size=512,
                                  num_image_embeds=N, disturbing_mask=False, vocab_size=cfg.vocab_size)
     model = cx.CXRBERT(config, args)
+    if manifest is not None:      # the reference's own state_dict(), before anything here touches the module tree
+        manifest.update({k: [list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in model.state_dict().items()})
     inner = model.enc.encoder
 
     class LegacyTuple(torch.nn.Module):
@@ -182,7 +187,7 @@ def grad_summary(grads: dict, shapes, seed=99):
                 grad_idx=np.stack(idx), grad_vals=np.stack(vals))
 
 
-def run_case(cx, CfgCls, cfg, B, N, S, family, seed, with_grads, full_logits=False, store_hidden=True, ncols=64):
+def run_case(cx, CfgCls, cfg, B, N, S, family, seed, with_grads, full_logits=False, store_hidden=True, ncols=64, lab_ncols=0):
     params = O.make_params(cfg, seed=seed)
     batch = synth.make_batch(cfg, B, N, S, family, seed=seed)
     model = build_reference_model(cx, CfgCls, cfg, N, params)
@@ -207,6 +212,20 @@ def run_case(cx, CfgCls, cfg, B, N, S, family, seed, with_grads, full_logits=Fal
     out.update(logits_summary(mlm.detach(), np.unique(cols)))
     if full_logits:
         out["mlm"] = mlm.detach().numpy()
+    if lab_ncols:
+        # The LABELLED rows of the MLM logits, entry by entry, for the fused step's labelled-rows-only head (train_origin.py:120-126 only
+        # ever reads those rows: CrossEntropyLoss(ignore_index=-100)).  All 30,522 columns of ~200 rows would be 26 MB of incompressible
+        # f32; stored instead: `lab_ncols` sampled columns of every labelled row + the logit at the label + (above, for every
+        # position) the row's logsumexp over ALL columns, its arg-max and its maximum.
+        lab = tb["txt_labels"].reshape(-1)
+        rows = torch.nonzero(lab != -100).reshape(-1)                    # flat b * L + i, row-major: the order TrainStep uses
+        lcols = np.unique((np.abs(O.splitmix_uniform(5151, lab_ncols)) * cfg.vocab_size).astype(np.int64) % cfg.vocab_size)
+        flat = mlm.detach().reshape(-1, cfg.vocab_size)[rows]
+        out["lab_rows"] = rows.numpy().astype(np.int32)
+        out["lab_ids"] = lab[rows].numpy().astype(np.int32)
+        out["lab_cols"] = lcols.astype(np.int32)
+        out["lab_logits_cols"] = flat[:, torch.from_numpy(lcols)].numpy()
+        out["lab_logit_at_label"] = flat.gather(1, lab[rows].view(-1, 1)).reshape(-1).numpy()
     if with_grads:
         (itm_loss + mlm_loss).backward()
         g = ref_named_grads(model)
@@ -304,6 +323,51 @@ def gen_masks(out_path):
     print("masks:", len(cases), "cases ->", out_path)
 
 
+def gen_manifest(cx, CfgCls, out_path):
+    """state_manifest.json: key -> [shape, dtype] of the REAL reference CXRBERT.state_dict() at BERT-base (what train_origin.py:254-266
+    writes into pytorch_model.bin and :28-34 loads back), so that tests can show a reference-written checkpoint loads here without the
+    reference at hand.  The CNN trunk's keys (`enc.img_encoder.model.*`, torchvision ResNet-50 children 0-7: models/image.py:46-53)
+    cannot come from the import -- torchvision is in neither the reference tree nor this image -- and are listed separately as
+    'unpinned' from torchvision's published module names."""
+    import transformers
+    cfg = O.CONFIGS["base"]
+    man = {}
+    build_reference_model(cx, CfgCls, cfg, 36, O.make_params(cfg, seed=1), manifest=man)
+    blocks = {4: 3, 5: 4, 6: 6, 7: 3}
+    cnn = {"enc.img_encoder.model.0.weight": [64, 3, 7, 7]}
+
+    def bn(prefix, c):
+        for n_ in ("weight", "bias", "running_mean", "running_var"):
+            cnn[f"{prefix}.{n_}"] = [c]
+        cnn[f"{prefix}.num_batches_tracked"] = []
+    bn("enc.img_encoder.model.1", 64)
+    cin = 64
+    for child, nb in blocks.items():
+        w = 64 * 2 ** (child - 4)
+        for i in range(nb):
+            pre = f"enc.img_encoder.model.{child}.{i}"
+            cnn[f"{pre}.conv1.weight"] = [w, cin, 1, 1]; bn(f"{pre}.bn1", w)
+            cnn[f"{pre}.conv2.weight"] = [w, w, 3, 3]; bn(f"{pre}.bn2", w)
+            cnn[f"{pre}.conv3.weight"] = [4 * w, w, 1, 1]; bn(f"{pre}.bn3", 4 * w)
+            if i == 0:
+                cnn[f"{pre}.downsample.0.weight"] = [4 * w, cin, 1, 1]; bn(f"{pre}.downsample.1", 4 * w)
+            cin = 4 * w
+    doc = dict(source="CXRBERT(config, args).state_dict() of /root/reference imported under the shims of oracle/gen_golden.py",
+               transformers_version=transformers.__version__, torch_version=torch.__version__,
+               config=dict(vocab_size=cfg.vocab_size, hidden_size=cfg.hidden, num_hidden_layers=cfg.layers, num_attention_heads=cfg.heads,
+                           intermediate_size=cfg.intermediate, max_position_embeddings=cfg.max_pos),
+               keys=man,
+               older_transformers_extra_keys={"enc.txt_embeddings.position_ids": [[1, cfg.max_pos], "int64"],
+                                              "note": "persistent buffer in transformers 3.x-4.30 (the versions the reference's import paths "
+                                                      "imply); newer versions register it non-persistent, so the import above does not list it"},
+               img_encoder_keys_unpinned=dict(note="torchvision.models.resnet50 children()[:-2] under nn.Sequential (models/image.py:46-53): names "
+                                                   "from torchvision's published module layout, NOT produced by the import (torchvision absent)",
+                                              keys=cnn))
+    with open(out_path, "w") as f:
+        json.dump(doc, f, indent=1, sort_keys=True)
+    print("manifest:", len(man), "reference keys +", len(cnn), "unpinned CNN keys ->", out_path)
+
+
 def gen_adamw(out_path):
     """3 steps on 16 elements with python floats (independent of torch): HF AdamW <=4.x."""
     lr, b1, b2, eps, wd = 1e-3, 0.9, 0.999, 1e-6, 0.01
@@ -342,6 +406,8 @@ def main(argv=()):
         gen_masks(os.path.join(OUT, "masks.npz"))
     if want("adamw"):
         gen_adamw(os.path.join(OUT, "adamw.npz"))
+    if want("manifest"):
+        gen_manifest(cx, CfgCls, os.path.join(OUT, "state_manifest.json"))
     c1 = O.CONFIGS["c1"]
     for fam in ("full", "s2s", "bar", "noncross", "1d"):
         if not want(f"c1_{fam}"):
@@ -372,6 +438,12 @@ def main(argv=()):
         r = run_case(cx, CfgCls, base, B=2, N=36, S=473, family="full", seed=22, with_grads=True, store_hidden=False, ncols=256)
         np.savez_compressed(os.path.join(OUT, "base_full.npz"), **r)
         print("base full", float(r["mlm_loss"]), float(r["itm_loss"]))
+    # the benchmarked path's shape: B = 4 ragged bidirectional samples (they pack), gradients of every parameter and the labelled
+    # rows' logits for the labelled-rows-only head
+    if want("base_full_b4"):
+        r = run_case(cx, CfgCls, base, B=4, N=36, S=473, family="full", seed=26, with_grads=True, store_hidden=False, ncols=32, lab_ncols=1024)
+        np.savez_compressed(os.path.join(OUT, "base_full_b4.npz"), **r)
+        print("base full b4", float(r["mlm_loss"]), float(r["itm_loss"]), "labelled rows", int(r["lab_rows"].shape[0]))
     if want("base_noncross"):
         r = run_case(cx, CfgCls, base, B=1, N=36, S=473, family="noncross", seed=23, with_grads=False, store_hidden=False, ncols=256)
         np.savez_compressed(os.path.join(OUT, "base_noncross.npz"), **r)

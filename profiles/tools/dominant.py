@@ -8,7 +8,7 @@ cases
   ffn1   the FFN-up projection (256x256 ring kernel, NT form): [32768, 768] x [3072, 768]^T + bias, GELU and GELU' epilogue, two f16 outputs
   attn   attention forward + backward (dQ, dK/dV) at B = 64, A = 12, L = 512, ragged packed rows, dropout 0.1 from keep-bits
   qkv wo ffn2 dz da dctx dxqkv dw2 dwqkv dwo   the other GEMM calls of an encoder layer (GEMM_FAMILY below)
-usage: python3 profiles/tools/dominant.py <case> [reps]   |   python3 profiles/tools/dominant.py all"""
+usage: python3 profiles/tools/dominant.py <case> [reps] [warm-up]   |   python3 profiles/tools/dominant.py all [reps] [warm-up] [out.json]"""
 import os
 import sys
 
@@ -131,33 +131,52 @@ def _gemm_family(name, dev):
     return fn, dict(kernel=GEMM_FAMILY[name][0], symbol="gemm_", flop=fl, bytes=by)
 
 
-def time_case(name, reps=20, warm=3, dev="cuda"):
-    """HIP events on the stream the kernel is launched on; ms per call of the case's launch callable."""
+def time_case(name, reps=200, warm=50, dev="cuda", batch=10):
+    """HIP events on the stream the kernel is launched on.  `warm` untimed calls first (clock ramp, cold caches, first-touch page faults:
+    round 4's 20-launch timing sat 25 % below its own rocprofv3 average), then `reps` timed calls in batches of `batch` (one event pair
+    per batch: per-call events would put a host round trip between launches).  meta["ms"] = MEDIAN batch mean per call; ms_min / ms_max
+    = fastest / slowest batch mean; ms_mean = all timed calls.  rocprofv3's per-launch average over the same run (which includes the
+    warm-up launches) is what profiles/tools/r05_condense.py puts beside it."""
+    import statistics
     fn, meta = make_case(name, dev)
     st = torch.cuda.current_stream()
     for _ in range(warm):
         fn()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record(st)
-    for _ in range(reps):
-        fn()
-    e1.record(st)
-    e1.synchronize()
-    meta["ms"] = e0.elapsed_time(e1) / reps
+    nb = max(1, reps // batch)
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(nb + 1)]
+    evs[0].record(st)
+    for i in range(nb):
+        for _ in range(batch):
+            fn()
+        evs[i + 1].record(st)
+    evs[-1].synchronize()
+    per = [evs[i].elapsed_time(evs[i + 1]) / batch for i in range(nb)]
+    meta["ms"] = statistics.median(per)
+    meta["ms_min"], meta["ms_max"], meta["ms_mean"] = min(per), max(per), sum(per) / nb
+    meta["timed_calls"], meta["warmup_calls"] = nb * batch, warm
     return meta
 
 
 if __name__ == "__main__":
     case = sys.argv[1] if len(sys.argv) > 1 else "dw"
-    reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+    reps = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+    warm = int(sys.argv[3]) if len(sys.argv) > 3 else 50
     if case == "all":
-        tot = 0.0
+        import json
+        tot, rows = 0.0, {}
         for c in ["ffn1", "dw", "attn"] + list(GEMM_FAMILY):
-            m = time_case(c, reps=reps)
+            m = time_case(c, reps=reps, warm=warm)
             n = LAUNCHES_PER_STEP.get(c) or GEMM_FAMILY[c][1]
             tot += n * m["ms"]
-            print(f"{c:6s} {m['ms'] * 1e3:7.1f} us  {m['flop'] / m['ms'] / 1e9:5.0f} TFLOP/s  x{n} = {n * m['ms']:.2f} ms per step   {m['kernel']}")
-        print(f"sum over a step (12 layers, stand-alone times): {tot:.2f} ms")
+            rows[c] = dict(us_median=m["ms"] * 1e3, us_min=m["ms_min"] * 1e3, us_max=m["ms_max"] * 1e3, us_mean=m["ms_mean"] * 1e3,
+                           tflops=m["flop"] / m["ms"] / 1e9, flop=m["flop"], bytes=m["bytes"], launches_per_step=n, kernel=m["kernel"])
+            print(f"{c:6s} median {m['ms'] * 1e3:7.1f} us (min {m['ms_min'] * 1e3:.1f}, max {m['ms_max'] * 1e3:.1f})  {m['flop'] / m['ms'] / 1e9:5.0f} TFLOP/s  "
+                  f"x{n} = {n * m['ms']:.2f} ms per step   {m['kernel']}", flush=True)
+        print(f"sum over a step (12 layers, stand-alone medians): {tot:.2f} ms")
+        if len(sys.argv) > 4:
+            with open(sys.argv[4], "w") as f:
+                json.dump(rows, f, indent=1)
         sys.exit(0)
-    m = time_case(case, reps=reps)
-    print(f"{case}: {m['ms'] * 1e3:.1f} us per call (HIP events) = {m['flop'] / m['ms'] / 1e9:.0f} TFLOP/s algorithmic; {m['kernel']}")
+    m = time_case(case, reps=reps, warm=warm)
+    print(f"{case}: median {m['ms'] * 1e3:.1f} us per call (min {m['ms_min'] * 1e3:.1f}, max {m['ms_max'] * 1e3:.1f}, mean {m['ms_mean'] * 1e3:.1f}; HIP events, "
+          f"{m['timed_calls']} calls after {m['warmup_calls']} warm-up) = {m['flop'] / m['ms'] / 1e9:.0f} TFLOP/s algorithmic; {m['kernel']}")

@@ -12,11 +12,11 @@ from medvill_amd import _lib
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def header_functions():
-    src = open(os.path.join(ROOT, "include", "medvill.h")).read()
+def header_functions(name="medvill.h"):
+    src = open(os.path.join(ROOT, "include", name)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     out = {}
-    for m in re.finditer(r"\b(?:int|void|const char\*)\s+(mv_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
+    for m in re.finditer(r"\b(?:int|void|size_t|const char\*)\s+(mv_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
         args = m.group(2).strip()
         n = 0 if args in ("", "void") else len([a for a in args.split(",") if a.strip()])
         out[m.group(1)] = n
@@ -26,7 +26,7 @@ def header_functions():
 def test_library_is_built_and_loads():
     assert os.path.exists(_lib.LIB_PATH), "run __graft_entry__.build() first"
     lib = _lib.load()
-    assert lib.mv_abi_version() == 5
+    assert lib.mv_abi_version() == _lib.ABI_VERSION == 6
     assert b"gfx950" in lib.mv_build_info()
 
 
@@ -39,6 +39,31 @@ def test_every_declared_symbol_is_exported_with_matching_arity():
         assert name in _lib.PROTOTYPES, f"{name} has no ctypes prototype"
         assert len(_lib.PROTOTYPES[name]) == nargs, (name, len(_lib.PROTOTYPES[name]), nargs)
     assert set(_lib.PROTOTYPES) == set(decl)
+
+
+def _exports(path):
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+    return {ln.split()[-1] for ln in out.splitlines() if ln.split() and ln.split()[-1].startswith("mv_")}
+
+
+def test_product_library_exports_the_header_and_nothing_else_and_has_no_knobs():
+    """SURVEY 8(b): no global mutable state.  The kernel-forcing knobs live in libmedvill_hip_dbg.so only (include/medvill_debug.h);
+    the product library exports exactly what medvill.h declares."""
+    assert _exports(_lib.LIB_PATH) == set(header_functions())
+    dbg = header_functions("medvill_debug.h")
+    assert set(dbg) == set(_lib.DEBUG_PROTOTYPES) == {"mv_debug_set_knob", "mv_debug_get_knob"}
+    for name, nargs in dbg.items():
+        assert len(_lib.DEBUG_PROTOTYPES[name]) == nargs
+    assert os.path.exists(_lib.DBG_LIB_PATH), "run __graft_entry__.build() first"
+    assert _exports(_lib.DBG_LIB_PATH) == set(header_functions()) | set(dbg)
+    raw = ctypes.CDLL(_lib.DBG_LIB_PATH)
+    for name, (kid, default) in _lib.KNOBS.items():           # the debug library starts from the product's constants
+        assert raw.mv_debug_get_knob(kid) == default, name
+    assert raw.mv_debug_set_knob(99, 0) == -1 and raw.mv_debug_set_knob(4, 10) == -1
+    raw.mv_build_info.restype = ctypes.c_char_p
+    assert b"debug-knobs" in raw.mv_build_info()
+    assert b"debug-knobs" not in _lib.load().mv_build_info()
 
 
 def test_signatures_have_no_torch_types():

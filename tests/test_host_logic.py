@@ -153,6 +153,71 @@ def test_mask_descriptors_know_when_padding_is_invisible():
         assert m[:10, 10:].any()                          # valid queries do see padding there
 
 
+def _manifest():
+    import json
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "state_manifest.json")) as f:
+        return json.load(f)
+
+
+def test_state_dict_keys_and_shapes_equal_the_reference_manifest():
+    """tests/golden/state_manifest.json is the key -> shape list of the REAL reference CXRBERT.state_dict() at BERT-base
+    (oracle/gen_golden.py --only manifest imports the reference to write it).  This model's state_dict() must have exactly those keys
+    and shapes: what the reference's trainer saves (train_origin.py:254-266) is what loads here, and the other way round."""
+    man = _manifest()
+    c = man["config"]
+    cfg = mv.ModelConfig(vocab_size=c["vocab_size"], hidden=c["hidden_size"], layers=c["num_hidden_layers"], heads=c["num_attention_heads"],
+                         intermediate=c["intermediate_size"], max_pos=c["max_position_embeddings"])
+    lay, _ = mv.param_layout(cfg)
+    ours = {k: list(s) for k, (_, s) in lay.items()}
+    for alias, canon in ALIASES.items():
+        ours[alias] = ours[canon]
+    ref = {k: v[0] for k, v in man["keys"].items()}
+    assert set(ours) == set(ref), (sorted(set(ours) - set(ref))[:5], sorted(set(ref) - set(ours))[:5])
+    assert all(ours[k] == ref[k] for k in ref)
+    # the CNN trunk's keys (unpinned: torchvision's published names) are the ones ImageEncoder_cnn holds
+    enc = mv.ImageEncoder_cnn(num_image_embeds=9)
+    cnn = {"enc.img_encoder." + k: list(v.shape) for k, v in enc.state_dict().items()}
+    assert cnn == man["img_encoder_keys_unpinned"]["keys"]
+
+
+def test_a_checkpoint_written_with_the_reference_keys_loads(tmp_path):
+    """A pytorch_model.bin holding EVERY key of the reference manifest at a small geometry -- the tied / shared tensors stored under all
+    their names, the `position_ids` buffer older transformers versions save, the CNN trunk -- loads strictly (nothing missing, nothing
+    unexpected), lands in the right parameters, and a checkpoint saved from here has the manifest's key set again."""
+    import json
+    man = _manifest()
+    c = man["config"]
+    dims = {c["vocab_size"]: 1024, c["hidden_size"]: 128, c["intermediate_size"]: 512, c["max_position_embeddings"]: 128}
+    g = torch.Generator().manual_seed(5)
+    sd = {}
+    for k, (shape, dt) in man["keys"].items():
+        l = k.split("layer.")[1].split(".")[0] if "layer." in k else None
+        if l is not None and int(l) >= 2:
+            continue                                          # TINY has two layers
+        sd[k] = torch.randn([dims.get(d, d) for d in shape], generator=g)
+    for alias, canon in ALIASES.items():                      # the reference stores one tensor under several names
+        sd[alias] = sd[canon]
+    sd["enc.txt_embeddings.position_ids"] = torch.arange(128).view(1, -1)
+    enc = mv.ImageEncoder_cnn(num_image_embeds=9)
+    cnn_sd = {k: torch.randn(v.shape, generator=g) if v.dtype.is_floating_point else v.clone() for k, v in enc.state_dict().items()}
+    sd.update({"enc.img_encoder." + k: v for k, v in cnn_sd.items()})
+    d = tmp_path / "ref_ckpt"
+    os.makedirs(d)
+    torch.save(sd, d / "pytorch_model.bin")
+    with open(d / "config.json", "w") as f:
+        json.dump(TINY, f)
+    m = mv.CXRBERT.from_pretrained(str(d), device="cpu", img_encoder=enc)
+    r = m.load_state_dict(sd, strict=True)
+    assert r.missing_keys == [] and r.unexpected_keys == []
+    out = m.state_dict()
+    for k in sd:
+        if "position_ids" in k:
+            continue
+        assert torch.equal(out[k].float().cpu(), sd[k].float()), k
+    assert {k for k in out if not k.startswith("enc.img_encoder.")} == \
+        {k for k in man["keys"] if "layer." not in k or int(k.split("layer.")[1].split(".")[0]) < 2}
+
+
 def test_region_encoder_container_matches_torchvision_layout():
     """ImageEncoder_cnn holds exactly the parameters / buffers of torchvision's resnet50 children()[:-2] under the
     reference's `model.<idx>` names (models/image.py:50-52), all frozen (cxrbert_origin.py:66-70 unfreezes nothing)."""

@@ -90,6 +90,68 @@ def test_args_namespace_of_main_origin_is_what_the_trainer_reads():
             CXRBERT_Trainer(args, train_dataloader=[], test_dataloader=None)
 
 
+def _hf_bert_state(name):
+    """A genuine HF BertModel state dict (its own key names) at the geometry of a --bert_model choice, randomly initialised."""
+    import transformers
+    from medvill_amd.trainer import BERT_CONFIGS
+    torch.manual_seed(7)
+    return transformers.BertModel(transformers.BertConfig(**BERT_CONFIGS[name])).state_dict()
+
+
+def test_bert_model_names_that_mean_pretrained_weights_never_random_init_silently(tmp_path):
+    """cxrbert_origin.py:43-55: only `bert-base-scratch` / `bert-small-scratch` build a random BertModel; every other --bert_model
+    value loads PRETRAINED weights.  Here (no network) such a value needs the weights handed over, else it raises."""
+    import warnings
+    from medvill_amd.checkpoint import from_hf_bert_keys
+    from medvill_amd.trainer import BERT_CONFIGS, load_pretrained_bert, resolve_bert_model
+    tiny = "google/bert_uncased_L-2_H-128_A-2"
+    for name in ("bert-base-scratch", "bert-small-scratch"):
+        cfg, sd = resolve_bert_model(main_origin_parser().parse_args(["--bert_model", name]), name)
+        assert sd is None and cfg == BERT_CONFIGS[name]
+    for name in ("bert-base-uncased", tiny, "emilyalsentzer/Bio_ClinicalBERT", "bionlp/bluebert_pubmed_mimic_uncased_L-12_H-768_A-12"):
+        with pytest.raises(RuntimeError, match="PRETRAINED"):
+            resolve_bert_model(main_origin_parser().parse_args(["--bert_model", name]), name)
+    with pytest.raises(NotImplementedError):
+        resolve_bert_model(main_origin_parser().parse_args([]), "albert-base-v2")
+    args = main_origin_parser().parse_args(["--bert_model", tiny])
+    args.allow_random_init = True                                            # the explicit opt-out warns
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        assert resolve_bert_model(args, tiny) == (BERT_CONFIGS[tiny], None)
+    assert any("RANDOM" in str(x.message) for x in w)
+    # weights handed over: as a state dict, and as a checkpoint directory (pytorch_model.bin + config.json)
+    hf = _hf_bert_state(tiny)
+    args = main_origin_parser().parse_args(["--bert_model", tiny])
+    args.init_state_dict = hf
+    cfg, sd = resolve_bert_model(args, tiny)
+    assert sd is hf
+    d = tmp_path / "tiny_bert"
+    os.makedirs(d)
+    torch.save({"bert." + k: v for k, v in hf.items()}, d / "pytorch_model.bin")      # BertForPreTraining-style prefix
+    import json
+    with open(d / "config.json", "w") as f:
+        json.dump(BERT_CONFIGS[tiny], f)
+    cfg2, sd2 = resolve_bert_model(main_origin_parser().parse_args([]), str(d))
+    assert cfg2 == BERT_CONFIGS[tiny] and set(from_hf_bert_keys(sd2)) == set(from_hf_bert_keys(hf))
+    # the weights land in the modules the reference takes from `bert` (cxrbert_origin.py:56-57,72-73), shared tensors follow
+    m = mv.CXRBERT(cfg, None, device="cpu")
+    before = {k: v.clone() for k, v in m.state_dict().items()}
+    n = load_pretrained_bert(m, sd2)
+    after = m.state_dict()
+    assert n == sum(1 for k in m._param_names if k.startswith(("enc.txt_embeddings.", "enc.encoder.", "enc.pooler.")))
+    assert torch.equal(after["enc.txt_embeddings.word_embeddings.weight"], hf["embeddings.word_embeddings.weight"])
+    assert torch.equal(after["mlm.predictions.decoder.weight"], hf["embeddings.word_embeddings.weight"])          # tied
+    assert torch.equal(after["enc.img_embeddings.LayerNorm.weight"], hf["embeddings.LayerNorm.weight"])           # shared
+    assert torch.equal(after["enc.encoder.layer.1.output.dense.weight"], hf["encoder.layer.1.output.dense.weight"])
+    assert torch.equal(after["enc.pooler.dense.bias"], hf["pooler.dense.bias"])
+    for k in ("itm.linear.weight", "mlm.predictions.transform.dense.weight", "enc.img_embeddings.img_embeddings.weight"):
+        assert torch.equal(after[k], before[k])                               # the heads / image projection keep their own init
+    bad = dict(hf)
+    bad.pop("encoder.layer.0.attention.self.query.weight")
+    with pytest.raises(RuntimeError, match="lacks"):
+        load_pretrained_bert(m, bad)
+
+
 @pytest.mark.gpu
 def test_main_origin_loop_through_the_models_import_path(tmp_path):
     """The body of main_origin.py:52-62 -- build the trainer from `args`, `train(epoch)`, `save(epoch, output_path)` -- through
@@ -100,6 +162,8 @@ def test_main_origin_loop_through_the_models_import_path(tmp_path):
     from models.train_origin import CXRBERT_Trainer
     args = main_origin_parser().parse_args(["--bert_model", "google/bert_uncased_L-2_H-128_A-2", "--batch_size", "4", "--num_image_embeds", "36",
                                             "--seq_len", "128", "--lr", "1e-3", "--output_path", str(tmp_path), "--epochs", "2"])
+    # this --bert_model value means "start from the pretrained BERT-Tiny" in the reference: the weights are handed over (no network)
+    args.init_state_dict = _hf_bert_state(args.bert_model)
     torch.manual_seed(args.seed)                       # utils.set_seed(args.seed) of main_origin.py:25
     N, S, V = args.num_image_embeds, 40, 30522
 
@@ -121,6 +185,8 @@ def test_main_origin_loop_through_the_models_import_path(tmp_path):
     test_dl = DataLoader(Tuples(4, 100), batch_size=args.batch_size, num_workers=0, shuffle=False)
     trainer = CXRBERT_Trainer(args, train_dataloader=train_dl, test_dataloader=test_dl)
     assert trainer.model.cfg.hidden == 128 and trainer.model.cfg.layers == 2
+    assert torch.equal(trainer.model.state_dict()["enc.encoder.layer.0.intermediate.dense.weight"].cpu(),
+                       args.init_state_dict["encoder.layer.0.intermediate.dense.weight"])
     res = []
     for epoch in range(args.epochs):
         res.append(trainer.train(epoch))

@@ -211,14 +211,47 @@ def test_pure_bf16_forward_operands_stay_within_their_measured_bound(golden_dir)
     assert d.mean() < 6e-3 and d.max() < 3.5e-2
 
 
-@pytest.mark.parametrize("dtype,rtol", [(torch.float32, 1e-3), (torch.bfloat16, 4e-2)])
-def test_bert_base_gradients_against_reference_golden(golden_dir, dtype, rtol):
-    """Config 2's family at scale (BERT-base, L=512, bidirectional, B=2 ragged): the fused training step's gradient of
-    EVERY parameter against the reference's loss.backward() (norm + 16 sampled entries per tensor)."""
-    z, meta, cfg, P, b = load_case(golden_dir, "base_full")
+@pytest.mark.parametrize("case", ["base_full", "base_full_b4"])
+@pytest.mark.parametrize("dtype,rtol,pack", [(torch.float32, 1e-3, False), (torch.bfloat16, 4e-2, False), (torch.bfloat16, 4e-2, True)])
+def test_bert_base_gradients_against_reference_golden(golden_dir, dtype, rtol, pack, case):
+    """Config 2's family at scale (BERT-base, 12 layers, L=512, bidirectional, B=2 / B=4 ragged): the fused training step's gradient
+    of EVERY parameter against the reference's loss.backward() (norm + 16 sampled entries per tensor).  pack=True is the path
+    bench.py times and CXRBERT_Trainer runs -- TrainStep's defaults: mask descriptors, padding removed (packed rows), the last layer on
+    the consumed rows only with those rows as its only queries (`tq`), the MLM head on the labelled rows only, f16 operands and loss-
+    scaled f16 gradients -- held to the same tolerances as the padded path."""
+    z, meta, cfg, P, b = load_case(golden_dir, case)
     model = make_model(cfg, P, dtype)
-    stats = mv.TrainStep(model, lr=0.0, pack_rows=False)(dict(b), train=True).cpu()
+    batch = dict(b)
+    if pack:
+        batch["attn_desc"] = mv.data.MaskDesc.make("full", meta["N"], meta["S"], b["n_ids"], DEV)
+        ts = mv.TrainStep(model, lr=0.0)                                      # the defaults ARE the benchmarked path
+        assert ts.pack_rows and ts.tail_rows and model.engine.tail_queries
+    else:
+        ts = mv.TrainStep(model, lr=0.0, pack_rows=False)
+    stats = ts(batch, train=True).cpu()
+    eng = model.engine
+    if pack:
+        Lq = meta["N"] + meta["S"] + 3
+        assert eng.S["cu"] is not None and eng.S["tq"] is not None and eng.S["sel"] is not None and eng.S["M"] < meta["B"] * Lq
+        assert eng.dt == mv._lib.MV_F16 and eng.fdt == mv._lib.MV_F16
+        assert float(eng.scaler[6]) == 0.0                                    # no non-finite gradient under the loss scale
+    else:
+        assert eng.S["cu"] is None
     tol = FP32_TOL if dtype == torch.float32 else BF16_TOL
+    if "lab_rows" in z.files:
+        # the labelled-rows-only MLM head against the reference's logits AT those rows, entry by entry (1,024 sampled columns of
+        # every labelled row, the logit at the label, and each row's logsumexp / maximum over all 30,522 columns)
+        R = int(z["lab_rows"].shape[0])
+        assert int(stats[1]) == R
+        logits = eng.S["ht_"]["logits"][:R, :cfg.vocab_size].float().cpu()
+        lab_ids = torch.from_numpy(z["lab_ids"].astype(np.int64))
+        lc = torch.from_numpy(z["lab_cols"].astype(np.int64))
+        d_cols = float(np.abs(logits[:, lc].numpy() - z["lab_logits_cols"]).max())
+        d_lab = float(np.abs(logits.gather(1, lab_ids.view(-1, 1)).reshape(-1).numpy() - z["lab_logit_at_label"]).max())
+        d_lse = float(np.abs(torch.logsumexp(logits, -1).numpy() - z["lse"].reshape(-1)[z["lab_rows"]]).max())
+        d_max = float(np.abs(logits.max(-1).values.numpy() - z["maxval"].reshape(-1)[z["lab_rows"]]).max())
+        print(f"{case} {dtype} pack={pack}: labelled rows {R}: |dlogits| cols {d_cols:.2e} label {d_lab:.2e} lse {d_lse:.2e} max {d_max:.2e}")
+        assert max(d_cols, d_lab, d_lse, d_max) < tol
     assert abs(float(stats[0] / stats[1]) - float(z["mlm_loss"])) < tol and abs(float(stats[3] / stats[4]) - float(z["itm_loss"])) < tol
     names = [str(n) for n in z["grad_names"]]
     gmax = float(z["grad_norms"].max())
@@ -235,7 +268,7 @@ def test_bert_base_gradients_against_reference_golden(golden_dir, dtype, rtol):
         worst = max(worst, e1, e2 * 0.25)
         table.append((e2, e1, k, ref_norm))
     table.sort(reverse=True)
-    print(f"base_full {dtype}: worst gradient deviation {worst:.2e}; largest entry deviations: "
+    print(f"{case} {dtype} pack={pack}: worst gradient deviation {worst:.2e}; largest entry deviations: "
           + "; ".join(f"{k} e2={e2:.3f} e1={e1:.4f} |g|={n:.2e}" for e2, e1, k, n in table[:6]))
     # norm of every tensor within rtol; single entries within 4 rtol of the tensor's scale -- 6 rtol for the two head weights whose
     # gradient is a sum of B = 2 outer products (pooler, ITM): their entries are heavy-tailed (a few are tens of RMS), so one
@@ -392,6 +425,40 @@ def test_head_submodules_are_callable_like_the_reference(golden_dir, dtype, tol,
     assert float((out.detach() - (xin.detach() @ W.t() + bb)).abs().max()) < tol
     out[:, 1].sum().backward()
     assert float((xin.grad - W[1].expand(5, -1)).abs().max()) < tol * float(W.abs().max()) + 1e-6
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 2e-2)])
+def test_head_calls_are_reentrant_like_nn_modules(golden_dir, dtype, tol):
+    """the reference's heads are plain nn.Modules -- two calls in one graph (or gradient accumulation over two forwards)
+    back-propagate independently.  model.mlm(x1) and model.mlm(x2) BEFORE either backward must give the gradients of the two calls
+    made one after the other, and the head's backward must leave the other heads' gradient buffers (same bucket) alone."""
+    z, meta, cfg, P, b = load_case(golden_dir, "c1v1k_full")
+    model = make_model(cfg, P, dtype)
+    g = torch.Generator(device="cpu").manual_seed(3)
+    xs = [torch.randn(n, cfg.hidden, generator=g).to(DEV) for n in (7, 5)]
+    ws = [torch.randn(n, cfg.vocab_size, generator=g).to(DEV) for n in (7, 5)]
+    names = [n for n, _ in model.named_parameters() if n.startswith("mlm.") or n.endswith("word_embeddings.weight")]
+
+    def run(together):
+        model.zero_grad()
+        leaves = [x.clone().requires_grad_(True) for x in xs]
+        if together:
+            outs = [model.mlm(x)[0] for x in leaves]                       # both forwards first ...
+            sum((o.float() * w).sum() for o, w in zip(outs, ws)).backward()   # ... then both backwards
+        else:
+            for x, w in zip(leaves, ws):
+                (model.mlm(x)[0].float() * w).sum().backward()
+        return [x.grad.clone() for x in leaves] + [model.get_parameter(n).grad.clone() for n in names]
+
+    eng = model.engine
+    eng.ensure_grad()
+    eng.g["itm.linear.weight"].fill_(1.0)
+    eng.g["enc.pooler.dense.bias"].fill_(2.0)
+    one, two = run(False), run(True)
+    for a_, b_, n in zip(one, two, ["x1", "x2"] + names):
+        scale = max(float(a_.abs().max()), 1e-6)
+        assert float((a_ - b_).abs().max()) <= tol * scale, (n, float((a_ - b_).abs().max()), scale)
+    assert float(eng.g["itm.linear.weight"].min()) == 1.0 and float(eng.g["enc.pooler.dense.bias"].max()) == 2.0
 
 
 def test_no_grad_forward_keeps_no_per_layer_activations():
@@ -551,7 +618,7 @@ def test_packed_rows_reproduce_the_padded_step(family, B, N, S, tq):
     assert rel < tol and worst < tol
 
 
-@pytest.mark.parametrize("family,N,S", [("mixed", 36, 473), ("s2s", 100, 665)])
+@pytest.mark.parametrize("family,N,S", [("mixed", 36, 473), ("s2s", 100, 665), ("full", 36, 473)])
 def test_packed_rows_reproduce_the_padded_step_at_bert_base_scale(family, N, S):
     """The same property on the production kernels' shapes (BERT-base, L = 512 / 768: 256-row GEMM tiles, persistent weight-
     gradient kernel with odd token counts, MFMA attention with per-sample row offsets), dropout off (the hidden-state
@@ -564,6 +631,8 @@ def test_packed_rows_reproduce_the_padded_step_at_bert_base_scale(family, N, S):
         model.reset_parameters(seed=2)
         model.train()
         stats = mv.TrainStep(model, lr=0.0, pack_rows=pack)(batch, train=True)
+        # "full": every sample is bidirectional, so the packed step also runs its last layer with the consumed rows as the only queries
+        assert (model.engine.S["tq"] is not None) == (pack and family == "full")
         out.append((stats.clone(), model.engine.flat_g.clone()))
         del model
     (s0, g0), (s1, g1) = out

@@ -128,9 +128,9 @@ def test_gradients_match_reference(golden_dir, name):
     assert np.abs(dE - z["dE_special_rows"]).max() <= 2e-6 * max(1.0, np.abs(z["dE_special_rows"]).max())
 
 
-@pytest.mark.parametrize("name", ["base_s2s", "base_full", "base_noncross", "base768_s2s"])
+@pytest.mark.parametrize("name", ["base_s2s", "base_full", "base_full_b4", "base_noncross", "base768_s2s"])
 def test_bert_base_matches_reference(golden_dir, name):
-    """BERT-base at the scale of BASELINE.json configs 3 / 2 / 4 / 5 (L = 512 seq2seq, bidirectional B=2 ragged,
+    """BERT-base at the scale of BASELINE.json configs 3 / 2 / 4 / 5 (L = 512 seq2seq, bidirectional B=2 and B=4 ragged,
     non-cross; L = 768 seq2seq with max_position_embeddings 768)."""
     z, meta = _load(golden_dir, name + ".npz")
     cfg, P, b = _oracle_inputs(z, meta)
@@ -146,6 +146,12 @@ def test_bert_base_matches_reference(golden_dir, name):
     assert np.abs(mlm.detach()[..., cols].numpy() - z["logits_cols"]).max() < 1e-4
     assert np.abs(itm.detach().numpy() - z["itm"]).max() < 1e-4
     assert abs(float(ml) - float(z["mlm_loss"])) < 1e-4 and abs(float(il) - float(z["itm_loss"])) < 1e-4
+    if "lab_rows" in z:          # the labelled rows' logits (what train_origin.py:120-126's CrossEntropyLoss(ignore_index=-100) reads)
+        rows = torch.from_numpy(z["lab_rows"].astype(np.int64))
+        assert np.array_equal(rows.numpy(), np.nonzero(b["txt_labels"].reshape(-1).numpy() != -100)[0])
+        flat = mlm.detach().reshape(-1, cfg.vocab_size)[rows]
+        assert np.abs(flat[:, torch.from_numpy(z["lab_cols"].astype(np.int64))].numpy() - z["lab_logits_cols"]).max() < 1e-4
+        assert np.abs(flat.gather(1, torch.from_numpy(z["lab_ids"].astype(np.int64)).view(-1, 1)).reshape(-1).numpy() - z["lab_logit_at_label"]).max() < 1e-4
     if with_grads:
         (ml + il).backward()
         for i, k in enumerate(str(n) for n in z["grad_names"]):
