@@ -207,6 +207,24 @@ def _drop_in_user_timings(mv, model, step, cfg, dev, B, N, S, n, out, time, Simp
         one(t + 2)
     torch.cuda.synchronize()
     out["dropin_forward_backward_b16_ms"] = (time.perf_counter() - t0) / n * 1e3
+    # (iii) the same loop with ONE line changed: `loss = medvill_amd.losses.mlm_itm_loss(mlm, itm, labels, aligned)` under
+    # model.lazy_logits = True (the MLM head runs on the labelled rows inside the loss; no [B,L,V] tensor): B = 16 and B = 64
+    model.lazy_logits = True
+    for bsz, key in ((16, "dropin_lazy_loss_b16_ms"), (64, "dropin_lazy_loss_b64_ms")):
+        bl = mv.data.synthetic_batch(cfg.vocab_size, bsz, N, S, "full", seed=998, device=dev)
+
+        def one_lazy(t):
+            mlm, itm = model(bl["cls_tok"], bl["input_txt"], bl["attn_mask"], bl["segment"], (bl["img_feats"], bl["img_pos"]), bl["sep_tok"])
+            mv.losses.mlm_itm_loss(mlm, itm, bl["txt_labels"], bl["is_aligned"]).backward()
+            eng.adamw_step(t, lr=1e-5)
+        one_lazy(1)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for t in range(n):
+            one_lazy(t + 2)
+        torch.cuda.synchronize()
+        out[key] = (time.perf_counter() - t0) / n * 1e3
+    model.lazy_logits = False
     return out
 
 
@@ -253,6 +271,11 @@ def main():
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "4" if os.environ.get("MV_SINGLE_DEVICE") == "1" else "8")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC for RCCL (the hosts of this pool support nothing else)
     os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")            # kernel arguments in device memory: see medvill_amd/__init__.py (-0.3 ms per step)
+    # each rank on the CPUs of its GPU's NUMA node, before anything touches the GPU (multi-GPU hosts: two sockets); importing the package
+    # starts no HIP runtime
+    import medvill_amd.dist as mvdist
+    numa = mvdist.bind_to_gpu_numa(0 if os.environ.get("MV_SINGLE_DEVICE") == "1" else local_rank) if world > 1 or os.environ.get("MV_NUMA_BIND") == "1" \
+        else {"bound": False, "why": "single-GPU run"}
     import torch
     # rehearsal hooks for a 1-GPU box: MV_DIST_BACKEND=gloo MV_SINGLE_DEVICE=1 run every rank on cuda:0 over gloo
     if os.environ.get("MV_SINGLE_DEVICE") == "1":
@@ -324,6 +347,8 @@ def main():
     value = world * B / (ms_per_step / 1e3)
     st = stats.cpu()
     exposed_ms = step.exchange_exposed_ms() if dist_on else 0.0
+    timeline = step.exchange_timeline() if dist_on else None
+    rank_env = mvdist.rank_environment({"numa": numa}) if dist_on else [dict(mvdist.rank_environment({"numa": numa})[0])]
     packed = model.engine.S.get("cu") is not None
     tq_on = model.engine.S.get("tq") is not None          # last layer's attention ran with the consumed rows as its only queries
 
@@ -365,6 +390,7 @@ def main():
                     if d_["config"].get("dist_backend") == "nccl":
                         extras["rccl_rehearsal_ms_per_step"] = d_["ms_per_step"]
                         extras["rccl_rehearsal_exposed_ms"] = d_["config"].get("allreduce_exposed_ms")
+                        extras["rccl_rehearsal_timeline"] = d_["config"].get("allreduce_timeline")
                 except Exception as e:
                     print(f"[bench] one-rank RCCL rehearsal unavailable: {e!r}", file=sys.stderr, flush=True)
                 c5 = CONFIGS["c5"]
@@ -450,11 +476,19 @@ def main():
                        "trainer_hostloader_full_ms_per_step": extras.get("trainer_hostloader_full_ms_per_step"),
                        "trainer_hostloader_bar_ms_per_step": extras.get("trainer_hostloader_bar_ms_per_step"),
                        "dropin_forward_backward_b16_ms": extras.get("dropin_forward_backward_b16_ms"),
+                       # ... and with the two CrossEntropyLoss calls replaced by medvill_amd.losses.mlm_itm_loss under model.lazy_logits
+                       "dropin_lazy_loss_b16_ms": extras.get("dropin_lazy_loss_b16_ms"), "dropin_lazy_loss_b64_ms": extras.get("dropin_lazy_loss_b64_ms"),
                        "rccl_ranks": rccl_ranks, "dist_backend": backend, "allreduce_exposed_ms": exposed_ms,
+                       # rank 0's view of the gradient exchange: when each bucket's all-reduce was issued / completed relative to the first
+                       # bucket's issue, and when the compute stream waited for the rest (None undistributed)
+                       "allreduce_timeline": timeline,
+                       # GPU_MAX_HW_QUEUES / HSA_ENABLE_IPC_MODE_LEGACY / ... and the NUMA binding AS SEEN BY EVERY RANK
+                       "rank_env": rank_env,
                        # the same step as a one-rank RCCL job with every collective issued (child process); at 8 ranks the model of DESIGN.md 7
                        # expects 0.5-0.6 ms of exposed all-reduce (the embeddings bucket) on top
                        "rccl_rehearsal_ms_per_step": extras.get("rccl_rehearsal_ms_per_step"),
                        "rccl_rehearsal_exposed_ms": extras.get("rccl_rehearsal_exposed_ms"),
+                       "rccl_rehearsal_timeline": extras.get("rccl_rehearsal_timeline"),
                        "expected_exposed_allreduce_ms_at_8_ranks": "0.5-0.6 (model, DESIGN.md 7; unmeasured)",
                        "mlm_loss": float(st[0] / max(float(st[1]), 1.0)), "itm_loss": float(st[3] / max(float(st[4]), 1.0))},
             # dominant kernel (the FFN-up GEMM, largest single share of the step): algorithmic FLOPs per launch / its

@@ -25,7 +25,8 @@ enum {
   MV_KNOB_ID_PERSISTENT_CUS = 5, /* (0) the persistent weight-gradient GEMM kernels launch at most n blocks; 0 = one per CU */
   MV_KNOB_ID_ROWOPS_VARIANT = 6, /* (0) mv_layernorm_bwd: low byte 0 prefetching kernel, 8 waves per block | 1 one row at a time, 4 waves |
                                     2, 3 prefetching, 4 / 16 waves; bits 8.. = grid cap (0 = default) */
-  MV_KNOB_ID_ATTN_FWD = 8,       /* (0) attention forward: 0 one 32-query sub-tile per wave | 1 two sub-tiles per wave, 256-query blocks */
+  MV_KNOB_ID_ATTN_FWD = 8,       /* (0) reserved for profiles/r05_two_subtile_attention_experiment.patch (two 32-query sub-tiles per wave): no effect otherwise */
+  MV_KNOB_ID_GEMM_ROUNDS = 9,    /* (1) mv_gemm chooses the ring tile height (256 / 320 rows) that minimises whole rounds of CUs; 0 = the choice of rounds 1-4 */
   MV_KNOB_ID_ATTN_ORDER = 7      /* (0) attention block order: 0 row block slowest | 1 a (sample, head)'s row blocks adjacent on one XCD
                                     (measured slower: profiles/r05_notes.txt) */
 };

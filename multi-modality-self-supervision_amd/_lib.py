@@ -83,7 +83,7 @@ ABI_VERSION = 6
 
 # knob name -> (id, default): csrc/mv_common.h / include/medvill_debug.h
 KNOBS = {"impl": (0, 0), "gemm_force": (1, 0), "gemm_nj": (2, 0), "gemm_dbg": (3, 0), "attn_planes": (4, 16), "persistent_cus": (5, 0),
-         "rowops_variant": (6, 0), "attn_order": (7, 0), "attn_fwd": (8, 0)}
+         "rowops_variant": (6, 0), "attn_order": (7, 0), "attn_fwd": (8, 0), "gemm_rounds": (9, 1)}
 
 _lib = None          # the product library
 _dbg = None          # the debug library (lazily)

@@ -6,7 +6,7 @@
 #include "../../include/medvill_debug.h"
 #endif
 
-#define MV_KNOB_DEFAULTS {0, 0, 0, 0, 16, 0, 0, 0, 0}
+#define MV_KNOB_DEFAULTS {0, 0, 0, 0, 16, 0, 0, 0, 0, 1}
 #ifdef MV_DEBUG_KNOBS
 static int g_knobs[MV_KNOB_COUNT] = MV_KNOB_DEFAULTS;
 int mv_knob(int id) { return g_knobs[id]; }

@@ -774,226 +774,6 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_mfma_kernel(AttnArgs a) {
   PROF_FLUSH(0);
 }
 
-// ---- forward, two 32-query sub-tiles per wave (round 5) -----------------------------------------------------------------------
-// The one-sub-tile kernel above spends 5,200-5,800 cycles of wall time per tile body against ~1,700 cycles of its own issue: each wave is ONE
-// dependency chain (LDS reads -> score MFMAs -> row maximum -> exponentials -> conversions -> P.V MFMAs) and a SIMD holds two or three of
-// them (profiles/r04_notes.txt).  Here a wave owns 64 queries as TWO independent 32-query chains over the same K / V tile: every K and V
-// fragment is read from LDS once and feeds both chains' MFMAs (half the LDS fragment traffic per FLOP), and while one chain is in its
-// softmax arithmetic the other's MFMAs are in the matrix pipe -- from the SAME wave, so it does not depend on what the SIMD's other wave is
-// doing.  A block is 4 waves = 256 queries (a [256, 64] context tile), half as many blocks pay the 12.6 k-cycle prologue; ~200 registers,
-// two blocks per CU, a ring of four K / V stages (64 KiB).  Same arithmetic per element as attn_fwd_mfma_kernel in the same order: results
-// are bit-identical to it (tests/test_kernels_gpu.py).
-template <bool DROP, bool F16>
-__device__ __forceinline__ void fwd2_tile(const AttnArgs& a, unsigned tk, unsigned tv, unsigned tq, f32x16 (&o)[2][2], float (&m2)[2],
-                                          float (&lsum)[2], const uint32_t* const (&myw)[2], const bool (&q_ok)[2], int k0, int Lv, int cls, bool plain,
-                                          float c2, float neg, int h, const unsigned long long* const (&mp)[2]) {
-  f32x16 st[2][2];        // [sub-tile][32-key half]
-#pragma unroll
-  for (int qi = 0; qi < 2; ++qi)
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) st[qi][kk][i] = 0.f;
-  // scores of both sub-tiles: per 16-deep slice of dh two Q fragments (from the wave's own Q image in LDS: 32 registers of Q fragments
-  // held across the loop made hipcc spill them to scratch, and every reload's vmcnt wait drained the LDS-DMA ring) and two K fragments,
-  // four MFMAs -- every K fragment is read once for both sub-tiles
-#pragma unroll
-  for (int s = 0; s < 4; ++s) {
-    const bf16x8 q0f = frag_row_x(tq, 0, s), q1f = frag_row_x(tq, 32, s);
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      const bf16x8 kf = frag_row_x(tk, 32 * kk, s);
-      st[0][kk] = mma32<F16>(kf, q0f, st[0][kk]);
-      st[1][kk] = mma32<F16>(kf, q1f, st[1][kk]);
-    }
-  }
-  // A tile that is not all-visible (class 2) or that holds the sample's ragged end gets its additive mask HERE, in place, in raw score
-  // units (neg = -10000 / scale, so that neg * scale * log2(e) is the reference's -10000 in the exponent's units; keys past the sample's
-  // end: -inf).  ONE tile body: with a body per tile class (as the one-sub-tile kernel has) the 128 accumulator registers of this kernel
-  // came out of the classes' code in different registers and hipcc paid the merge with 74 spilled registers.
-  if (!plain) {
-    const bool tail = (k0 + 64 > Lv);
-#pragma unroll
-    for (int qi = 0; qi < 2; ++qi)
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        uint32_t w = 0xffffffffu;
-        if (cls != 1) { const int wi = (k0 >> 5) + kk; w = (q_ok[qi] && wi < a.W) ? myw[qi][wi] : 0xffffffffu; }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int kr = acc_row(r, h);
-          float v = st[qi][kk][r] + (((w >> kr) & 1u) ? 0.f : neg);
-          if (tail && (k0 + 32 * kk + kr >= Lv)) v = -INFINITY;
-          st[qi][kk][r] = v;
-        }
-      }
-  }
-  float alpha[2];
-#pragma unroll
-  for (int qi = 0; qi < 2; ++qi) {
-    float mx = -INFINITY;
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[qi][kk][r]);
-    mx *= c2;
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float mn = fmaxf(m2[qi], mx);
-    alpha[qi] = fexp2(m2[qi] - mn);
-    m2[qi] = mn;
-    f32x2 ps2 = {0.f, 0.f};
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-      for (int r = 0; r < 16; r += 2) {
-        const float p0 = fexp2(fmaf(st[qi][kk][r], c2, -mn));
-        const float p1 = fexp2(fmaf(st[qi][kk][r + 1], c2, -mn));
-        st[qi][kk][r] = p0;
-        st[qi][kk][r + 1] = p1;
-        ps2 += (f32x2){p0, p1};
-      }
-    const float ps = ps2[0] + ps2[1];
-    lsum[qi] = lsum[qi] * alpha[qi] + ps;          // the normaliser sums the UNdropped probabilities
-    if (DROP) {
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        u64x8 m0, m1;
-        sload_masks16(mp[qi] + 16 * kk, m0, m1);
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {       // `ps` was computed from these values by compiler-scheduled adds: see sel_lane_after
-          st[qi][kk][r] = sel_lane_after(st[qi][kk][r], ps, m0[r]);
-          st[qi][kk][8 + r] = sel_lane_after(st[qi][kk][8 + r], ps, m1[r]);
-        }
-        __builtin_amdgcn_sched_barrier(0);      // 32 mask SGPRs live at a time: hoisting the four loads of a tile spilled ~100 SGPRs
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { o[qi][0][i] *= alpha[qi]; o[qi][1][i] *= alpha[qi]; }
-  }
-  // P.V of both sub-tiles: one V fragment read, two MFMAs
-#pragma unroll
-  for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
-      bf16x8 pf[2];
-#pragma unroll
-      for (int qi = 0; qi < 2; ++qi) pf[qi] = pack8t<F16>(st[qi][kk], s2);
-#pragma unroll
-      for (int dt = 0; dt < 2; ++dt) {
-        const bf16x8 vf = frag_tr_x(tv, dt, 32 * kk + 16 * s2);
-#pragma unroll
-        for (int qi = 0; qi < 2; ++qi) o[qi][dt] = mma32<F16>(vf, pf[qi], o[qi][dt]);
-      }
-    }
-}
-
-#define FWD2_LDS (FWD2_NS * 16384 + 4 * 8192)
-#define FWD2_NS 3      // 48 KiB of K / V stages + 32 KiB of Q images = 80 KiB of LDS per block: two blocks per CU
-template <bool F16, bool DROP>
-__global__ __launch_bounds__(256, 2) void attn_fwd2_mfma_kernel(AttnArgs a) {
-  extern __shared__ __attribute__((aligned(128))) char smem[];   // FWD2_NS stages x (K 8 KiB + V 8 KiB) | 4 waves x Q image 8 KiB
-  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  int xb, head, b;
-  att_block(a, xb, head, b);
-  const int L = a.L, H = a.H, ld = 3 * a.H, T = a.T;
-  const int qb0 = xb * 256, q0 = qb0 + wid * 64;
-  // tile classes of the block's four 64-row tiles (lane t holds key tile t), requested before the row plan like the kernel above
-  TileMasks tmk;
-  {
-    const int ta = qb0 >> 6, tw = min(q0 >> 6, T - 1);
-    uint8_t cw = 0;
-    bool any = false;
-    if (lane < T) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        if (ta + i < T) {
-          const uint8_t c = a.info[((size_t)b * T + ta + i) * T + lane];
-          any |= (c != 0);
-          if (ta + i == tw) cw = c;
-        }
-      }
-    }
-    tmk.need = __ballot(any);
-    tmk.w_nz = __ballot(cw != 0);
-    tmk.w_is1 = __ballot(cw == 1);
-  }
-  const int Lv = a.cu ? a.cu[b + 1] - a.cu[b] : L;             // positions of this sample that exist as rows
-  const int Lq = a.qlim ? min(Lv, a.qlim[b]) : Lv;             // ... and those that are queries
-  if (qb0 >= Lq) return;
-  const bool wave_on = q0 < Lq;
-  const int q[2] = {q0 + l31, q0 + 32 + l31};
-  const bool q_ok[2] = {q[0] < Lq, q[1] < Lq};
-  const size_t rowbase = a.cu ? (size_t)a.cu[b] : (size_t)b * L;
-  const size_t lrow = (size_t)b * L;                            // logical row base (mask words)
-  const dma_rsrc_t rsq = dma_rsrc(a.qkv, a.bytes_qkv);
-  // the wave's own [64 queries][64] Q image (rows past Lq zero-filled), by LDS-DMA: older than every K / V transfer of this wave, so the
-  // first counted wait of the tile loop covers it; only this wave reads it
-  char* const qimg = smem + FWD2_NS * 16384 + wid * 8192;
-  tile_dma<1>(rsq, a.bytes_qkv, rowbase, q0, Lq, ld, head * 64, qimg, 0, lane);
-
-  const float c2 = a.scale * LOG2E, neg = MASK_ADD / a.scale;
-  float m2[2] = {-INFINITY, -INFINITY}, lsum[2] = {0.f, 0.f};
-  f32x16 o[2][2];
-#pragma unroll
-  for (int qi = 0; qi < 2; ++qi)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { o[qi][0][i] = 0.f; o[qi][1][i] = 0.f; }
-
-  const int nkt = (Lv + 63) / 64;
-  int cur = next_tile(tmk.need, -1, nkt);
-  int iss = cur, issued = 0, done = 0;
-  auto issue = [&]() {
-    char* st_ = smem + (issued % FWD2_NS) * 16384;
-    tile_dma<4>(rsq, a.bytes_qkv, rowbase, iss * 64, Lv, ld, H + head * 64, st_, wid, lane);
-    tile_dma<4>(rsq, a.bytes_qkv, rowbase, iss * 64, Lv, ld, 2 * H + head * 64, st_ + 8192, wid, lane);
-    ++issued;
-    iss = next_tile(tmk.need, iss, nkt);
-  };
-#pragma unroll
-  for (int i = 0; i < FWD2_NS - 1; ++i)
-    if (iss < nkt) issue();
-  const uint32_t* const myw[2] = {a.bits + (lrow + (q_ok[0] ? q[0] : 0)) * a.W, a.bits + (lrow + (q_ok[1] ? q[1] : 0)) * a.W};
-  const FragLane fl = frag_lane(lane);            // two registers held across the loop: the lane's part of every fragment address
-  const unsigned smem_a = lds_addr(smem);
-  while (cur < nkt) {
-    att_wait_stage<4>(issued - done - 1);           // this wave's pieces of tile `cur` have landed ...
-    __builtin_amdgcn_s_barrier();                   // ... and everybody's; everybody is done reading the slot refilled next
-    __builtin_amdgcn_sched_barrier(0);
-    const unsigned tKa = smem_a + (unsigned)(done % FWD2_NS) * 16384u;
-    const int cls = !wave_on ? 0 : (((tmk.w_is1 >> cur) & 1) ? 1 : (((tmk.w_nz >> cur) & 1) ? 2 : 0));
-    if (wave_on && cls != 0) {
-      const int k0 = cur * 64;
-      // (the two lane words are made opaque per tile: hipcc otherwise hoists every derived address out of the loop and spills them)
-      unsigned rk_ = fl.rk, tr_ = fl.tr;
-      int h_ = h;
-      asm volatile("" : "+v"(rk_), "+v"(tr_), "+v"(h_));
-      const unsigned tk = tKa + rk_, tv = tKa + 8192u + tr_, tq = lds_addr(qimg) + rk_;
-      const bool plain = (cls == 1) && (k0 + 64 <= Lv);
-      const unsigned long long* db0 = DROP ? (const unsigned long long*)a.dropbits + dbits_block(a, (size_t)b * a.A + head, q0 >> 5, cur) : nullptr;
-      const unsigned long long* const mp[2] = {db0, DROP ? db0 + (size_t)a.NKT * 32 : nullptr};       // the next 32-query block of the same key tile
-      fwd2_tile<DROP, F16>(a, tk, tv, tq, o, m2, lsum, myw, q_ok, k0, Lv, cls, plain, c2, neg, h_, mp);
-    }
-    if (iss < nkt) issue();
-    cur = next_tile(tmk.need, cur, nkt);
-    ++done;
-  }
-  // epilogue: whole rows through a per-wave LDS patch (every wave is past its last tile: the K / V stages are free)
-  __builtin_amdgcn_s_barrier();
-  char* patch = smem + wid * ATT_PATCH_BYTES;
-#pragma unroll
-  for (int qi = 0; qi < 2; ++qi) {
-    const float ltot = lsum[qi] + __shfl_xor(lsum[qi], 32, 64);
-    const float inv = (DROP ? a.inv_keep : 1.0f) / ltot;
-    const int rows_ok = Lq - (q0 + 32 * qi);            // (<= 0 for a sub-tile without queries: nothing is stored)
-    store_rows_tile<F16>(patch, o[qi], inv, q_ok[qi], a.out + (rowbase + q0 + 32 * qi) * (size_t)H + head * 64, (size_t)H, rows_ok, lane);
-    if constexpr (F16) {
-      if (a.out2) store_rows_tile<false>(patch, o[qi], inv, q_ok[qi], a.out2 + (rowbase + q0 + 32 * qi) * (size_t)H + head * 64, (size_t)H, rows_ok, lane);
-    }
-    if (q_ok[qi] && h == 0) a.lse[((size_t)b * a.A + head) * L + q[qi]] = (m2[qi] + log2f(ltot)) * LN2;
-  }
-}
-
 // ---- backward: dQ ----------------------------------------------------------------------------
 // One 64-key tile of the dQ pass for a wave's 32 queries.  MASKED: the tile needs its mask words (class 2; a ragged
 // TAIL tile is always run as masked), DROP: attention dropout is on -- compile-time, so the per-element loops are
@@ -1660,23 +1440,7 @@ extern "C" int mv_attn_fwd(int dtype, const void* qkv, const uint32_t* bits, con
     if (!attr) {
       (void)hipFuncSetAttribute((const void*)attn_fwd_mfma_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, FWD_NS * 16384);
       (void)hipFuncSetAttribute((const void*)attn_fwd_mfma_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, FWD_NS * 16384);
-      (void)hipFuncSetAttribute((const void*)attn_fwd2_mfma_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, FWD2_LDS);
-      (void)hipFuncSetAttribute((const void*)attn_fwd2_mfma_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, FWD2_LDS);
-      (void)hipFuncSetAttribute((const void*)attn_fwd2_mfma_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, FWD2_LDS);
-      (void)hipFuncSetAttribute((const void*)attn_fwd2_mfma_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, FWD2_LDS);
       attr = true;
-    }
-    if (mv_knob(MV_KNOB_ATTN_FWD) == 1) {        // two 32-query sub-tiles per wave, 256-query blocks
-      const dim3 g2((L + 255) / 256, A, B);
-      if (dtype == MV_F16) {
-        if (a.drop_on) hipLaunchKernelGGL((attn_fwd2_mfma_kernel<true, true>), g2, dim3(256), FWD2_LDS, stream, a);
-        else hipLaunchKernelGGL((attn_fwd2_mfma_kernel<true, false>), g2, dim3(256), FWD2_LDS, stream, a);
-      } else {
-        if (a.drop_on) hipLaunchKernelGGL((attn_fwd2_mfma_kernel<false, true>), g2, dim3(256), FWD2_LDS, stream, a);
-        else hipLaunchKernelGGL((attn_fwd2_mfma_kernel<false, false>), g2, dim3(256), FWD2_LDS, stream, a);
-      }
-      MV_CHECK_LAUNCH();
-      return MV_OK;
     }
     if (dtype == MV_F16) hipLaunchKernelGGL(attn_fwd_mfma_kernel<true>, dim3((L + 127) / 128, A, B), dim3(256), FWD_NS * 16384, stream, a);
     else hipLaunchKernelGGL(attn_fwd_mfma_kernel<false>, dim3((L + 127) / 128, A, B), dim3(256), FWD_NS * 16384, stream, a);

@@ -34,8 +34,9 @@ enum {
   MV_KNOB_PERSISTENT_CUS = 5,  // persistent GEMM kernels launch at most n blocks (0 = one per CU)
   MV_KNOB_ROWOPS_VARIANT = 6,  // mv_layernorm_bwd kernel form
   MV_KNOB_ATTN_ORDER = 7,      // attention block -> (row block, head, sample) order: 0 row block slowest (default) | 1 a pair's row blocks adjacent on one XCD
-  MV_KNOB_ATTN_FWD = 8,        // attention forward kernel: 0 one 32-query sub-tile per wave (128-query blocks) | 1 two sub-tiles per wave (256-query blocks)
-  MV_KNOB_COUNT = 9
+  MV_KNOB_ATTN_FWD = 8,        // reserved: the two-sub-tile forward experiment (profiles/r05_two_subtile_attention_experiment.patch) selects its kernel with it
+  MV_KNOB_GEMM_ROUNDS = 9,     // 1 (default): mv_gemm picks the ring tile height (256 / 320 rows) that minimises whole rounds of CUs | 0: rounds 1-4's choice
+  MV_KNOB_COUNT = 10
 };
 __attribute__((visibility("hidden"))) int mv_knob(int id);
 #define g_mv_impl (mv_knob(MV_KNOB_IMPL))

@@ -339,11 +339,20 @@ static inline bool aligned_to(const void* p, size_t a) { return p == nullptr || 
 // hip_ops.py can size the workspace without re-deriving this from the source.
 struct GemmRoute {
   bool big;            // the 256-row ring kernels (else the 128x128 kernel)
-  int variant;         // ring variant: 14 = 256x256x64 two stages, 24 = its persistent form, 2 = 256x128
+  int variant;         // ring variant: 14 = 256x256x64 two stages, 24 = its persistent form, 2 = 256x128, 10 = 320x256 (one round)
   long long tiles;     // output tiles of the chosen kernel
   long long sk_auto;   // split-K slabs wanted at splitk = 0 with an unlimited workspace (1 = none)
 };
-static GemmRoute gemm_route(int ta, int tb, int M, int N, int K, int splitk) {
+static int gemm_n_cu() {
+  static const int n = [] {
+    int dev = 0, v = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) v = prop.multiProcessorCount;
+    return v > 0 ? v : 256;
+  }();
+  return n;
+}
+static GemmRoute gemm_route(int ta, int tb, int M, int N, int K, int splitk, bool rows256 = false) {      // rows256: the caller needs 256-row tiles (fused column sums)
   GemmRoute r;
   const int tm2 = (M + 255) / 256;
   const long long t256 = (long long)tm2 * ((N + 255) / 256), t128 = (long long)tm2 * ((N + 127) / 128);
@@ -354,15 +363,42 @@ static GemmRoute gemm_route(int ta, int tb, int M, int N, int K, int splitk) {
                                      (t128 >= 128 || (K >= 4096 && splitk != 1)));
   r.variant = 0;
   r.sk_auto = 1;
+  // WHOLE ROUNDS of tiles (round 5).  y = x.W^T and dx = dy.W with narrow outputs (768 columns: attention output projection, FFN-down and
+  // the three input gradients of a layer) over ~25,500 packed rows are 300 tiles of 256 x 256 -- 1.17 rounds of the 256 CUs, the second one
+  // 44 tiles on an idle chip -- and 1,200 tiles of 128 x 128 = 1.56 rounds of that kernel's 768 slots; as 320 x 256 tiles they are 240 tiles:
+  // ONE round with 94 % of the CUs busy.  That is wave quantisation, not kernel quality (a tile takes the same time whether 44 or 256 CUs
+  // are busy), so the tile shape is chosen per call by (whole rounds) x (time of one round of that kernel).
+  // Measured at 25,483 rows (profiles/r05_notes.txt): FFN-down 151 -> 112 us, da 156 -> 113, dx(qkv) 117 -> 87, Wo 50 -> 42, dctx 44 -> 34.
+  const bool rounds_on = mv_knob(MV_KNOB_GEMM_ROUNDS) != 0 && g_mv_gemm_force == 0 && g_mv_gemm_nj == 0;
+  if (rounds_on && !ta && !r.big && splitk <= 1 && M >= 2048 && N >= 256 && (N & 7) == 0 && (K & 7) == 0 && K >= 256) {
+    // whole rounds x the measured time of one round (any K: the three kernels' rounds scale alike): 128 x 128 tiles on 768 slots 75,
+    // 256 x 256 ring tiles on 256 CUs 85, 320 x 256 ring tiles 112 (FFN-down shape, us).  A partly filled round costs a full one.
+    const int n_cu = gemm_n_cu();
+    const long long tn = (N + 255) / 256, t320 = (long long)((M + 319) / 320) * tn;
+    const long long s128 = (long long)((M + GT_BM - 1) / GT_BM) * ((N + GT_BN - 1) / GT_BN);
+    const long long c128 = ((s128 + 3 * n_cu - 1) / (3 * n_cu)) * 75, c256 = ((t256 + n_cu - 1) / n_cu) * 85,
+                    c320 = rows256 ? (1ll << 60) : ((t320 + n_cu - 1) / n_cu) * 112;
+    if (c256 < c128 && c256 <= c320) { r.big = true; r.variant = 14; r.tiles = t256; return r; }
+    if (c320 < c128 && c320 < c256) { r.big = true; r.variant = 10; r.tiles = t320; return r; }
+  }
+  // Wide y = x.W^T outputs run several rounds of tiles; the last one is partly empty.  320-row tiles when they take strictly less
+  // (rounds x rows): the fused QKV projection at 25,483 rows is 900 tiles of 256 rows = 4 rounds (3.52 full) or 720 of 320 = 3 rounds.
+  if (rounds_on && r.big && !ta && !tb && !rows256 && splitk <= 1 && (K & 7) == 0) {
+    const int n_cu = gemm_n_cu();
+    const long long tn = (N + 255) / 256, t320 = (long long)((M + 319) / 320) * tn;
+    const long long c256 = ((t256 + n_cu - 1) / n_cu) * 8, c320 = ((t320 + n_cu - 1) / n_cu) * 10;
+    if (c320 < c256) { r.variant = 10; r.tiles = t320; return r; }
+  }
   if (r.big) {
     // 256x256 with 64-deep stages (whole 128-B lines per LDS-DMA row): best measured.  Weight gradients (split-K units, f32 partial
     // tiles) gain 5-8 % from the persistent form; y = x.W^T does not (profiles/r01_gemm_variants.txt)
-    r.variant = g_mv_gemm_nj ? g_mv_gemm_nj : (ta ? 24 : 14);        // (knob: 14, 24 or 2 = 256x128 tiles, 4 waves, two blocks per CU)
+    r.variant = g_mv_gemm_nj ? g_mv_gemm_nj : (ta ? 24 : 14);        // (knob: 14, 24, 10 = 320-row tiles or 2 = 256x128 tiles, 4 waves, two blocks per CU)
+    if (r.variant == 10 && ta) r.variant = 24;                      // the 320-row form exists for y = x.W^T and dx = dy.W
     const bool v128 = r.variant == 2;
-    r.tiles = v128 ? t128 : t256;
+    r.tiles = v128 ? t128 : (r.variant == 10 ? (long long)((M + 319) / 320) * ((N + 255) / 256) : t256);
     const long long slots = v128 ? 512 : 256;
     // enough slabs to give every CU a unit, each at least 1024 deep; at most 32
-    if (r.tiles < slots && K >= 2048) { long long sk = slots / r.tiles; if (sk > K / 1024) sk = K / 1024; if (sk > 32) sk = 32; if (sk < 1) sk = 1; r.sk_auto = sk; }
+    if (r.variant != 10 && r.tiles < slots && K >= 2048) { long long sk = slots / r.tiles; if (sk > K / 1024) sk = K / 1024; if (sk > 32) sk = 32; if (sk < 1) sk = 1; r.sk_auto = sk; }
   } else {
     r.tiles = (long long)((M + GT_BM - 1) / GT_BM) * ((N + GT_BN - 1) / GT_BN);
     if (r.tiles < 512 && K >= 2048) { long long sk = 768 / r.tiles; if (sk > K / 1024) sk = K / 1024; if (sk > 16) sk = 16; if (sk < 1) sk = 1; r.sk_auto = sk; }
@@ -454,7 +490,7 @@ extern "C" int mv_gemm(int dtype, int ta, int tb, int M, int N, int K, const voi
     if (bytesA >= 0x7fffffffULL || bytesB >= 0x7fffffffULL) return MV_E_SHAPE;
     p.bytesA = (unsigned)bytesA; p.bytesB = (unsigned)bytesB;
     // tile choice (gemm_route): a 256-row ring kernel when it fills the chip, the 128x128 kernel for small problems, dx and 768-column outputs
-    const GemmRoute route = gemm_route(ta, tb, M, N, K, splitk);
+    const GemmRoute route = gemm_route(ta, tb, M, N, K, splitk, colsum_part != nullptr);
     const bool big = route.big;
     if (big) {
       const int variant = route.variant;
@@ -479,13 +515,7 @@ extern "C" int mv_gemm(int dtype, int ta, int tb, int M, int N, int K, const voi
                            (epi == MV_EPI_NONE || epi == MV_EPI_BIAS || epi == MV_EPI_BIAS_GELU_D || ((epi == MV_EPI_MUL || epi == MV_EPI_RES) && p.r8_ok))))
         return MV_E_SHAPE;
       dim3 grid(tiles, splitk);
-      static int n_cu = 0;
-      if (n_cu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
-        if (n_cu <= 0) n_cu = 256;
-      }
+      const int n_cu = gemm_n_cu();
       // persistent kernels: at most g_mv_persistent_cus blocks when the host partitions the chip (mv_set_persistent_cus)
       const int n_blk = (g_mv_persistent_cus > 0 && g_mv_persistent_cus < n_cu) ? g_mv_persistent_cus : n_cu;
       const int rc_ring = mv_launch_ring(p, ta, tb, f16, variant, tiles, splitk, n_blk, stream);

@@ -323,7 +323,7 @@ __device__ __forceinline__ bf16x8 g2_frag(const char* tile, int base, int l15, i
 // store as sixteen 32-byte fragments per instruction (measured: ~1 TB/s).  Each wave transposes 16 rows at a time
 // through its own 4.25-KiB scratch (272-B row pitch: conflict-free both ways) so that 16 lanes cover one full output
 // row: whole 128/256-byte lines per store.  Loads run one row-group ahead of the stores (see epilogue4v).
-// Expects in scope: p, acc, scr, split, m0, n0, wm, wn, l15, lq, rrow, c4, col_on, NJ.
+// Expects in scope: p, acc, scr, split, m0, n0, wm, wn, l15, lq, rrow, c4, col_on, NJ, G2_NI (16-row groups per wave).
 // 16-bit outputs, a wave's 64 whole columns: the accumulators of one 16-row group go through the wave's LDS scratch (272-B row pitch) so that
 // a lane owns 8 consecutive columns of a row (8 lanes per row, 8 rows per pass): 16-byte stores, whole 128-byte lines per row.  NI_ = number
 // of 16-row groups per wave (8 in the 256-row kernels, 4 in the 128x128 kernel).  Expects in scope: p, acc[NI_][4], scr, m0, n0, wm, wn, l15,
@@ -383,7 +383,7 @@ __device__ __forceinline__ bf16x8 g2_frag(const char* tile, int base, int l15, i
     constexpr bool HAS_R = (E_) == MV_EPI_BIAS_RES || (E_) == MV_EPI_RES || (E_) == MV_EPI_MUL || (E_) == MV_EPI_DGELU || (E_) == MV_EPI_BIAS_RES_RELU; \
     constexpr bool WIDE_E = (E_) == MV_EPI_NONE || (E_) == MV_EPI_BIAS || (E_) == MV_EPI_BIAS_GELU_D;          \
     constexpr bool WIDE_R = (E_) == MV_EPI_MUL || (E_) == MV_EPI_RES || (E_) == MV_EPI_BIAS_RES;      /* 16-bit elementwise operand, 16-byte loads */ \
-    if (G2_WIDE_COND(NJ)) G2_EPI_WIDE(E_, 8)                                                                  \
+    if (G2_WIDE_COND(NJ)) G2_EPI_WIDE(E_, G2_NI)                                                                \
     else {                                                                                                     \
     const int ncol = n0 + wn + c4 * 4;                                                                         \
     const bool lane_fast = ((E_) >= 0) && col_on && p.vec_ok && (p.N - ncol >= 4);                             \
@@ -399,26 +399,26 @@ __device__ __forceinline__ bf16x8 g2_frag(const char* tile, int base, int l15, i
         rb[t] = (f32x4){0.f, 0.f, 0.f, 0.f};                                                                   \
         if (col_on) rb[t] = epi_load_res4<EE>(p, m0 + wm + (t >> 2) * 16 + (t & 3) * 4 + rrow, ncol);          \
       }                                                                                                        \
-      _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                          \
+      _Pragma("unroll") for (int i = 0; i < G2_NI; ++i) {                                                      \
         _Pragma("unroll") for (int j = 0; j < NJ; ++j) *(f32x4*)(scr + l15 * 272 + j * 64 + lq * 16) = acc[i][j]; \
         _Pragma("unroll") for (int rr = 0; rr < 4; ++rr) {                                                     \
           const int row = rr * 4 + rrow, mcur = m0 + wm + i * 16 + row;                                        \
           const f32x4 v = *(const f32x4*)(scr + row * 272 + c4 * 16);                                          \
           const f32x4 rc = rb[(i % G2_RG) * 4 + rr];                                                           \
-          if (i + G2_RG < 8 && col_on) rb[(i % G2_RG) * 4 + rr] = epi_load_res4<EE>(p, mcur + 16 * G2_RG, ncol); \
+          if (i + G2_RG < G2_NI && col_on) rb[(i % G2_RG) * 4 + rr] = epi_load_res4<EE>(p, mcur + 16 * G2_RG, ncol); \
           if (col_on) epilogue4v<EE>(p, mcur, ncol, v, b4, rc);                                                \
         }                                                                                                      \
       }                                                                                                        \
     } else {                                                                                                   \
       f32x4 rcur = {0.f, 0.f, 0.f, 0.f};                                                                       \
       if (lane_fast) rcur = epi_load_res4<EE>(p, m0 + wm + rrow, ncol);                                        \
-      _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                          \
+      _Pragma("unroll") for (int i = 0; i < G2_NI; ++i) {                                                      \
         _Pragma("unroll") for (int j = 0; j < NJ; ++j) *(f32x4*)(scr + l15 * 272 + j * 64 + lq * 16) = acc[i][j]; \
         _Pragma("unroll 1") for (int rr = 0; rr < 4; ++rr) {                                                   \
           const int row = rr * 4 + rrow, mcur = m0 + wm + i * 16 + row;                                        \
           const int fn = i * 4 + rr + 1;                                                                       \
           f32x4 rnext = {0.f, 0.f, 0.f, 0.f};                                                                  \
-          if (lane_fast && fn < 32) rnext = epi_load_res4<EE>(p, m0 + wm + (fn >> 2) * 16 + (fn & 3) * 4 + rrow, ncol); \
+          if (lane_fast && fn < 4 * G2_NI) rnext = epi_load_res4<EE>(p, m0 + wm + (fn >> 2) * 16 + (fn & 3) * 4 + rrow, ncol); \
           const f32x4 v = *(const f32x4*)(scr + row * 272 + c4 * 16);                                          \
           if (col_on) {                                                                                        \
             if ((E_) < 0) store_partial4(p, split, mcur, ncol, v);                                             \

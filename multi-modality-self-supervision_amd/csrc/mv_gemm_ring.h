@@ -28,21 +28,26 @@ __device__ __forceinline__ void g2_stage_mma_tr(const char* tA, const char* tB, 
   }
 }
 
-template <bool TA, bool TB, int NJ, int WN, int NSTAGE, int KS, bool F16 = false>
+// MI = 16-row accumulator groups per wave: 8 -> the 256-row tile; 10 -> a 320-row tile (2 x 160 rows per wave pair, 160 accumulator registers,
+// 72 KiB stages).  Why 320: an output of 768 columns over ~25,500 packed rows is 300 tiles of 256 x 256 = 1.17 rounds of the 256 CUs (the second
+// round runs 44 tiles on an otherwise idle chip), and 1.56 rounds of 768 slots on the 128 x 128 kernel; as 320 x 256 tiles it is 240 tiles: ONE
+// round with 94 % of the CUs busy (mv_gemm.hip: gemm_route picks the row count that makes a single round).
+template <bool TA, bool TB, int NJ, int WN, int NSTAGE, int KS, bool F16 = false, int MI = 8>
 __global__ __launch_bounds__(128 * WN, 2) void gemm_ring_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NW = 2 * WN;                      // waves per block
   constexpr int BN = WN * 16 * NJ;
   constexpr bool BP512 = BN > 128;                // pitch of a contraction-major B image
   constexpr int BKS = G2_BK * KS;                 // contraction depth of one stage (32 or 64)
-  constexpr int A_BYTES = 16384 * KS;
+  constexpr int BM = 32 * MI;                     // rows of the tile: two wave rows of 16 * MI
+  constexpr int A_BYTES = BM * 64 * KS;
   constexpr int B_BYTES = (BP512 ? 16384 : 8192) * KS;
   constexpr int STAGE = A_BYTES + B_BYTES;
   constexpr int LPS = (A_BYTES + B_BYTES) / 1024 / NW;   // LDS-DMA instructions per wave per stage
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, lq = lane >> 4;
-  const int wm = (wid / WN) * 128, wn = (wid % WN) * (16 * NJ);
+  const int wm = (wid / WN) * (16 * MI), wn = (wid % WN) * (16 * NJ);
 
   const int nwg = gridDim.x;
   int bid = blockIdx.x;
@@ -51,7 +56,7 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_ring_kernel(GemmArgs p) {
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + in;
   }
   const int tiles_n = (p.N + BN - 1) / BN;
-  const int tiles_m = (p.M + G2_BM - 1) / G2_BM;
+  const int tiles_m = (p.M + BM - 1) / BM;
   int tm, tn;
   {
     const int GM = 8;
@@ -61,7 +66,7 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_ring_kernel(GemmArgs p) {
     tm = group * GM + rem % gm;
     tn = rem / gm;
   }
-  const int m0 = tm * G2_BM, n0 = tn * BN;
+  const int m0 = tm * BM, n0 = tn * BN;
   const int split = blockIdx.y;
   const int kbeg = split * p.kchunk;
   const int kend = min(p.K, kbeg + p.kchunk);
@@ -70,9 +75,9 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_ring_kernel(GemmArgs p) {
   const dma_rsrc_t rsA = dma_rsrc(p.A, p.bytesA);
   const dma_rsrc_t rsB = dma_rsrc(p.B, p.bytesB);
 
-  f32x4 acc[8][NJ];
+  f32x4 acc[MI][NJ];
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
@@ -80,7 +85,7 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_ring_kernel(GemmArgs p) {
   do {                                                                                                      \
     char* st__ = smem + ((S_) % NSTAGE) * STAGE;                                                            \
     const int k0__ = kbeg + (S_) * BKS;                                                                     \
-    g2_issue<TA, true, A_BYTES / 1024, NW, KS>(rsA, p.bytesA, p.lda, m0, p.M, G2_BM, k0__, kend, st__, wid, lane, p.dbg); \
+    g2_issue<TA, true, A_BYTES / 1024, NW, KS>(rsA, p.bytesA, p.lda, m0, p.M, BM, k0__, kend, st__, wid, lane, p.dbg); \
     g2_issue<TB, BP512, B_BYTES / 1024, NW, KS>(rsB, p.bytesB, p.ldb, n0, p.N, BN, k0__, kend, st__ + A_BYTES, wid, lane, p.dbg); \
   } while (0)
 
@@ -109,12 +114,12 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_ring_kernel(GemmArgs p) {
     const char* tA__ = smem + ((S_) % NSTAGE) * STAGE;                                           \
     const char* tB__ = tA__ + A_BYTES;                                                           \
     _Pragma("unroll") for (int j = 0; j < NJ; ++j) FB_[j] = g2_frag<TB, BP512, KS>(tB__, wn + j * 16, l15, lq, KS_); \
-    _Pragma("unroll") for (int i = 0; i < 8; ++i) FA_[i] = g2_frag<TA, true, KS>(tA__, wm + i * 16, l15, lq, KS_);   \
+    _Pragma("unroll") for (int i = 0; i < MI; ++i) FA_[i] = g2_frag<TA, true, KS>(tA__, wm + i * 16, l15, lq, KS_);   \
   } while (0)
 #define G2_FRAGS(FA_, FB_, S_) G2_FRAGS_K(FA_, FB_, S_, 0)
 #define G2_MMA(FA_, FB_)                                                                         \
   do {                                                                                           \
-    _Pragma("unroll") for (int i = 0; i < 8; ++i)                                                \
+    _Pragma("unroll") for (int i = 0; i < MI; ++i)                                               \
     _Pragma("unroll") for (int j = 0; j < NJ; ++j)                                               \
         acc[i][j] = mma16<F16>(FB_[j], FA_[i], acc[i][j]);                                       \
   } while (0)
@@ -125,10 +130,10 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_ring_kernel(GemmArgs p) {
       __builtin_amdgcn_sched_barrier(0);
       if (do_load && s + NSTAGE - 1 < nst) G2_ISSUE(s + NSTAGE - 1);   // refills the buffer everyone finished reading
       if (!do_mma) continue;
-      if constexpr (KS == 2 && !TA && !TB) {
+      if constexpr (KS == 2 && !TA && !TB && MI == 8) {
         // all 24 fragment reads of the 64-deep stage are issued before its first MFMA: the MFMAs then wait on a
         // counted lgkmcnt that only the first reads hold up, instead of a read-wait-MFMA ping-pong per 2 fragments
-        bf16x8 fa0[8], fb0[NJ], fa1[8], fb1[NJ];
+        bf16x8 fa0[MI], fb0[NJ], fa1[MI], fb1[NJ];
         G2_FRAGS_K(fa0, fb0, s, 0);
         G2_FRAGS_K(fa1, fb1, s, 1);
         __builtin_amdgcn_sched_barrier(0);
@@ -137,7 +142,7 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_ring_kernel(GemmArgs p) {
       } else {       // (g2_stage_mma_tr spills in this kernel -- 3-4x slower, measured; the persistent form below takes it)
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-          bf16x8 fa[8], fb[NJ];
+          bf16x8 fa[MI], fb[NJ];
           G2_FRAGS_K(fa, fb, s, ks);
           G2_MMA(fa, fb);
         }
@@ -153,7 +158,7 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_ring_kernel(GemmArgs p) {
   if (p.dbg & 1) {
     float t = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
       for (int j = 0; j < NJ; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
     if (t == 123.456f) ((float*)p.C)[0] = t;     // keeps the accumulators live without storing the tile
@@ -167,6 +172,7 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_ring_kernel(GemmArgs p) {
   char* scr = smem + wid * 4608;
   const int rrow = lane >> 4, c4 = lane & 15;
   const bool col_on = (c4 * 4) < 16 * NJ;
+  constexpr int G2_NI = MI;                       // 16-row groups per wave the epilogue walks
   if (p.splitk > 1) { G2_EPI_BODY(-1) return; }
   MV_EPI_SWITCH(p.epi, G2_EPI_BODY)
 }
@@ -304,6 +310,7 @@ __global__ __launch_bounds__(128 * WN, 1) void gemm_pring_kernel(GemmArgs p, int
     char* scr = smem + ((cfs + NSTAGE - 1) % NSTAGE) * STAGE + wid * 4608;
     const int rrow = lane >> 4, c4 = lane & 15;
     const bool col_on = (c4 * 4) < 16 * NJ;
+    constexpr int G2_NI = 8;
     if (p.splitk > 1) { G2_EPI_BODY(-1) }
     else { MV_EPI_SWITCH(p.epi, G2_EPI_BODY) }
     // whole tile inside the matrix and vector stores: every one of the 32 row-group stores above was issued
@@ -328,14 +335,15 @@ __global__ __launch_bounds__(128 * WN, 1) void gemm_pring_kernel(GemmArgs p, int
     hipLaunchKernelGGL((gemm_pring_kernel<TA_, TB_, NJ_, WN_, NS_, F16_>), dim3(units < n_cu ? units : n_cu),        \
                        dim3(128 * (WN_)), shm, stream, p, units, tiles);                                             \
   } while (0)
-#define LAUNCH_RING(TA_, TB_, NJ_, WN_, NS_, KS_, F16_)                                                              \
+#define LAUNCH_RING_MI(TA_, TB_, NJ_, WN_, NS_, KS_, F16_, MI_)                                                      \
   do {                                                                                                               \
-    constexpr size_t shm = (size_t)(NS_) * (KS_) * (16384 + ((WN_) * 16 * (NJ_) > 128 ? 16384 : 8192));               \
+    constexpr size_t shm = (size_t)(NS_) * (KS_) * (2048 * (MI_) + ((WN_) * 16 * (NJ_) > 128 ? 16384 : 8192));        \
     static bool attr_set = false;                                                                                    \
     if (!attr_set) {                                                                                                 \
-      (void)hipFuncSetAttribute((const void*)gemm_ring_kernel<TA_, TB_, NJ_, WN_, NS_, KS_, F16_>,                   \
+      (void)hipFuncSetAttribute((const void*)gemm_ring_kernel<TA_, TB_, NJ_, WN_, NS_, KS_, F16_, MI_>,              \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);                               \
       attr_set = true;                                                                                               \
     }                                                                                                                \
-    hipLaunchKernelGGL((gemm_ring_kernel<TA_, TB_, NJ_, WN_, NS_, KS_, F16_>), grid, dim3(128 * (WN_)), shm, stream, p); \
+    hipLaunchKernelGGL((gemm_ring_kernel<TA_, TB_, NJ_, WN_, NS_, KS_, F16_, MI_>), grid, dim3(128 * (WN_)), shm, stream, p); \
   } while (0)
+#define LAUNCH_RING(TA_, TB_, NJ_, WN_, NS_, KS_, F16_) LAUNCH_RING_MI(TA_, TB_, NJ_, WN_, NS_, KS_, F16_, 8)

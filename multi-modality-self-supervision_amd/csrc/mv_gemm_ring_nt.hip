@@ -5,9 +5,11 @@ int mv_launch_ring_nt(const GemmArgs& p, bool f16, int variant, int tiles, int s
   dim3 grid(tiles, splitk);
   if (f16) {
     if (variant == 2) LAUNCH_RING(false, false, 4, 2, 3, 1, true);
+    else if (variant == 10) LAUNCH_RING_MI(false, false, 4, 4, 2, 2, true, 10);        // 320 x 256 tiles (one round of CUs: gemm_route)
     else LAUNCH_RING(false, false, 4, 4, 2, 2, true);
   } else {
     if (variant == 24) LAUNCH_PRING(false, false, 4, 4, 2, false);
+    else if (variant == 10) LAUNCH_RING_MI(false, false, 4, 4, 2, 2, false, 10);
     else LAUNCH_RING(false, false, 4, 4, 2, 2, false);
   }
   return MV_OK;

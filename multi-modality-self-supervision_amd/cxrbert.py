@@ -64,10 +64,20 @@ class _CXRBertFn(torch.autograd.Function):
         eng.shadow_dirty = True                 # parameters may have been stepped by an external optimizer
         eng.training = model.training           # dropout (p = 0.1 at every site of the reference) only in train mode
         eng.keep_acts = bool(model._want_grad)  # under torch.no_grad() nothing is saved for a backward
-        hidden, pooled = eng.encoder_forward(cls_tok, input_txt, attn_mask, segment, feats, pos, sep_tok)
+        from .data import MaskDesc
+        # lazy MLM logits (want_heads == 3): nothing downstream needs a row per position, so descriptor masks whose padding is invisible
+        # run on the valid rows only, like the fused training step
+        pack = want_heads == 3 and isinstance(attn_mask, MaskDesc) and eng.is16 and attn_mask.packable()
+        hidden, pooled = eng.encoder_forward(cls_tok, input_txt, attn_mask, segment, feats, pos, sep_tok, pack=pack)
         ctx.model, ctx.want_heads = model, want_heads
         if want_heads == 2:                     # ITM head only (retrieval: `self.itm(cls)` on the pooled output)
             return eng._itm_forward().clone()
+        if want_heads == 3:                     # the loss decides which rows of the MLM head are ever computed: see LazyLogits
+            model._lazy = None
+            tok = torch.zeros(1, dtype=torch.float32, device=eng.device)
+            itm = eng._itm_forward().clone()
+            ctx.mark_non_differentiable(itm)    # ITM logits for metrics; the ITM loss goes through losses.mlm_itm_loss with the MLM loss
+            return tok, itm
         if want_heads:
             mlm, itm = eng.heads_full()
             return mlm, itm
@@ -78,6 +88,15 @@ class _CXRBertFn(torch.autograd.Function):
         model = ctx.model
         eng = model.engine
         eng.zero_grad()
+        if ctx.want_heads == 3:
+            if model._lazy is None:
+                raise RuntimeError("lazy logits: backward() reached the model without a loss from medvill_amd.losses.mlm_itm_loss(mlm, itm, ...)")
+            rows, ids, aligned, mlm_on, itm_on = model._lazy
+            gv = float(g0) if g0 is not None else 0.0          # d(total) / d(loss), normally 1.0 (one host read on the drop-in path)
+            eng.heads_train(rows, ids, aligned, mlm_scale=(gv / max(int(rows.numel()), 1)) if mlm_on else 0.0,
+                            itm_scale=(gv / int(aligned.numel())) if itm_on else 0.0, compute_grad=True)
+            eng.encoder_backward()
+            return
         if ctx.want_heads == 2:
             eng.heads_full_backward(None, g0)
         elif ctx.want_heads:
@@ -122,6 +141,55 @@ class _CXRBertFn(torch.autograd.Function):
                 _CXRBertFn._backward_once(ctx, g0, g1)
         grads = tuple(eng.g[n].clone() for n in model._param_names)
         return (None,) * 9 + grads
+
+
+class LazyLogits:
+    """What CXRBERT.forward returns in place of the [B, L, V] MLM logits under `model.lazy_logits = True`.
+
+    The reference's step (train_origin.py:106-131) materialises 64 x 512 x 30,522 logits and hands them to CrossEntropyLoss(ignore_index=-100),
+    which reads the ~10 % labelled rows.  With lazy logits the encoder runs in forward(), and the MLM head runs inside
+    `medvill_amd.losses.mlm_itm_loss(mlm, itm, txt_labels, is_aligned)` -- the one-line replacement for the two CrossEntropyLoss calls -- on
+    the LABELLED rows only, fused with the loss (the fused training step's head).  `loss.backward(); optimizer.step()` work as before.
+    `.stats` (after the loss): f32[6] = [mlm_nll_sum, n_labelled, mlm_correct, itm_nll_sum, B, itm_correct] (train_origin.py:133-146's
+    counters); `.materialize()` computes the full logits after all (inspection)."""
+
+    def __init__(self, model, tok, shape):
+        self.model, self.tok, self.shape, self.stats = model, tok, tuple(shape), None
+
+    def loss(self, txt_labels, is_aligned, mlm_task=True, itm_task=True):
+        from .data import label_index
+        eng = self.model.engine
+        rows, ids = label_index(txt_labels.to(eng.device))
+        aligned = is_aligned.to(eng.device, torch.int32)
+        return _LazyLossFn.apply(self.tok, self, rows, ids, aligned, bool(mlm_task), bool(itm_task))
+
+    @torch.no_grad()
+    def materialize(self):
+        eng = self.model.engine
+        if eng.S.get("cu") is not None:
+            raise RuntimeError("the forward ran on packed rows (mask descriptors): there is no logit row per position to materialise")
+        return eng.heads_full()[0]
+
+
+class _LazyLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, tok, lazy, rows, ids, aligned, mlm_on, itm_on):
+        model = lazy.model
+        eng = model.engine
+        R, B = int(rows.numel()), int(aligned.numel())
+        stats = eng.heads_train(rows, ids, aligned, mlm_scale=1.0 / max(R, 1), itm_scale=1.0 / B, compute_grad=False)
+        lazy.stats = stats
+        model._lazy = (rows, ids, aligned, mlm_on, itm_on)       # _CXRBertFn.backward redoes the head WITH its gradient (and again per
+        loss = tok.new_zeros(())                                 # loss-scale retry): the labelled-rows head is ~2 % of a step
+        if mlm_on:
+            loss = loss + stats[0] / torch.clamp(stats[1], min=1.0)      # mean over the labelled positions (ignore_index=-100)
+        if itm_on:
+            loss = loss + stats[3] / stats[4]
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.reshape(1), None, None, None, None, None, None
 
 
 _MLM_PARAMS = ("mlm.predictions.transform.dense.weight", "mlm.predictions.transform.dense.bias",
@@ -223,7 +291,9 @@ class _HeadFn(torch.autograd.Function):
             if eng._side is not None:
                 torch.cuda.current_stream().wait_stream(eng._side)     # the decoder's / transform's parameter gradients (side stream)
             eng._dE_ev = None
-            return [unscaled(dxr)] + [eng.g[n].clone() for n in _MLM_PARAMS]
+            # (dxr is a view of a named scratch buffer of the engine: hand autograd a tensor of its own -- on the fp32 path `unscaled` is the
+            # identity, and the next head backward would overwrite what this one returned)
+            return [unscaled(dxr).clone()] + [eng.g[n].clone() for n in _MLM_PARAMS]
         outs = _scaled_retry(eng, run)
         return (None, None, outs[0].view(*g.shape[:-1], H).to(ctx.in_dtype)) + tuple(outs[1:])
 
@@ -342,6 +412,10 @@ class CXRBERT(nn.Module):
         return hidden, pooled, None
 
     def forward(self, cls_tok, input_txt, attn_mask, segment, input_img, sep_tok):
+        if getattr(self, "lazy_logits", False):
+            # (mlm, itm) like the reference, with `mlm` a LazyLogits handle for medvill_amd.losses.mlm_itm_loss (see LazyLogits)
+            tok, itm = self._run(3, cls_tok, input_txt, attn_mask, segment, input_img, sep_tok)
+            return LazyLogits(self, tok, (itm.shape[0], self.engine.S["L"], self.cfg.vocab_size)), itm
         return self._run(True, cls_tok, input_txt, attn_mask, segment, input_img, sep_tok)
 
     def _itm_module_forward(self, x):

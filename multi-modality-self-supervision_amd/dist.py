@@ -36,6 +36,84 @@ def bucket_ranges(layout, n_flat, layers):
     return r
 
 
+def _read(path):
+    try:
+        with open(path) as f:
+            return f.read().strip()
+    except OSError:
+        return None
+
+
+def gpu_numa_node(local_rank: int, root: str = "/"):
+    """NUMA node of HIP device `local_rank`, from sysfs alone (no GPU call: this runs BEFORE the HIP runtime starts).  The KFD topology
+    lists the GPU agents in HIP's enumeration order (nodes with simd_count > 0); HIP_/ROCR_VISIBLE_DEVICES index lists are applied.
+    -> (node or None, pci address or None)."""
+    import glob
+    gpus = []
+    for d in sorted(glob.glob(os.path.join(root, "sys/class/kfd/kfd/topology/nodes/*")), key=lambda x: int(os.path.basename(x))):
+        props = dict(l.split(None, 1) for l in (_read(os.path.join(d, "properties")) or "").splitlines() if " " in l)
+        if int(props.get("simd_count", "0")) > 0:
+            loc, dom = int(props.get("location_id", "0")), int(props.get("domain", "0"))
+            gpus.append(f"{dom:04x}:{(loc >> 8) & 0xff:02x}:{(loc >> 3) & 0x1f:02x}.{loc & 7:x}")
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v and all(x.strip().isdigit() for x in v.split(",")):
+            gpus = [gpus[int(x)] for x in v.split(",") if int(x) < len(gpus)]
+    if not (0 <= local_rank < len(gpus)):
+        return None, None
+    node = _read(os.path.join(root, "sys/bus/pci/devices", gpus[local_rank], "numa_node"))
+    return (int(node) if node not in (None, "") and int(node) >= 0 else None), gpus[local_rank]
+
+
+def bind_to_gpu_numa(local_rank: int, root: str = "/"):
+    """Pin this process (and the threads it starts later: the mask check workers, the DataLoader hand-over) to the CPUs of the NUMA node
+    its GPU hangs off -- on an 8-GPU MI355X host the GPUs sit on two sockets, and a rank whose host threads run on the other socket
+    pays the inter-socket hop on every launch and every pinned-memory copy.  Call before the first GPU call.  Best effort: returns a
+    description (what was done or why not) and never raises.  MV_NUMA_BIND=0 switches it off."""
+    info = {"local_rank": local_rank, "bound": False}
+    if os.environ.get("MV_NUMA_BIND", "1") == "0":
+        info["why"] = "MV_NUMA_BIND=0"
+        return info
+    try:
+        node, pci = gpu_numa_node(local_rank, root)
+        info["pci"], info["numa_node"] = pci, node
+        if node is None:
+            info["why"] = "no NUMA node recorded for this GPU (single-node host or sysfs not readable)"
+            return info
+        cpulist = _read(os.path.join(root, f"sys/devices/system/node/node{node}/cpulist"))
+        cpus = set()
+        for part in (cpulist or "").split(","):
+            if "-" in part:
+                lo, hi = part.split("-")
+                cpus.update(range(int(lo), int(hi) + 1))
+            elif part.strip():
+                cpus.add(int(part))
+        allowed = os.sched_getaffinity(0)
+        want = cpus & allowed
+        if not want:
+            info["why"] = "the node's CPUs are outside this process's affinity mask"
+            return info
+        os.sched_setaffinity(0, want)
+        info["bound"], info["cpus"] = True, len(want)
+    except Exception as e:               # never cost a run
+        info["why"] = repr(e)
+    return info
+
+
+def rank_environment(extra=None):
+    """What every rank of the job sees of the settings that decide how streams and RCCL behave -- gathered to rank 0 (bench line)."""
+    env = {k: os.environ.get(k) for k in ("GPU_MAX_HW_QUEUES", "HSA_ENABLE_IPC_MODE_LEGACY", "HIP_FORCE_DEV_KERNARG", "NCCL_DEBUG",
+                                          "HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES")}
+    env["rank"] = dist.get_rank() if dist.is_initialized() else 0
+    if extra:
+        env.update(extra)
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return [env]
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, env)
+    return out
+
+
 class GradAllReducer:
     def __init__(self, flat_g: torch.Tensor, layout, n_flat: int, layers: int, group=None, merge_layers: int = 2, stream=None):
         self.flat_g = flat_g
@@ -58,6 +136,9 @@ class GradAllReducer:
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.timing = False            # bench: record how long the compute stream waits for the exchange in finish()
         self._exposed = []
+        self._bucket_ev = []           # timing only: per step [(name, bytes, issue event, done event)]
+        self._bucket_log = []
+        self._ts_stream = None         # timing only: a stream that does nothing but wait for a bucket and record its completion
 
     def check_replicas(self, flat_p: torch.Tensor):
         """Raise unless every rank holds the same parameters (sum and sum of squares, all-reduced MIN and MAX)."""
@@ -84,7 +165,7 @@ class GradAllReducer:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t
 
-    def _launch(self, s, e, events=()):
+    def _launch(self, s, e, events=(), name=""):
         if (self.world == 1 and not self.force) or e <= s:
             return
         view = self.flat_g[s:e]
@@ -96,7 +177,19 @@ class GradAllReducer:
                 for x in events:                 # gradients produced on the engine's side stream
                     if x is not None:
                         self.stream.wait_event(x)
-                self.works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                if self.timing:
+                    t0 = torch.cuda.Event(enable_timing=True)
+                    t0.record(self.stream)       # the bucket's gradients are final here: the collective is issued now
+                w = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                self.works.append(w)
+            if self.timing:
+                if self._ts_stream is None:
+                    self._ts_stream = torch.cuda.Stream(device=self.flat_g.device)
+                with torch.cuda.stream(self._ts_stream):
+                    w.wait()                     # this stream alone waits for the bucket (neither the compute nor the side stream does)
+                    t1 = torch.cuda.Event(enable_timing=True)
+                    t1.record(self._ts_stream)
+                self._bucket_ev.append((name, (e - s) * 4, t0, t1))
         else:
             self.works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
@@ -105,7 +198,7 @@ class GradAllReducer:
         event after the bucket's weight-gradient GEMMs, or None when everything is on the current stream)."""
         if name == "heads":
             # mlm.predictions.* / pooler / itm are final; the tied E gradient is NOT (embedding scatter comes last)
-            self._launch(*self.ranges["heads"], events=(event,))
+            self._launch(*self.ranges["heads"], events=(event,), name="heads")
         elif name.startswith("layer"):
             l = int(name[5:])
             if self._pending_hi is None:
@@ -113,10 +206,10 @@ class GradAllReducer:
                 self._pending_ev = []
             self._pending_ev.append(event)
             if l % self.merge == 0 or l == 0:
-                self._launch(self.ranges[name][0], self._pending_hi, self._pending_ev)
+                self._launch(self.ranges[name][0], self._pending_hi, self._pending_ev, name=f"layers{l}..")
                 self._pending_hi = None
         elif name == "embeddings":
-            self._launch(*self.ranges["embeddings"])
+            self._launch(*self.ranges["embeddings"], name="embeddings")
 
     def finish(self):
         """Make the current stream wait for every outstanding bucket."""
@@ -129,6 +222,9 @@ class GradAllReducer:
         if timed:
             e1.record(torch.cuda.current_stream())
             self._exposed.append((e0, e1))
+            if self._bucket_ev:
+                self._bucket_log.append((self._bucket_ev, e0, e1))
+        self._bucket_ev = []
         self.works.clear()
         self._pending_hi = None
 
@@ -140,3 +236,29 @@ class GradAllReducer:
         v = [a.elapsed_time(b) for a, b in self._exposed]
         self._exposed.clear()
         return sum(v) / len(v)
+
+    def bucket_timeline(self):
+        """Per bucket, averaged over the timed steps: when its all-reduce was issued and when it completed, in ms relative to the issue
+        of the step's FIRST bucket; plus when the compute stream started / stopped waiting in finish().  Shows how much of the exchange
+        sits under the remaining backward and which bucket is the exposed tail."""
+        if not self._bucket_log:
+            return None
+        torch.cuda.synchronize()
+        acc, n = {}, 0
+        wait0 = wait1 = 0.0
+        for evs, e0, e1 in self._bucket_log:
+            base = evs[0][2]
+            for i, (name, nbytes, t0, t1) in enumerate(evs):
+                a = acc.setdefault(i, dict(bucket=name, mbytes=nbytes / 1e6, issued_at_ms=0.0, done_at_ms=0.0))
+                a["issued_at_ms"] += base.elapsed_time(t0)
+                a["done_at_ms"] += base.elapsed_time(t1)
+            wait0 += base.elapsed_time(e0)
+            wait1 += base.elapsed_time(e1)
+            n += 1
+        self._bucket_log.clear()
+        out = []
+        for i in sorted(acc):
+            a = acc[i]
+            a["issued_at_ms"], a["done_at_ms"] = a["issued_at_ms"] / n, a["done_at_ms"] / n
+            out.append(a)
+        return {"buckets": out, "compute_stream_wait_from_ms": wait0 / n, "compute_stream_wait_until_ms": wait1 / n, "steps": n}

@@ -406,8 +406,13 @@ def set_rowops_variant(v: int = 0):
     L.set_knob("rowops_variant", v)
 
 
+def set_gemm_rounds(on: int = 1):
+    """1 (default): mv_gemm picks the ring tile height that minimises whole rounds of CUs (csrc/mv_gemm.hip: gemm_route); 0: off."""
+    L.set_knob("gemm_rounds", 1 if on else 0)
+
+
 def set_attn_fwd(variant: int = 0):
-    """Attention forward kernel: 0 one 32-query sub-tile per wave, 1 two sub-tiles per wave (csrc/mv_attn.hip)."""
+    """Reserved: selects the two-sub-tile forward kernel when profiles/r05_two_subtile_attention_experiment.patch is applied."""
     L.set_knob("attn_fwd", variant)
 
 

@@ -49,6 +49,10 @@ class TrainStep:
     def exchange_exposed_ms(self):
         return self.dp.exposed_ms() if self.dp is not None else 0.0
 
+    def exchange_timeline(self):
+        """Per-bucket issue / completion times of the gradient all-reduce (dist.GradAllReducer.bucket_timeline), or None."""
+        return self.dp.bucket_timeline() if self.dp is not None else None
+
     def _prep(self, batch):
         dev = self.eng.device
         rows, ids = batch.get("label_rows"), batch.get("label_ids")

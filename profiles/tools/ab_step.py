@@ -64,6 +64,8 @@ VARIANTS = {
                ("MLM logits in the forward encoding (f16)", lambda: setattr(model.engine, "logits_16", True))],
     "tq": [("last layer's attention: every row a query", lambda: setattr(model.engine, "tail_queries", False)),
            ("consumed rows only as queries (reordered rows, qlim)", lambda: setattr(model.engine, "tail_queries", True))],
+    "rounds": [("ring tile height: rounds 1-4's choice (128x128 kernel for 768-column outputs)", lambda: mv.hip_ops.set_gemm_rounds(0)),
+               ("ring tile height chosen for whole rounds of CUs (320 x 256 tiles: one round at ~25k rows)", lambda: mv.hip_ops.set_gemm_rounds(1))],
     "order": [("attention blocks: row block slowest (rounds 3-4)", lambda: mv.hip_ops.set_attn_order(0)),
               ("attention blocks: a pair's row blocks adjacent on one XCD", lambda: mv.hip_ops.set_attn_order(1))],
     "tail": [("last layer on all rows", lambda: setattr(step, "tail_rows", False)), ("last layer on consumed rows", lambda: setattr(step, "tail_rows", True))],

@@ -163,7 +163,8 @@ def _rccl_one_rank_worker(rank, world, port, out):
             stats = ts(batch, train=True)
         ts.sync()
         torch.cuda.synchronize()
-        res.append((m.engine.flat_p.cpu(), stats.cpu(), float(ts.exchange_exposed_ms()), None if ts.dp is None else len(ts.dp.ranges)))
+        res.append((m.engine.flat_p.cpu(), stats.cpu(), float(ts.exchange_exposed_ms()), None if ts.dp is None else len(ts.dp.ranges),
+                    ts.exchange_timeline(), mv.dist.rank_environment({"numa": mv.dist.bind_to_gpu_numa(0)}) if distributed else None))
     out[0] = res
     dist.destroy_process_group()
 
@@ -176,8 +177,17 @@ def test_one_rank_rccl_group_runs_every_collective():
     mgr = mp.Manager()
     out = mgr.dict()
     mp.spawn(_rccl_one_rank_worker, args=(1, _free_port(), out), nprocs=1, join=True)
-    (p_d, s_d, exposed, nb), (p_s, s_s, _, _) = out[0]
+    (p_d, s_d, exposed, nb, timeline, env), (p_s, s_s, _, _, tl_s, _) = out[0]
     assert bool(torch.isfinite(p_d).all()) and nb is not None and nb >= 3
+    # the per-bucket timeline the bench line carries: heads first, the embeddings bucket last, every bucket completes
+    # after it was issued, and the compute stream's wait ends after the last bucket is done
+    assert tl_s is None and timeline is not None and timeline["steps"] == 3
+    names = [b_["bucket"] for b_ in timeline["buckets"]]
+    assert names[0] == "heads" and names[-1] == "embeddings" and len(names) >= 3
+    assert all(b_["done_at_ms"] >= b_["issued_at_ms"] >= 0.0 and b_["mbytes"] > 0 for b_ in timeline["buckets"])
+    assert abs(sum(b_["mbytes"] for b_ in timeline["buckets"]) - 4e-6 * p_d.numel()) < 1e-3          # the buckets tile the flat gradient
+    assert timeline["compute_stream_wait_until_ms"] >= timeline["buckets"][-1]["issued_at_ms"]
+    assert len(env) == 1 and env[0]["rank"] == 0 and env[0]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and "bound" in env[0]["numa"]
     d = (p_d - p_s).abs()
     assert float(d.max()) < 3 * 2e-3 + 1e-4 and float(d.mean()) < 5e-5
     assert float(s_d[1]) == float(s_s[1]) and exposed >= 0.0
@@ -278,3 +288,65 @@ def test_c_abi_rccl_communicator_on_two_ranks(tmp_path):
     out = mgr.dict()
     mp.spawn(_comm_abi_worker, args=(2, str(tmp_path / "uid"), out), nprocs=2, join=True)
     assert max(out[0]) < 1e-2 and max(out[1]) < 1e-2, dict(out)
+
+
+_TWO_ON_ONE = r"""
+import os, sys, time
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+sys.path.insert(0, sys.argv[3])
+import torch
+rank, path = int(sys.argv[1]), sys.argv[2]
+torch.cuda.set_device(0)                      # BOTH ranks on the one GPU of the box
+import medvill_amd as mv
+if rank == 0:
+    uid = mv.hip_ops.RcclComm.unique_id()
+    open(path + ".tmp", "wb").write(uid)
+    os.replace(path + ".tmp", path)
+else:
+    for _ in range(1200):
+        if os.path.exists(path):
+            break
+        time.sleep(0.05)
+    uid = open(path, "rb").read()
+try:
+    comm = mv.hip_ops.RcclComm(rank, 2, uid)
+except RuntimeError as e:
+    print("REFUSED", e)
+    sys.exit(0)
+t = torch.full((1024,), float(rank + 1), device="cuda:0")
+comm.allreduce_async(t)
+comm.wait()
+torch.cuda.synchronize()
+print("SUM", float(t[0]), float(t[-1]))
+comm.destroy()
+"""
+
+
+@pytest.mark.timeout(300)
+def test_c_abi_rccl_two_processes_on_the_one_gpu_enter_the_two_rank_path(tmp_path):
+    """the TWO-rank mv_comm_* path on a one-GPU box.  Two processes build a two-rank communicator on the same device.
+    RCCL either runs it (then the sum must be 1 + 2) or refuses it at init ("Duplicate GPU detected", ncclInvalidUsage) -- which the C ABI
+    must hand back as a negative MV_E_COMM_BASE - ncclResult_t status that medvill_amd raises as `ncclResult_t <n>`: either way
+    mv_comm_unique_id / mv_comm_init were entered with world = 2 and nothing hangs."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = str(tmp_path / "uid2")
+    procs = [subprocess.Popen([sys.executable, "-c", _TWO_ON_ONE, str(r), path, root], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for r in range(2)]
+    outs = []
+    for p_ in procs:
+        try:
+            o, e = p_.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            pytest.fail("a two-rank communicator on one device neither ran nor was refused within 240 s")
+        outs.append((p_.returncode, o.strip().splitlines()[-1] if o.strip() else "", e[-400:]))
+    assert all(rc == 0 for rc, _, _ in outs), outs
+    kinds = {o.split()[0] for _, o, _ in outs}
+    assert kinds in ({"SUM"}, {"REFUSED"}), outs
+    if kinds == {"SUM"}:
+        assert all(o.split()[1:] == ["3.0", "3.0"] for _, o, _ in outs), outs
+    else:
+        assert all("ncclResult_t" in o for _, o, _ in outs), outs

@@ -318,3 +318,43 @@ def test_trainer_checks_every_entry_of_every_batch_one_batch_ahead():
     assert tr2._full_check_now(True) is False and tr2._mask_batches == {True: 131, False: 3}
     with pytest.raises(ValueError):
         tr2._init_mask_policy(SimpleNamespace(verify_masks="sometimes"))
+
+
+def test_numa_binding_reads_sysfs_and_never_raises(tmp_path, monkeypatch):
+    """dist.bind_to_gpu_numa: rank -> PCI address from the KFD topology (GPU agents in enumeration order), -> NUMA node -> CPU list.
+    Driven here over a fake sysfs tree; on a host without the files it reports why and binds nothing."""
+    from medvill_amd import dist as D2
+    root = tmp_path
+    for i, (simd, loc) in enumerate([(0, 0), (0, 0), (1024, 0x0500), (1024, 0x8500)]):          # two CPU agents, two GPUs
+        d = root / "sys/class/kfd/kfd/topology/nodes" / str(i)
+        d.mkdir(parents=True)
+        (d / "properties").write_text(f"cpu_cores_count {0 if simd else 64}\nsimd_count {simd}\nlocation_id {loc}\ndomain 0\n")
+    for bdf, node in (("0000:05:00.0", 0), ("0000:85:00.0", 1)):
+        d = root / "sys/bus/pci/devices" / bdf
+        d.mkdir(parents=True)
+        (d / "numa_node").write_text(f"{node}\n")
+    allowed = sorted(os.sched_getaffinity(0))
+    half = max(1, len(allowed) // 2)
+    lists = {0: allowed[:half], 1: allowed[half:] or allowed[:1]}
+    for node, cpus in lists.items():
+        d = root / f"sys/devices/system/node/node{node}"
+        d.mkdir(parents=True)
+        (d / "cpulist").write_text(",".join(str(c) for c in cpus) + "\n")
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES", raising=False)
+    monkeypatch.delenv("ROCR_VISIBLE_DEVICES", raising=False)
+    monkeypatch.delenv("CUDA_VISIBLE_DEVICES", raising=False)
+    assert D2.gpu_numa_node(0, str(root)) == (0, "0000:05:00.0") and D2.gpu_numa_node(1, str(root)) == (1, "0000:85:00.0")
+    assert D2.gpu_numa_node(2, str(root)) == (None, None)
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "1")
+    assert D2.gpu_numa_node(0, str(root)) == (1, "0000:85:00.0")
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES")
+    try:
+        info = D2.bind_to_gpu_numa(1, str(root))
+        assert info["bound"] and info["numa_node"] == 1 and set(os.sched_getaffinity(0)) == set(lists[1])
+    finally:
+        os.sched_setaffinity(0, allowed)
+    assert D2.bind_to_gpu_numa(0, str(tmp_path / "nothing_here"))["bound"] is False          # no sysfs: says why, binds nothing
+    monkeypatch.setenv("MV_NUMA_BIND", "0")
+    assert D2.bind_to_gpu_numa(0, str(root)) == {"local_rank": 0, "bound": False, "why": "MV_NUMA_BIND=0"}
+    env = D2.rank_environment({"x": 1})
+    assert len(env) == 1 and env[0]["rank"] == 0 and env[0]["x"] == 1 and "GPU_MAX_HW_QUEUES" in env[0]

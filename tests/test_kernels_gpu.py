@@ -41,11 +41,12 @@ def dgelu(z):
 GEMM_SHAPES = [(256, 256, 256), (130, 70, 200), (1024, 768, 768), (64, 2, 768), (96, 1000, 128), (517, 264, 3072)]
 
 
-VARIANT = {"mfma": (1, 0), "mfma2s": (1, 32), "mfma256k64": (2, 14), "pring256": (2, 24), "mfma_auto": (0, 0)}   # mv_set_gemm_variant(force, nj)
+# set_gemm_variant(force, nj); "ring320" = the 320 x 256-tile form of the ring kernel (ta = 0 layouts; ta = 1 falls back to the persistent kernel)
+VARIANT = {"mfma": (1, 0), "mfma2s": (1, 32), "mfma256k64": (2, 14), "pring256": (2, 24), "mfma_auto": (0, 0), "ring320": (2, 10)}
 
 
 @pytest.mark.parametrize("impl", ["mfma", "mfma2s", "mfma256k64", "pring256", "simple_bf16", "f32", "mfma:f16", "mfma256k64:f16", "pring256:f16",
-                                  "mfma_auto:f16"])
+                                  "mfma_auto:f16", "ring320", "ring320:f16"])
 @pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 1), (1, 0)])
 @pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
 def test_gemm_layouts(impl, ta, tb, M, N, K):
@@ -84,7 +85,49 @@ def test_gemm_layouts(impl, ta, tb, M, N, K):
         ops.set_gemm_variant(0, 0)
 
 
-@pytest.mark.parametrize("impl", ["mfma", "mfma256k64", "pring256"])
+@pytest.mark.parametrize("M", [25483, 21760, 27200, 27201, 18000])
+@pytest.mark.parametrize("form", ["wo", "ffn2", "da", "dctx"])
+def test_one_round_ring_tiles_on_the_layer_shapes(M, form):
+    """Round 5: 768-column products over ~25,500 packed rows run as ONE round of 256-column ring tiles -- 256 rows per tile when
+    ceil(M/256) * 3 <= 256 CUs, else 320 (240 tiles at 25,483 rows); beyond 27,200 rows the 128 x 128 kernel as before.  The library's
+    own choice (no knob) on the production shapes and epilogues against an f64 product on sampled rows -- first / last rows of the
+    matrix, rows around every tile edge of both tile heights -- and nothing written past row M."""
+    H, I = 768, 3072
+    K = {"wo": H, "ffn2": I, "da": I, "dctx": H}[form]
+    tb = form in ("da", "dctx")
+    f16 = torch.float16
+    a = rnd((M, K), f16, 11, 0.5)
+    b = rnd((K, H) if tb else (H, K), f16, 12, 0.05)
+    r = rnd((M, H), f16, 13)
+    bias = rnd((H,), torch.float32, 14)
+    c = torch.full((M + 8, H), 7.0, dtype=f16, device=DEV)
+    if form in ("wo", "ffn2"):
+        ops.gemm(a, b, c, M=M, N=H, K=K, bias=bias, epi=EPI_BIAS_RES, r=r)          # dropout off: deterministic reference
+    elif form == "da":
+        ops.gemm(a, b, c, tb=True, M=M, N=H, K=K, epi=EPI_RES, r=r)
+    else:
+        ops.gemm(a, b, c, tb=True, M=M, N=H, K=K)
+    assert (c[M:] == 7.0).all()
+    rows = sorted({x for e in (0, 255, 256, 319, 320, 639, 640, 12799, 12800, M // 2) for x in (e, e + 1) if x < M}
+                  | {M - 1, M - 2, M - 161, (M - 1) // 320 * 320, (M - 1) // 256 * 256})
+    idx = torch.tensor(rows, device=DEV)
+    y = a[idx].double() @ (b.double() if tb else b.double().t())
+    if form in ("wo", "ffn2"):
+        y = y + bias.double() + r[idx].double()
+    elif form == "da":
+        y = y + r[idx].double()
+    assert torch.isfinite(c[:M].float()).all()
+    assert relerr(c[idx], y) < 2e-3
+    # a coarse whole-matrix check against torch's own f16 matmul (different summation order, f16 output rounding on both sides)
+    full = (a @ (b if tb else b.t())).float()
+    if form in ("wo", "ffn2"):
+        full = full + bias + r.float()
+    elif form == "da":
+        full = full + r.float()
+    assert relerr(c[:M], full.double()) < 5e-3
+
+
+@pytest.mark.parametrize("impl", ["mfma", "mfma256k64", "pring256", "ring320"])
 @pytest.mark.parametrize("epi", [EPI_MUL, EPI_RES])
 @pytest.mark.parametrize("rdt", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("tb", [False, True])
@@ -107,7 +150,7 @@ def test_gemm_elementwise_operand_16_byte_path(impl, epi, rdt, tb, M, N, K):
     assert torch.isfinite(c.float()).all() and relerr(c, ref) < 1e-2
 
 
-@pytest.mark.parametrize("impl", ["mfma", "mfma2s", "mfma256k64", "pring256", "f32"])
+@pytest.mark.parametrize("impl", ["mfma", "mfma2s", "mfma256k64", "pring256", "f32", "ring320"])
 @pytest.mark.parametrize("epi", [EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RES, EPI_DGELU, EPI_RES, EPI_BIAS_TANH, EPI_BIAS_GELU_D, EPI_MUL])
 @pytest.mark.parametrize("M,N,K,cdt", [(256, 384, 128, "bf16"), (200, 130, 72, "f32"), (128, 768, 768, "f32")])
 def test_gemm_epilogues(impl, epi, M, N, K, cdt):

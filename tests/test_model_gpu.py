@@ -115,6 +115,54 @@ def test_dropin_backward_matches_reference_gradients(golden_dir, name, dtype, rt
     print(f"{name} {dtype}: worst grad deviation {worst:.2e}")
 
 
+@pytest.mark.parametrize("dtype,rtol", [(torch.float32, 2e-4), (torch.bfloat16, 3e-2)])
+def test_lazy_logits_loss_equals_the_two_cross_entropies(golden_dir, dtype, rtol):
+    """`model.lazy_logits = True` + `medvill_amd.losses.mlm_itm_loss(mlm, itm, txt_labels, is_aligned)` in place of
+    the two CrossEntropyLoss calls of train_origin.py:120-126.  Same loss value as the reference's golden, same gradient of every parameter
+    as the literal path (full logits -> torch cross-entropy -> backward), an upstream factor is honoured, the accuracy counters of
+    train_origin.py:133-146 come out of `.stats`, and with mask DESCRIPTORS the forward runs on packed rows."""
+    z, meta, cfg, P, b = load_case(golden_dir, "c1v1k_full")
+    model = make_model(cfg, P, dtype)
+    labels, aligned = b["txt_labels"].to(DEV), b["is_aligned"].to(DEV)
+    tol = FP32_TOL if dtype == torch.float32 else BF16_TOL
+    mlm, itm = fwd(model, b)
+    ref = mv.losses.mlm_itm_loss(mlm, itm, labels, aligned)              # plain tensors: exactly the two torch cross-entropies
+    assert abs(float(ref) - float(z["mlm_loss"]) - float(z["itm_loss"])) < 2 * tol
+    ref.backward()
+    g_ref = {n: p.grad.clone() for n, p in model.named_parameters()}
+    n_correct = int(((mlm.argmax(-1) == labels) & (labels != -100)).sum())
+    gmax = max(float(g.abs().max()) for g in g_ref.values())
+    for desc in (False, True):
+        model.zero_grad()
+        model.lazy_logits = True
+        bb = dict(b)
+        if desc:
+            bb["attn_mask"] = mv.data.MaskDesc.make("full", meta["N"], meta["S"], b["n_ids"], DEV)
+        lz, itm2 = fwd(model, bb)
+        assert isinstance(lz, mv.cxrbert.LazyLogits) and lz.shape == tuple(mlm.shape) and not itm2.requires_grad
+        assert float((itm2 - itm.detach()).abs().max()) < tol
+        loss = mv.losses.mlm_itm_loss(lz, itm2, labels, aligned)
+        assert abs(float(loss) - float(ref)) < (1e-5 if dtype == torch.float32 else 5e-3)
+        assert (model.engine.S["cu"] is not None) == (desc and dtype != torch.float32)
+        st = lz.stats.cpu()
+        assert int(st[1]) == int((labels != -100).sum()) and int(st[4]) == meta["B"]
+        if dtype == torch.float32:
+            assert int(st[2]) == n_correct
+        (2.0 * loss).backward()                                         # an upstream factor reaches every gradient
+        for n, p in model.named_parameters():
+            scale = max(float(g_ref[n].abs().max()), 1e-3 * gmax)
+            assert float((p.grad - 2.0 * g_ref[n]).abs().max()) <= 2.0 * rtol * scale, (desc, n)
+        if not desc or dtype == torch.float32:
+            assert float((lz.materialize().float() - mlm.detach().float()).abs().max()) < tol
+        else:
+            with pytest.raises(RuntimeError, match="packed rows"):
+                lz.materialize()
+    model.zero_grad()
+    lz, itm2 = fwd(model, b)                                            # (still lazy)
+    with pytest.raises(RuntimeError, match="mlm_itm_loss"):
+        lz.tok.sum().backward()                                         # a backward that never went through the loss is refused
+
+
 @pytest.mark.parametrize("dtype,gop", [(torch.float32, None), (torch.bfloat16, "f16"), (torch.bfloat16, "bf16")])
 def test_fused_train_step_equals_dropin_path(golden_dir, dtype, gop):
     """TrainStep (labelled rows only, fused CE) must give the same losses and gradients as
@@ -639,7 +687,9 @@ def test_packed_rows_reproduce_the_padded_step_at_bert_base_scale(family, N, S):
     assert torch.equal(s0[[1, 2, 4, 5]], s1[[1, 2, 4, 5]]) and float((s0 - s1).abs().max() / s0.abs().max()) < 1e-5
     rel = float((g0 - g1).norm() / g0.norm())
     print(f"BERT-base {family} L={N + S + 3}: packed vs padded gradient rel L2 {rel:.2e}")
-    assert rel < 1e-3
+    # "full" also reorders the last layer's rows (consumed rows first, `tq`): that layer's softmax sums its keys in another order, which
+    # shows at the 16-bit rounding level of its outputs (measured 1.2e-3 here; the small-model test above allows the same 5x for it)
+    assert rel < (3e-3 if family == "full" else 1e-3)
 
 
 @pytest.mark.parametrize("dtype,family,layers", [(torch.float32, "bar", 2), (torch.bfloat16, "mixed", 2), (torch.bfloat16, "full", 1)])

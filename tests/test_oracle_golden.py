@@ -179,3 +179,28 @@ def test_param_count_and_flops():
     assert abs(3 * O.flops_fwd_per_sample(O.CONFIGS["base"], 512, 36) / 1e9 - 364.0760) < 1e-3
     assert abs(3 * O.flops_fwd_per_sample(O.CONFIGS["base768"], 768, 100) / 1e9 - 568.2895) < 1e-3
     assert abs(3 * O.flops_fwd_per_sample(O.CONFIGS["c1"], 64, 16) / 1e9 - 1.6954) < 1e-3
+
+
+# ------------------------------------------------------------------ region encoder
+def test_resnet_oracle_against_torchvision_fixture_when_one_exists(golden_dir):
+    """oracle/resnet_oracle.py restates torchvision's ResNet-50 trunk (models/image.py:46-53); torchvision is in neither the reference
+    tree nor this image, so the restatement is UNPINNED until tests/golden/resnet50.npz -- written by oracle/gen_resnet_golden.py
+    wherever torchvision is installed -- exists.  With the fixture: eval- and train-mode feature maps and the updated running
+    statistics against torchvision's own."""
+    path = os.path.join(golden_dir, "resnet50.npz")
+    if not os.path.exists(path):
+        pytest.skip("parity unpinned: no torchvision here and no tests/golden/resnet50.npz (python oracle/gen_resnet_golden.py where torchvision exists)")
+    import medvill_amd as mv
+    from oracle import gen_resnet_golden as G
+    from oracle import resnet_oracle as R
+    z = np.load(path)
+    enc = mv.ImageEncoder_cnn(num_image_embeds=4)
+    sd = G.fill_state({k[len("model."):]: v for k, v in enc.state_dict().items()}, seed=int(z["w_seed"]))
+    assert sorted(sd) == [str(k) for k in z["keys"]]
+    sd = {"model." + k: v.clone() for k, v in sd.items()}
+    x = G.make_input(int(z["in_seed"]))
+    assert np.abs(R.trunk(sd, x, training=False).numpy() - z["out_eval"]).max() < 1e-4 * max(1.0, np.abs(z["out_eval"]).max())
+    assert np.abs(R.trunk(sd, x, training=True).numpy() - z["out_train"]).max() < 1e-3 * max(1.0, np.abs(z["out_train"]).max())
+    for p_ in G.PROBES:
+        assert np.abs(sd[f"model.{p_}.running_mean"].numpy() - z[f"rm_{p_}"]).max() < 1e-4
+        assert np.abs(sd[f"model.{p_}.running_var"].numpy() - z[f"rv_{p_}"]).max() < 1e-4
