@@ -425,6 +425,10 @@ def main():
         # dominant kernel: the FFN-up GEMM with its fused epilogue (largest single launch of the step; its symbol, the 256x256 ring
         # kernel, and the persistent weight-gradient kernel each take ~20 % of the step's kernel time: profiles/r03_bench_kernel_stats.txt).
         # The weight-gradient GEMM is reported beside it: its call is two kernels (split-K partials + reduction), timed together.
+        if os.environ.get("MV_BENCH_NO_KERNELS") == "1":      # (profiles/tools/r05_profile_all.sh: kernel statistics of the STEP alone)
+            print(json.dumps({"metric": "image-text pairs/sec pretraining step, BERT-base seq512", "value": value, "unit": "pairs/s", "n_gpus": world,
+                              "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "note": "MV_BENCH_NO_KERNELS=1: no roofline objects"}), flush=True)
+            return
         kern = time_kernel_case("ffn1")
         kern_dw = time_kernel_case("dw")
         # ... and every other MFMA kernel family of the step, each alone on the step's shapes (profiles/tools/dominant.py): attention (one

@@ -136,9 +136,8 @@ class GradAllReducer:
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.timing = False            # bench: record how long the compute stream waits for the exchange in finish()
         self._exposed = []
-        self._bucket_ev = []           # timing only: per step [(name, bytes, issue event, done event)]
+        self._bucket_ev = []           # timing only: per step [[name, bytes, issue event, event after the compute stream's wait for it]]
         self._bucket_log = []
-        self._ts_stream = None         # timing only: a stream that does nothing but wait for a bucket and record its completion
 
     def check_replicas(self, flat_p: torch.Tensor):
         """Raise unless every rank holds the same parameters (sum and sum of squares, all-reduced MIN and MAX)."""
@@ -183,13 +182,10 @@ class GradAllReducer:
                 w = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
                 self.works.append(w)
             if self.timing:
-                if self._ts_stream is None:
-                    self._ts_stream = torch.cuda.Stream(device=self.flat_g.device)
-                with torch.cuda.stream(self._ts_stream):
-                    w.wait()                     # this stream alone waits for the bucket (neither the compute nor the side stream does)
-                    t1 = torch.cuda.Event(enable_timing=True)
-                    t1.record(self._ts_stream)
-                self._bucket_ev.append((name, (e - s) * 4, t0, t1))
+                # (the completion side is stamped in finish(), on the compute stream, as it passes each bucket's wait: a stream of its own
+                #  that waits per bucket measured the buckets directly but cost 4.6 ms per step on the one-rank rehearsal -- its event
+                #  waits shared a hardware queue with the side stream)
+                self._bucket_ev.append([name, (e - s) * 4, t0, None])
         else:
             self.works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
@@ -217,8 +213,12 @@ class GradAllReducer:
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(torch.cuda.current_stream())
-        for w in self.works:
+        for i, w in enumerate(self.works):
             w.wait()
+            if timed and i < len(self._bucket_ev):
+                t1 = torch.cuda.Event(enable_timing=True)
+                t1.record(torch.cuda.current_stream())          # the compute stream is past this bucket's wait
+                self._bucket_ev[i][3] = t1
         if timed:
             e1.record(torch.cuda.current_stream())
             self._exposed.append((e0, e1))
@@ -238,9 +238,10 @@ class GradAllReducer:
         return sum(v) / len(v)
 
     def bucket_timeline(self):
-        """Per bucket, averaged over the timed steps: when its all-reduce was issued and when it completed, in ms relative to the issue
-        of the step's FIRST bucket; plus when the compute stream started / stopped waiting in finish().  Shows how much of the exchange
-        sits under the remaining backward and which bucket is the exposed tail."""
+        """Per bucket, averaged over the timed steps: when its all-reduce was ISSUED (its gradients final, on the issuing stream) and when
+        the COMPUTE stream was past its wait for it (`done_at_ms`: an upper bound of its completion -- the compute stream only starts
+        waiting at the end of the backward, `compute_stream_wait_from_ms`), in ms relative to the issue of the step's first bucket.
+        Buckets whose done_at equals the wait's start finished under the backward; the ones after it are the exposed tail."""
         if not self._bucket_log:
             return None
         torch.cuda.synchronize()
@@ -249,6 +250,8 @@ class GradAllReducer:
         for evs, e0, e1 in self._bucket_log:
             base = evs[0][2]
             for i, (name, nbytes, t0, t1) in enumerate(evs):
+                if t1 is None:
+                    continue
                 a = acc.setdefault(i, dict(bucket=name, mbytes=nbytes / 1e6, issued_at_ms=0.0, done_at_ms=0.0))
                 a["issued_at_ms"] += base.elapsed_time(t0)
                 a["done_at_ms"] += base.elapsed_time(t1)

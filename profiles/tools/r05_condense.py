@@ -15,7 +15,7 @@ import sys
 
 raw, out = sys.argv[1], sys.argv[2]
 os.makedirs(out, exist_ok=True)
-MAIN = re.compile(r"gemm_|attn_fwd|attn_bwd|splitk_reduce")     # kernels that belong to a case's call (fills / the keep-bit generator do not)
+MAIN = re.compile(r"gemm_|attn_fwd|attn_bwd|attn_dropmask|splitk_reduce")     # kernels that belong to a case's call (torch fills do not)
 WARM = 50
 
 
@@ -126,4 +126,10 @@ for case in cases:
                 for c_, v in sorted(cs.items()):
                     f.write(f"    {c_:34s} {v:18.4f}\n" if isinstance(v, float) and v < 10 else f"    {c_:34s} {v:18.1f}\n")
 json.dump(summary, open(os.path.join(out, "r05_kernels.json"), "w"), indent=1)
+if find("bench_stats", "*kernel_stats.csv"):
+    with open(os.path.join(out, "r05_bench_kernel_stats.txt"), "w") as f:
+        f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras --no-kernel-table   (MI355X, round 5; 7 steps)\n")
+        f.write("# side-stream kernels (weight gradients, reductions, column sums, keep-bit generator, AdamW) overlap the main chain: durations are\n"
+                "# inflated by sharing the chip and their sum exceeds the wall time\n")
+        f.write(stats_table("bench_stats", top=32))
 print("wrote", sorted(os.listdir(out)))

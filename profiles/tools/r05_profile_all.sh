@@ -25,4 +25,10 @@ for c in $CASES; do
   fi
   echo "done $c $(date +%T)"
 done
+if [ -z "$1" ] || [ "$MV_BENCH_STATS" = "1" ]; then
+  rm -rf $O/bench_stats
+  export MV_BENCH_NO_KERNELS=1      # the step's kernels only (bench.py otherwise times the dominant kernels alone, 250 launches each)
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench_stats -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras --no-kernel-table > $O/bench_stats.log 2>&1
+  unset MV_BENCH_NO_KERNELS
+fi
 python3 $R/profiles/tools/r05_condense.py $O $R/gpurun_out/r5_summary

@@ -179,8 +179,8 @@ def test_one_rank_rccl_group_runs_every_collective():
     mp.spawn(_rccl_one_rank_worker, args=(1, _free_port(), out), nprocs=1, join=True)
     (p_d, s_d, exposed, nb, timeline, env), (p_s, s_s, _, _, tl_s, _) = out[0]
     assert bool(torch.isfinite(p_d).all()) and nb is not None and nb >= 3
-    # the per-bucket timeline the bench line carries: heads first, the embeddings bucket last, every bucket completes
-    # after it was issued, and the compute stream's wait ends after the last bucket is done
+    # the per-bucket timeline the bench line carries: heads first, the embeddings bucket last, the compute stream
+    # passes every bucket's wait after the bucket was issued, and its wait ends after the last bucket was issued
     assert tl_s is None and timeline is not None and timeline["steps"] == 3
     names = [b_["bucket"] for b_ in timeline["buckets"]]
     assert names[0] == "heads" and names[-1] == "embeddings" and len(names) >= 3
