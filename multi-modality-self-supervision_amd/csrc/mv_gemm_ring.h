@@ -74,7 +74,6 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_ring_kernel(GemmArgs p) {
 
   const dma_rsrc_t rsA = dma_rsrc(p.A, p.bytesA);
   const dma_rsrc_t rsB = dma_rsrc(p.B, p.bytesB);
-
   f32x4 acc[MI][NJ];
 #pragma unroll
   for (int i = 0; i < MI; ++i)

@@ -175,6 +175,12 @@ class CXRBERT_Trainer:
         self.train_data, self.test_data = train_dataloader, test_dataloader
         self.distributed = torch.distributed.is_available() and torch.distributed.is_initialized() \
             and torch.distributed.get_world_size() > 1
+        # one process per GPU: the host threads of this rank (launches, the mask-check workers, pinned-memory copies) on the CPUs of its
+        # GPU's NUMA node (best effort, sysfs only; a launcher that binds before the first GPU call, as bench.py does, is better still)
+        self.numa = None
+        if self.distributed:
+            from .dist import bind_to_gpu_numa
+            self.numa = bind_to_gpu_numa(int(os.environ.get("LOCAL_RANK", torch.cuda.current_device())))
         self.mlm_task = _str2bool(getattr(args, "mlm_task", True))
         self.itm_task = _str2bool(getattr(args, "itm_task", True))
         self.step = TrainStep(self.model, lr=getattr(args, "lr", 1e-5), distributed=self.distributed, mlm_task=self.mlm_task,
