@@ -23,7 +23,11 @@ for f in "$SRC"/*.hip; do
   fi
 done
 for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
+# the test / experiment library: the same objects with the debug build of mv_api.hip (include/medvill_debug.h); kept out of "$OUT"/*.o
+mkdir -p "$OUT/dbg"
+"$HIPCC" --offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -Wno-unused-value -DMV_DEBUG_KNOBS "${SAN[@]}" -c "$SRC/mv_api.hip" -o "$OUT/dbg/mv_api_dbg.o"
 "$HIPCC" --offload-arch=gfx950 -shared -fPIC -Xarch_host -fsanitize=address,undefined -o "$OUT/libmedvill_hip_asan.so" "$OUT"/*.o
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC -Xarch_host -fsanitize=address,undefined -o "$OUT/libmedvill_hip_asan_dbg.so" $(ls "$OUT"/*.o | grep -v '/mv_api.o$') "$OUT/dbg/mv_api_dbg.o"
 cd "$ROOT"
 # detect_leaks=0: CPython itself never frees its arenas; halt_on_error: the first report fails the run
 env LD_PRELOAD="$ASAN_RT" ASAN_OPTIONS=detect_leaks=0:halt_on_error=1:abort_on_error=1 UBSAN_OPTIONS=halt_on_error=1:print_stacktrace=1 \
