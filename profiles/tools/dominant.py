@@ -38,7 +38,7 @@ def make_case(name, dev="cuda"):
         return fn, dict(kernel=f"gemm_pring_kernel<TN, 256x256x64, f16 operands> dW1 = dz^T.a: {I}x{H} over {M} rows, 7 split-K slabs (+ splitk_reduce_kernel)",
                         symbol="gemm_pring_kernel", flop=2.0 * M * I * H, bytes=2.0 * M * (I + H) + 4.0 * I * H)
     if name == "ffn1":
-        M = ROWS_PADDED
+        M = int(os.environ.get("MV_FFN1_ROWS", ROWS_PADDED))          # (experiments: the packed row count of a step is ROWS_PACKED)
         x, w, b = _rnd((M, H), 1.0, 21, dev), _rnd((I, H), 0.02, 22, dev), _rnd((I,), 0.02, 23, dev, torch.float32)
         o, d = torch.empty((M, I), device=dev, dtype=torch.float16), torch.empty((M, I), device=dev, dtype=torch.float16)
         fn = lambda: ops.gemm(x, w, o, M=M, N=I, K=H, bias=b, epi=EPI_BIAS_GELU_D, c2=d)
