@@ -66,6 +66,22 @@ def test_product_library_exports_the_header_and_nothing_else_and_has_no_knobs():
     assert b"debug-knobs" not in _lib.load().mv_build_info()
 
 
+def test_workspace_sizing_functions_are_pure_and_match_the_split_k_choice():
+    """mv_gemm_workspace_bytes / mv_workspace_bytes: what a host that is not hip_ops.py needs to size split-K workspaces.
+    Pure host arithmetic (no kernel, no device memory): callable here."""
+    lib = _lib.load()
+    H, I, V, M = 768, 3072, 30522, 25483
+    dw1 = lib.mv_gemm_workspace_bytes(_lib.MV_F16, 1, 1, I, H, M)          # dW1 = dz^T . a: 36 tiles of 256 x 256 -> 7 slabs fill 256 CUs
+    assert dw1 == 7 * I * H * 4
+    assert lib.mv_gemm_workspace_bytes(_lib.MV_F16, 1, 1, H, H, M) == 24 * H * H * 4          # 9 tiles -> 28 slabs wanted, 24 of >= 1024 rows
+    assert lib.mv_gemm_workspace_bytes(_lib.MV_F16, 0, 0, M, I, H) == 0                       # y = x.W^T over 1,200 tiles never splits
+    assert lib.mv_gemm_workspace_bytes(_lib.MV_F32, 1, 1, I, H, M) == 0                       # f32 data: plain kernels, no split
+    assert lib.mv_gemm_workspace_bytes(_lib.MV_F16, 1, 1, 0, H, M) == 0
+    step = lib.mv_workspace_bytes(H, I, V, 2048, M, 3300, 64 * 36)
+    assert step == max(dw1, lib.mv_gemm_workspace_bytes(_lib.MV_F16, 1, 1, H, H, M), lib.mv_gemm_workspace_bytes(_lib.MV_F16, 0, 1, 3300, H, V))
+    assert lib.mv_workspace_bytes(0, I, V, 2048, M, 3300, 2304) == 0
+
+
 def test_signatures_have_no_torch_types():
     src = open(os.path.join(ROOT, "include", "medvill.h")).read()
     assert 'extern "C"' in src

@@ -358,3 +358,21 @@ def test_numa_binding_reads_sysfs_and_never_raises(tmp_path, monkeypatch):
     assert D2.bind_to_gpu_numa(0, str(root)) == {"local_rank": 0, "bound": False, "why": "MV_NUMA_BIND=0"}
     env = D2.rank_environment({"x": 1})
     assert len(env) == 1 and env[0]["rank"] == 0 and env[0]["x"] == 1 and "GPU_MAX_HW_QUEUES" in env[0]
+
+
+def test_mlm_itm_loss_on_plain_tensors_is_the_two_cross_entropies():
+    """medvill_amd.losses.mlm_itm_loss with ordinary logits: exactly train_origin.py:120-126 (CrossEntropyLoss(ignore_index=-100) on the
+    transposed MLM logits + CrossEntropyLoss() on the ITM logits; a task switched off contributes nothing)."""
+    g = torch.Generator().manual_seed(4)
+    mlm, itm = torch.randn(3, 7, 19, generator=g, requires_grad=True), torch.randn(3, 2, generator=g, requires_grad=True)
+    labels = torch.full((3, 7), -100)
+    labels[0, 2], labels[1, 5], labels[2, 0] = 4, 18, 0
+    aligned = torch.tensor([1, 0, 1])
+    ce_m, ce_i = torch.nn.CrossEntropyLoss(ignore_index=-100), torch.nn.CrossEntropyLoss()
+    want = ce_i(itm, aligned) + ce_m(mlm.transpose(1, 2), labels)
+    got = mv.losses.mlm_itm_loss(mlm, itm, labels, aligned)
+    assert torch.allclose(got, want, atol=1e-6)
+    got.backward()
+    assert mlm.grad is not None and float(mlm.grad[0, 0].abs().sum()) == 0.0 and float(mlm.grad[0, 2].abs().sum()) > 0
+    assert torch.allclose(mv.losses.mlm_itm_loss(mlm, itm, labels, aligned, mlm_task=False), ce_i(itm, aligned), atol=1e-6)
+    assert torch.allclose(mv.losses.mlm_itm_loss(mlm, itm, labels, aligned, itm_task=False), ce_m(mlm.transpose(1, 2), labels), atol=1e-6)
