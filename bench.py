@@ -197,6 +197,7 @@ def _drop_in_user_timings(mv, model, step, cfg, dev, B, N, S, n, out, time, Simp
     def one(t):
         mlm, itm = model(b16["cls_tok"], b16["input_txt"], b16["attn_mask"], b16["segment"], (b16["img_feats"], b16["img_pos"]), b16["sep_tok"])
         loss = ce_m(mlm.transpose(1, 2), b16["txt_labels"]) + ce_i(itm, b16["is_aligned"])
+        model.zero_grad()                           # optim.zero_grad() of train_origin.py:129
         loss.backward()
         eng.adamw_step(t, lr=1e-5)
     step.sync()
@@ -215,7 +216,9 @@ def _drop_in_user_timings(mv, model, step, cfg, dev, B, N, S, n, out, time, Simp
 
         def one_lazy(t):
             mlm, itm = model(bl["cls_tok"], bl["input_txt"], bl["attn_mask"], bl["segment"], (bl["img_feats"], bl["img_pos"]), bl["sep_tok"])
-            mv.losses.mlm_itm_loss(mlm, itm, bl["txt_labels"], bl["is_aligned"]).backward()
+            loss = mv.losses.mlm_itm_loss(mlm, itm, bl["txt_labels"], bl["is_aligned"])
+            model.zero_grad()                       # optim.zero_grad() of train_origin.py:129
+            loss.backward()
             eng.adamw_step(t, lr=1e-5)
         one_lazy(1)
         torch.cuda.synchronize()

@@ -61,7 +61,9 @@ class _CXRBertFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, want_heads, cls_tok, input_txt, attn_mask, segment, feats, pos, sep_tok, *params):
         eng = model.engine
-        eng.shadow_dirty = True                 # parameters may have been stepped by an external optimizer
+        # parameters may have been stepped by an external optimizer: the 16-bit copies are refreshed on every forward (unless _run has just
+        # done so, ahead of the mask recognition's read-back)
+        eng.shadow_dirty = not model.__dict__.pop("_shadow_fresh", False)
         eng.training = model.training           # dropout (p = 0.1 at every site of the reference) only in train mode
         eng.keep_acts = bool(model._want_grad)  # under torch.no_grad() nothing is saved for a backward
         from .data import MaskDesc
@@ -125,6 +127,9 @@ class _CXRBertFn(torch.autograd.Function):
     def backward(ctx, g0, g1=None):
         model = ctx.model
         eng = model.engine
+        # gradients a previous backward left in the flat buffer THROUGH the .grad views (no zero_grad in between, or
+        # zero_grad(set_to_none=False)): keep them, this backward adds to them like autograd would
+        held = eng.flat_g.clone() if (model.grad_views and eng.flat_g is not None and _holds_views(model)) else None
         _CXRBertFn._backward_once(ctx, g0, g1)
         if eng.scaler is not None:
             # f16 gradient operands under a loss scale: this path hands gradients to torch (an external optimizer), so an
@@ -139,8 +144,48 @@ class _CXRBertFn(torch.autograd.Function):
                 s_new = max(float(eng.scaler[0]) / 16.0, 1.0)
                 eng.reset_scaler(s_new)
                 _CXRBertFn._backward_once(ctx, g0, g1)
-        grads = tuple(eng.g[n].clone() for n in model._param_names)
-        return (None,) * 9 + grads
+        if held is not None:
+            eng.flat_g.add_(held)
+        return (None,) * 9 + _hand_over_grads(model)
+
+
+def _holds_views(model):
+    eg = model.engine.g
+    for n, p in zip(model._param_names, model._plist):
+        g = p.grad
+        if g is not None and g.data_ptr() == eg[n].data_ptr():
+            return True
+    return False
+
+
+def _own_grads(model):
+    """Every .grad that is a view of the flat gradient buffer becomes a tensor of its own."""
+    eg = model.engine.g
+    for n, p in zip(model._param_names, model._plist):
+        if p.grad is not None and p.grad.data_ptr() == eg[n].data_ptr():
+            p.grad = p.grad.clone()
+
+
+def _hand_over_grads(model):
+    """The engine's gradients -> torch, for `loss.backward(); optimizer.step()` (train_origin.py:129-131).
+    model.grad_views (default): every Parameter whose .grad is None -- the state `optimizer.zero_grad()` leaves -- gets the matching VIEW of
+    the flat gradient buffer as its .grad and autograd receives None for it: no 440 MB copy + 200 accumulations per step (4-5 ms of host-bound
+    launches at BERT-base).  Like DistributedDataParallel(gradient_as_bucket_view=True) the views are rewritten by the next backward, so a
+    caller that keeps a .grad across steps must clone it.  A .grad that still IS the view (accumulation over several backward calls,
+    zero_grad(set_to_none=False)) already holds old + new (see `held` in backward); any other tensor found in .grad takes the copying path
+    (autograd adds a clone to it)."""
+    eng = model.engine
+    if not model.grad_views:
+        return tuple(eng.g[n].clone() for n in model._param_names)
+    out = []
+    for n, p in zip(model._param_names, model._plist):
+        g = eng.g[n]
+        if p.grad is None or p.grad.data_ptr() == g.data_ptr():
+            p.grad = g
+            out.append(None)
+        else:
+            out.append(g.clone())
+    return tuple(out)
 
 
 class LazyLogits:
@@ -160,6 +205,13 @@ class LazyLogits:
         from .data import label_index
         eng = self.model.engine
         rows, ids = label_index(txt_labels.to(eng.device))
+        if eng.S.get("inv") is not None and rows.numel() > 0:
+            # the forward ran on the valid rows only (mask descriptors): a label past a sample's text [SEP] has no row.  The reference
+            # Dataset never produces one (dataset_origin.py:105-135 pads the labels with -100); the device is idle here anyway
+            # (label_index has just read the row count back)
+            if bool((eng.S["inv"].index_select(0, rows.to(torch.int64)) < 0).any()):
+                raise ValueError("txt_labels holds a label at a padded position (after the text [SEP]); the lazy forward ran on the "
+                                 "valid rows only.  Set model.recognise_masks = False (and pass the mask matrix) to run every row")
         aligned = is_aligned.to(eng.device, torch.int32)
         return _LazyLossFn.apply(self.tok, self, rows, ids, aligned, bool(mlm_task), bool(itm_task))
 
@@ -279,6 +331,8 @@ class _HeadFn(torch.autograd.Function):
             return None, None, dx.view(*g.shape[:-1], H).to(ctx.in_dtype), gW, gb
 
         Vp = (V + 7) // 8 * 8
+        if model.grad_views:
+            _own_grads(model)        # this backward uses ranges of the flat gradient buffer as scratch: a .grad must not be a view of them
 
         def run():
             eng.S["hm_"] = ctx.hs
@@ -324,6 +378,10 @@ class CXRBERT(nn.Module):
             img_encoder = ImageEncoder_cnn(self.args, dtype=dtype).to(dev)
         self.img_encoder = img_encoder
         self._param_names = list(self.engine.layout.keys())
+        # drop-in switches: lazy MLM logits; recognition of the Dataset's materialised masks on the lazy path; gradients
+        # handed to torch as views of the flat gradient buffer instead of copies (see _CXRBertFn.backward)
+        self.lazy_logits, self.recognise_masks, self.grad_views = False, True, True
+        self.n_masks_seen = self.n_masks_recognised = 0
         self._register()
         self.reset_parameters()
 
@@ -338,6 +396,9 @@ class CXRBERT(nn.Module):
                 mod = mod._modules[p_]
             par = nn.Parameter(self.engine.p[name], requires_grad=True)
             mod._parameters[parts[-1]] = par
+        # the Parameter objects in layout order (the same objects for the model's lifetime: _rebind only re-points their .data).  Looking
+        # 200 names up with get_parameter costs ~1 ms of host time per use, and the drop-in step does it with the device idle
+        self._plist = [self.get_parameter(n) for n in self._param_names]
         self.enc.forward = self._enc_forward
         # the heads are callable on their own like the reference's sub-modules (cxrbert_origin.py:147-148, retrieval.py:31)
         self.itm.forward = self._itm_module_forward
@@ -399,11 +460,43 @@ class CXRBERT(nn.Module):
         raise TypeError("input_img must be (region_feats[B,N,2048], region_pos[B,N]); for pixels construct the model with "
                         "img_encoder='resnet50' (medvill_amd.image.ImageEncoder_cnn) or pass your own callable")
 
+    def _mask_descriptors(self, mask, input_txt, N):
+        """A materialised reference mask on the device -> MaskDesc when it IS one of the closed-form families, entry by entry: the
+        hypothesis of data.descriptors_from_dense is confirmed by comparing the mask words the kernels would run on (mv_mask_pack of
+        the matrix against mv_mask_build of the descriptors) before it is used.  One read of the matrix, one small copy to the host
+        (descriptors + verdict: the row plan needs the lengths there).  None: keep the matrix."""
+        from .data import MaskDesc, descriptors_from_dense
+        from . import hip_ops as ops
+        hyp = descriptors_from_dense(mask, input_txt, N)
+        if hyp is None:
+            return None
+        desc, ok = hyp
+        eng = self.engine
+        B, Lq = mask.shape[0], mask.shape[-1]
+        W32, Tt = (Lq + 31) // 32, (Lq + 63) // 64
+        words = [eng._buf(f"rec_bits{i}", (B, Lq, W32), torch.int32) for i in range(2)]
+        tiles = [eng._buf(f"rec_tinfo{i}", (B, Tt, Tt), torch.uint8) for i in range(2)]
+        ops.mask_pack(mask, words[0], tiles[0])
+        ops.mask_build(desc, B, Lq, words[1], tiles[1])
+        same = ok & (words[0] == words[1]).all()
+        host = torch.cat([desc.reshape(-1), same.to(torch.int32).view(1)]).cpu()
+        self.n_masks_seen += 1
+        if int(host[-1]) != 1:
+            return None
+        self.n_masks_recognised += 1
+        return MaskDesc(desc, Lq, host=host[:-1].view(B, 3).clone())
+
     def _run(self, want_heads, cls_tok, input_txt, attn_mask, segment, input_img, sep_tok):
         if attn_mask.dim() not in (2, 3):
             raise NotImplementedError            # cxrbert_origin.py:80-81
         feats, pos = self._regions(input_img)
-        params = [self.get_parameter(n) for n in self._param_names]
+        if want_heads == 3 and self.recognise_masks and torch.is_tensor(attn_mask) and attn_mask.is_cuda and self.engine.is16:
+            # lazy logits: nothing downstream needs a row per position, so a batch whose masks are the Dataset's closed forms runs on
+            # its valid rows (packed), like the fused training step does for the trainer
+            self.engine.sync_shadow()            # (enqueued first: the device converts the weights while the host waits for the verdict)
+            self.__dict__["_shadow_fresh"] = True
+            attn_mask = self._mask_descriptors(attn_mask, input_txt, int(feats.shape[1])) or attn_mask
+        params = self._plist
         self._want_grad = torch.is_grad_enabled()        # (grad mode is always off inside autograd.Function.forward)
         return _CXRBertFn.apply(self, want_heads, cls_tok, input_txt, attn_mask, segment, feats, pos, sep_tok, *params)
 

@@ -62,6 +62,49 @@ class MaskDesc:
         return MaskDesc(self.desc.to(device), self.L, self._host)
 
 
+def descriptors_from_dense(mask: torch.Tensor, input_ids: torch.Tensor, N: int):
+    """HYPOTHESIS {family, n2, vl} per sample for a materialised reference mask (dataset_origin.py:138-176), from two rows and a column
+    per sample -- the torch restatement, on whatever device the tensors live on, of the trainer's host recogniser
+    (CXRBERT_Trainer._recognise_masks: same probes, same precedence).  Nothing is read back: -> (desc int32 [B,3], ok bool []) with
+    `ok` false when some sample matches no family; the caller confirms the hypothesis entry by entry (CXRBERT._mask_descriptors compares
+    the mask words of mv_mask_pack(mask) and mv_mask_build(desc)) before anything runs on it.  None when the shapes rule it out."""
+    if not torch.is_tensor(mask) or mask.dtype != torch.int64 or mask.dim() not in (2, 3):
+        return None
+    B, L = mask.shape[0], mask.shape[-1]
+    S, n2 = L - N - 3, N + 2
+    if S < 1 or tuple(input_ids.shape) != (B, S + 1):
+        return None
+    dev = mask.device
+    ids = input_ids.to(dev)
+    T = S + 1
+    t = torch.arange(T, device=dev).view(1, T)
+    # valid length from the LAST non-zero id (random_word, dataset_origin.py:183-209, may put id 0 at a labelled in-text position)
+    last = torch.where(ids != 0, t, torch.full_like(t, -1)).max(dim=1).values
+    vl = n2 + last + 1
+    j = torch.arange(L, device=dev).view(1, L)
+    full_row = (j < vl.view(B, 1)).to(torch.int64)
+    if mask.dim() == 2:
+        fam = torch.full((B,), FAMILY_ID["1d"], dtype=torch.int64, device=dev)
+        ok = (mask == full_row).all()
+    else:
+        r0, rl, cl = mask[:, 0, :], mask[:, L - 1, :], mask[:, :, L - 1]
+        img_row, txt_row = (j < n2).to(torch.int64), (j >= n2).to(torch.int64)
+        bar_col = ((j < n2) | (j == L - 1)).to(torch.int64)
+        eq = lambda a, b: (a == b).all(dim=1)
+        one = lambda a: (a == 1).all(dim=1)
+        # (the last column tells a full-length BAR sample -- whose probe ROWS are all ones too -- from a full one)
+        is_full = eq(r0, full_row) & eq(rl, full_row) & eq(cl, full_row[:, L - 1:L].expand(B, L))
+        is_s2s = eq(r0, img_row) & one(rl)
+        is_bar = one(r0) & one(rl) & eq(cl, bar_col)
+        is_non = eq(r0, img_row) & eq(rl, txt_row)
+        fam = torch.full((B,), -1, dtype=torch.int64, device=dev)
+        for cond, name in ((is_non, "noncross"), (is_bar, "bar"), (is_s2s, "s2s"), (is_full, "full")):     # later entries win
+            fam = torch.where(cond, torch.full_like(fam, FAMILY_ID[name]), fam)
+        ok = (fam >= 0).all()
+    desc = torch.stack([fam.clamp(min=0), torch.full_like(fam, n2), vl], dim=1).to(torch.int32)
+    return desc, ok
+
+
 def build_mask(family: str, N: int, S: int, n_ids, device="cpu") -> torch.Tensor:
     """int64 [B,L,L] (or [B,L] for '1d') for per-sample text lengths n_ids (incl. the text [SEP])."""
     n_ids = torch.as_tensor(n_ids, device=device, dtype=torch.int64).view(-1)

@@ -265,7 +265,8 @@ class CXRBERT_Trainer:
             bar_col = np.broadcast_to(((j < n2) | (j == L - 1)).astype(np.int64), (B, L))
             eq = lambda a_, b_: (a_ == b_).all(1)
             one = lambda a_: (a_ == 1).all(1)
-            is_full = eq(r0, full_row) & eq(rl, full_row)
+            # (the last column tells a full-length BAR sample -- whose probe ROWS are all ones too -- from a full one)
+            is_full = eq(r0, full_row) & eq(rl, full_row) & eq(cl, np.broadcast_to(full_row[:, L - 1:L], (B, L)))
             is_s2s = eq(r0, img_row) & one(rl)
             is_bar = one(r0) & one(rl) & eq(cl, bar_col)
             is_non = eq(r0, img_row) & eq(rl, txt_row)

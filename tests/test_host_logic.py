@@ -376,3 +376,40 @@ def test_mlm_itm_loss_on_plain_tensors_is_the_two_cross_entropies():
     assert mlm.grad is not None and float(mlm.grad[0, 0].abs().sum()) == 0.0 and float(mlm.grad[0, 2].abs().sum()) > 0
     assert torch.allclose(mv.losses.mlm_itm_loss(mlm, itm, labels, aligned, mlm_task=False), ce_i(itm, aligned), atol=1e-6)
     assert torch.allclose(mv.losses.mlm_itm_loss(mlm, itm, labels, aligned, itm_task=False), ce_m(mlm.transpose(1, 2), labels), atol=1e-6)
+
+
+def test_torch_mask_recogniser_agrees_with_the_trainers_host_recogniser():
+    """data.descriptors_from_dense (torch, any device: the model API's recogniser for a `.to(device)`-ed mask, cxrbert.CXRBERT._mask_descriptors)
+    states the same hypothesis as CXRBERT_Trainer._recognise_masks (numpy, host) -- on the reference Dataset's own matrices
+    (tests/golden/masks.npz), on mixed batches at the benchmark geometry, and on matrices outside the families."""
+    from types import SimpleNamespace
+    from medvill_amd.trainer import CXRBERT_Trainer
+    tr = object.__new__(CXRBERT_Trainer)
+    tr.args = SimpleNamespace()
+    tr._init_mask_policy(tr.args)
+    z, cases = _golden_mask_cases()
+    for c in cases:
+        N, S = c["N"], c["S"]
+        L = N + S + 3
+        m = torch.from_numpy(np.ascontiguousarray(_unpack_bits(z[f"bits_{c['tag']}"], L).astype(np.int64)[None]))
+        ids = torch.zeros((1, S + 1), dtype=torch.int64)
+        ids[0, :c["n_ids"]] = 7                                  # n_ids counts the text [SEP]
+        got = mv.data.descriptors_from_dense(m, ids, N)
+        want = mv.data.MaskDesc.make(c["family"], N, S, [c["n_ids"]]).host_desc()
+        assert got is not None and bool(got[1]) and torch.equal(got[0], want), c
+        host = tr._recognise_masks(m, ids, N)
+        assert host is not None and torch.equal(host.host_desc(), got[0]), c
+    B, N, S = 64, 36, 473
+    for fam in ("mixed", "full", "s2s", "bar", "noncross", "1d"):
+        b = mv.data.synthetic_batch(30522, B, N, S, fam, seed=11, device="cpu")
+        desc, ok = mv.data.descriptors_from_dense(b["attn_mask"], b["input_txt"], N)
+        assert bool(ok) and torch.equal(desc, b["attn_desc"].host_desc()), fam
+    b = mv.data.synthetic_batch(30522, 4, N, S, "full", seed=12, device="cpu")
+    odd = b["attn_mask"].clone()
+    odd[2, 0, 5] = 0                                             # a probe row that fits no family: no hypothesis for the batch
+    assert not bool(mv.data.descriptors_from_dense(odd, b["input_txt"], N)[1]) and tr._recognise_masks(odd, b["input_txt"], N) is None
+    inner = b["attn_mask"].clone()
+    inner[1, 300, 200] ^= 1                                      # off the probes: still a hypothesis -- the every-entry check is what rejects it
+    assert bool(mv.data.descriptors_from_dense(inner, b["input_txt"], N)[1])
+    assert mv.data.descriptors_from_dense(b["attn_mask"], b["input_txt"][:, :-1], N) is None          # shapes rule it out
+    assert mv.data.descriptors_from_dense(b["attn_mask"].to(torch.int32), b["input_txt"], N) is None

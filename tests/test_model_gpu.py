@@ -132,13 +132,18 @@ def test_lazy_logits_loss_equals_the_two_cross_entropies(golden_dir, dtype, rtol
     g_ref = {n: p.grad.clone() for n, p in model.named_parameters()}
     n_correct = int(((mlm.argmax(-1) == labels) & (labels != -100)).sum())
     gmax = max(float(g.abs().max()) for g in g_ref.values())
-    for desc in (False, True):
+    for how in ("matrix", "descriptors", "recognised"):
+        # "recognised": the Dataset's matrix as the reference loop passes it (.to(device)); the lazy forward proves it equal to a closed
+        # form on the device and runs on descriptors (16-bit path: packed rows)
+        desc = how != "matrix"
         model.zero_grad()
-        model.lazy_logits = True
+        model.lazy_logits, model.recognise_masks = True, how == "recognised"
         bb = dict(b)
-        if desc:
+        if how == "descriptors":
             bb["attn_mask"] = mv.data.MaskDesc.make("full", meta["N"], meta["S"], b["n_ids"], DEV)
         lz, itm2 = fwd(model, bb)
+        if how == "recognised":
+            assert (model.n_masks_seen, model.n_masks_recognised) == ((1, 1) if dtype != torch.float32 else (0, 0))
         assert isinstance(lz, mv.cxrbert.LazyLogits) and lz.shape == tuple(mlm.shape) and not itm2.requires_grad
         assert float((itm2 - itm.detach()).abs().max()) < tol
         loss = mv.losses.mlm_itm_loss(lz, itm2, labels, aligned)
@@ -158,9 +163,104 @@ def test_lazy_logits_loss_equals_the_two_cross_entropies(golden_dir, dtype, rtol
             with pytest.raises(RuntimeError, match="packed rows"):
                 lz.materialize()
     model.zero_grad()
+    model.recognise_masks = True
     lz, itm2 = fwd(model, b)                                            # (still lazy)
     with pytest.raises(RuntimeError, match="mlm_itm_loss"):
         lz.tok.sum().backward()                                         # a backward that never went through the loss is refused
+
+
+def test_lazy_forward_proves_a_device_matrix_before_it_runs_on_descriptors(golden_dir):
+    """The reference loop hands the model the Dataset's [B, L, L] matrix after `.to(device)` (train_origin.py:95-104).  Under lazy logits the
+    model derives {family, n2, vl} on the device and runs on them ONLY when the matrix equals the closed form in every entry (mask words of
+    mv_mask_pack against mv_mask_build): a recognised batch reproduces the descriptor run; one flipped entry off the probe lines
+    keeps the matrix (and reproduces the un-recognising run); a label at a padded position is refused."""
+    z, meta, cfg, P, b = load_case(golden_dir, "c1v1k_full")
+    model = make_model(cfg, P, torch.bfloat16)
+    model.lazy_logits = True
+    labels, aligned = b["txt_labels"].to(DEV), b["is_aligned"].to(DEV)
+    dense = b["attn_mask"].to(DEV)
+
+    def run(mask, recognise=True, lab=labels):
+        model.zero_grad()
+        model.recognise_masks = recognise
+        bb = dict(b)
+        bb["attn_mask"] = mask
+        lz, itm = fwd(model, bb)
+        packed = model.engine.S["cu"] is not None
+        loss = mv.losses.mlm_itm_loss(lz, itm, lab, aligned)
+        loss.backward()
+        return packed, float(loss), model.engine.flat_g.clone()
+    p0, l0, g0 = run(mv.data.MaskDesc.make("full", meta["N"], meta["S"], b["n_ids"], DEV))
+    p1, l1, g1 = run(dense)
+    same = lambda a_, b_: float((a_ - b_).norm() / b_.norm()) < 1e-5         # (atomic sums: not bit-reproducible from run to run)
+    assert p0 and p1 and abs(l0 - l1) < 1e-5 and same(g0, g1) and (model.n_masks_seen, model.n_masks_recognised) == (1, 1)
+    p2, l2, g2 = run(dense, recognise=False)
+    assert not p2 and abs(l2 - l1) < 5e-3 and float((g2 - g1).norm() / g2.norm()) < 2e-2 and model.n_masks_seen == 1
+    bad = dense.clone()
+    L = dense.shape[-1]
+    bad[1, L // 2, 3] ^= 1                           # neither probe row (0, L-1) nor the probe column (L-1)
+    p3, l3, g3 = run(bad)
+    p4, l4, g4 = run(bad, recognise=False)
+    assert not p3 and not p4 and abs(l3 - l4) < 1e-5 and same(g3, g4) and (model.n_masks_seen, model.n_masks_recognised) == (2, 1)
+    n_ids = [int(v) for v in b["n_ids"]]
+    short = min(range(len(n_ids)), key=lambda i: n_ids[i])
+    if n_ids[short] < meta["S"] + 1:
+        lab2 = labels.clone()
+        lab2[short, L - 1] = 5                       # a label on a padded row: exists only when every row runs
+        with pytest.raises(ValueError, match="padded position"):
+            run(dense, lab=lab2)
+        assert run(dense, recognise=False, lab=lab2)[0] is False
+    model.zero_grad()
+
+
+def test_drop_in_gradients_are_views_of_the_flat_buffer_with_autograds_semantics(golden_dir):
+    """loss.backward() on the model API (train_origin.py:129-131): with .grad = None (after optimizer.zero_grad()) every Parameter's .grad
+    becomes a VIEW of the engine's flat gradient buffer (no copy, nothing for autograd to accumulate); a second backward without zero_grad
+    adds to it like autograd does; a foreign tensor in .grad is accumulated into, not replaced; grad_views = False restores the copies;
+    torch optimizers step on the views."""
+    z, meta, cfg, P, b = load_case(golden_dir, "c1v1k_full")
+    model = make_model(cfg, P, torch.float32)
+    labels, aligned = b["txt_labels"].to(DEV), b["is_aligned"].to(DEV)
+    eng = model.engine
+
+    def backward(scale=1.0):
+        mlm, itm = fwd(model, b)
+        (scale * mv.losses.mlm_itm_loss(mlm, itm, labels, aligned)).backward()
+
+    def close(a, w):          # (sums over rows may be taken in a different order from one run to the next)
+        return float((a - w).abs().max()) <= 1e-5 * max(float(w.abs().max()), 1e-6)
+    model.grad_views = False
+    backward()
+    ref = {n: p.grad.clone() for n, p in model.named_parameters()}
+    assert all(p.grad.data_ptr() != eng.g[n].data_ptr() for n, p in model.named_parameters())
+    model.grad_views = True
+    model.zero_grad()
+    backward()
+    for n, p in model.named_parameters():
+        assert p.grad.data_ptr() == eng.g[n].data_ptr() and close(p.grad, ref[n]), n
+    backward(0.5)                                    # no zero_grad in between: accumulation
+    for n, p in model.named_parameters():
+        assert p.grad.data_ptr() == eng.g[n].data_ptr()
+        assert float((p.grad - 1.5 * ref[n]).abs().max()) <= 1e-5 * max(float(ref[n].abs().max()), 1e-6), n
+    for p in model.parameters():
+        p.grad.zero_()                               # optimizer.zero_grad(set_to_none=False)
+    backward()
+    assert all(close(p.grad, ref[n]) for n, p in model.named_parameters())
+    model.zero_grad()
+    name = "enc.encoder.layer.0.attention.self.query.weight" if "enc.encoder.layer.0.attention.self.query.weight" in ref else next(iter(ref))
+    own = torch.ones_like(ref[name])
+    dict(model.named_parameters())[name].grad = own  # somebody else's tensor: autograd semantics = add to it
+    backward()
+    got = dict(model.named_parameters())[name].grad
+    assert got.data_ptr() != eng.g[name].data_ptr() and float((got - 1.0 - ref[name]).abs().max()) <= 1e-6 + 1e-5 * float(ref[name].abs().max())
+    # a torch optimizer on the views moves the parameters exactly as it does on copies
+    model.zero_grad()
+    backward()
+    before = {n: p.detach().clone() for n, p in model.named_parameters()}
+    torch.optim.SGD(model.parameters(), lr=0.5).step()
+    for n, p in model.named_parameters():
+        assert float((p.detach() - (before[n] - 0.5 * ref[n])).abs().max()) <= 1e-6 + 1e-5 * float(ref[n].abs().max()), n
+    model.zero_grad()
 
 
 @pytest.mark.parametrize("dtype,gop", [(torch.float32, None), (torch.bfloat16, "f16"), (torch.bfloat16, "bf16")])
