@@ -237,8 +237,8 @@ __device__ __forceinline__ size_t dbits_block(const AttnArgs& a, size_t bh, int 
 // One thread per 64-bit word.  The word's 64 keep decisions are 64 independent PL-bit uniforms compared with the threshold
 // thr = round(p * 2^PL), evaluated bit-sliced: PL bit-planes of 64 random bits each (two 32-bit hashes of a counter), most
 // significant plane first -- lt collects the lanes already known to be below the threshold, eq those still equal to its prefix.
-// drop = (x < thr), so P(drop) = thr / 2^PL.  2*PL hashes per 64 mask bits, no cross-lane work; the kernel is bound by the hashes'
-// quarter-rate multiplies, i.e. its time is proportional to PL (profiles/r03_notes.txt).
+// drop = (x < thr), so P(drop) = thr / 2^PL.  No cross-lane work; the kernel is bound by the hashes' quarter-rate multiplies
+// (profiles/r03_notes.txt: 2 * PL hashes per word, time proportional to PL -- until round 5 cut the planes after the eighth, see below).
 template <int PL>
 __global__ __launch_bounds__(256) void attn_dropmask_kernel(unsigned k0, unsigned k1, unsigned thr16, int A, int L, int NQB, int NKT,
                                                             const int32_t* __restrict__ cu, unsigned long long* __restrict__ out, size_t nwords) {
@@ -254,12 +254,32 @@ __global__ __launch_bounds__(256) void attn_dropmask_kernel(unsigned k0, unsigne
   if (qb * 32 >= Lv || kt * 64 >= Lv) return;        // no kernel ever looks at a block without an existing query or key
   const unsigned base = (unsigned)w * 32u;
   unsigned long long lt = 0ull, eq = ~0ull;
+  // PL > 8: only the 8 most significant planes are evaluated bit-sliced.  After them a lane is still undecided with probability 2^-8
+  // (its high byte equals the threshold's): 0.25 lanes per word on average, and those few draw their remaining PL - 8 bits one lane at a
+  // time from single extra hashes (counters below the planes').  Same distribution -- P(drop) = thr / 2^PL exactly -- for 16 + ~2 hashes
+  // per word instead of 2 * PL (round 5: 36 -> 23 us per layer at PL = 16).
+  constexpr int SL = PL > 8 ? PL - 8 : 0;          // planes left to the serial tail
 #pragma unroll
-  for (int j = PL - 1; j >= 0; --j) {
+  for (int j = PL - 1; j >= SL; --j) {
     const unsigned long long x = ((unsigned long long)mv_hash32(base + 2 * j, k0, k1) << 32) | mv_hash32(base + 2 * j + 1, k0, k1);
     const unsigned long long tb = 0ull - (unsigned long long)((thr16 >> j) & 1u);      // all ones where the threshold has this bit
     lt |= eq & ~x & tb;
     eq &= x ^ ~tb;
+  }
+  if constexpr (SL > 0) {
+    const unsigned lo = thr16 & ((1u << SL) - 1u);
+    constexpr int PER = 32 / SL;                    // lanes served by one hash
+    unsigned r = 0, ctr = 0;
+    int have = 0;
+    while (eq) {
+      const int l = __builtin_ctzll(eq);
+      eq &= eq - 1ull;
+      if (have == 0) { r = mv_hash32(base + ctr, k0, k1); ++ctr; have = PER; }
+      const unsigned x = r & ((1u << SL) - 1u);
+      r >>= SL;
+      --have;
+      if (x < lo) lt |= 1ull << l;
+    }
   }
   out[w] = ~lt;
 }
