@@ -59,7 +59,8 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_ring_kernel(GemmArgs p) {
   const int tiles_m = (p.M + BM - 1) / BM;
   int tm, tn;
   {
-    const int GM = 8;
+    // row tiles per group of the rasterisation (debug bits 32 / 64 / 128: 4 / 16 / 12 instead of 8 -- timing experiments only)
+    const int GM = (p.dbg & 32) ? 4 : (p.dbg & 64) ? 16 : (p.dbg & 128) ? 12 : 8;
     const int per_group = GM * tiles_n;
     const int group = bid / per_group, rem = bid - group * per_group;
     const int gm = min(GM, tiles_m - group * GM);
