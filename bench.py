@@ -211,11 +211,13 @@ def _drop_in_user_timings(mv, model, step, cfg, dev, B, N, S, n, out, time, Simp
     # (iii) the same loop with ONE line changed: `loss = medvill_amd.losses.mlm_itm_loss(mlm, itm, labels, aligned)` under
     # model.lazy_logits = True (the MLM head runs on the labelled rows inside the loss; no [B,L,V] tensor): B = 16 and B = 64
     model.lazy_logits = True
-    for bsz, key in ((16, "dropin_lazy_loss_b16_ms"), (64, "dropin_lazy_loss_b64_ms")):
+    # ... and with the labels also handed to the forward (`model(..., txt_labels=txt_labels)`: last layer on the consumed rows only), B = 64
+    for bsz, key in ((16, "dropin_lazy_loss_b16_ms"), (64, "dropin_lazy_loss_b64_ms"), (64, "dropin_lazy_loss_labels_in_forward_b64_ms")):
         bl = mv.data.synthetic_batch(cfg.vocab_size, bsz, N, S, "full", seed=998, device=dev)
+        kw = {"txt_labels": bl["txt_labels"]} if "labels_in_forward" in key else {}
 
         def one_lazy(t):
-            mlm, itm = model(bl["cls_tok"], bl["input_txt"], bl["attn_mask"], bl["segment"], (bl["img_feats"], bl["img_pos"]), bl["sep_tok"])
+            mlm, itm = model(bl["cls_tok"], bl["input_txt"], bl["attn_mask"], bl["segment"], (bl["img_feats"], bl["img_pos"]), bl["sep_tok"], **kw)
             loss = mv.losses.mlm_itm_loss(mlm, itm, bl["txt_labels"], bl["is_aligned"])
             model.zero_grad()                       # optim.zero_grad() of train_origin.py:129
             loss.backward()
@@ -485,6 +487,7 @@ def main():
                        "dropin_forward_backward_b16_ms": extras.get("dropin_forward_backward_b16_ms"),
                        # ... and with the two CrossEntropyLoss calls replaced by medvill_amd.losses.mlm_itm_loss under model.lazy_logits
                        "dropin_lazy_loss_b16_ms": extras.get("dropin_lazy_loss_b16_ms"), "dropin_lazy_loss_b64_ms": extras.get("dropin_lazy_loss_b64_ms"),
+                       "dropin_lazy_loss_labels_in_forward_b64_ms": extras.get("dropin_lazy_loss_labels_in_forward_b64_ms"),
                        "rccl_ranks": rccl_ranks, "dist_backend": backend, "allreduce_exposed_ms": exposed_ms,
                        # rank 0's view of the gradient exchange: when each bucket's all-reduce was issued / completed relative to the first
                        # bucket's issue, and when the compute stream waited for the rest (None undistributed)

@@ -70,7 +70,12 @@ class _CXRBertFn(torch.autograd.Function):
         # lazy MLM logits (want_heads == 3): nothing downstream needs a row per position, so descriptor masks whose padding is invisible
         # run on the valid rows only, like the fused training step
         pack = want_heads == 3 and isinstance(attn_mask, MaskDesc) and eng.is16 and attn_mask.packable()
-        hidden, pooled = eng.encoder_forward(cls_tok, input_txt, attn_mask, segment, feats, pos, sep_tok, pack=pack)
+        # forward(..., txt_labels=...) under lazy logits: the labelled rows are known, so the last layer's per-row work runs on the rows the
+        # heads consume only (and, in the full / 1-D families, its attention on those queries only), like the fused training step
+        fwd_labels = model.__dict__.pop("_fwd_labels", None) if want_heads == 3 else None
+        model._lazy_rows = fwd_labels
+        hidden, pooled = eng.encoder_forward(cls_tok, input_txt, attn_mask, segment, feats, pos, sep_tok, pack=pack,
+                                             tail_rows=None if fwd_labels is None else fwd_labels[0])
         ctx.model, ctx.want_heads = model, want_heads
         if want_heads == 2:                     # ITM head only (retrieval: `self.itm(cls)` on the pooled output)
             return eng._itm_forward().clone()
@@ -204,6 +209,14 @@ class LazyLogits:
     def loss(self, txt_labels, is_aligned, mlm_task=True, itm_task=True):
         from .data import label_index
         eng = self.model.engine
+        given = self.model._lazy_rows
+        if given is not None:
+            # the forward was given the labels (forward(..., txt_labels=...)) and ran its last layer on exactly their rows
+            rows, ids, src = given
+            if txt_labels is not src and not torch.equal(txt_labels.to(eng.device), src.to(eng.device)):
+                raise ValueError("mlm_itm_loss: txt_labels differ from the labels the lazy forward was given")
+            aligned = is_aligned.to(eng.device, torch.int32)
+            return _LazyLossFn.apply(self.tok, self, rows, ids, aligned, bool(mlm_task), bool(itm_task))
         rows, ids = label_index(txt_labels.to(eng.device))
         if eng.S.get("inv") is not None and rows.numel() > 0:
             # the forward ran on the valid rows only (mask descriptors): a label past a sample's text [SEP] has no row.  The reference
@@ -218,8 +231,9 @@ class LazyLogits:
     @torch.no_grad()
     def materialize(self):
         eng = self.model.engine
-        if eng.S.get("cu") is not None:
-            raise RuntimeError("the forward ran on packed rows (mask descriptors): there is no logit row per position to materialise")
+        if eng.S.get("cu") is not None or eng.S.get("sel") is not None:
+            raise RuntimeError("the forward ran on packed rows (mask descriptors) or on the labelled rows only (txt_labels given): "
+                               "there is no logit row per position to materialise")
         return eng.heads_full()[0]
 
 
@@ -382,6 +396,7 @@ class CXRBERT(nn.Module):
         # handed to torch as views of the flat gradient buffer instead of copies (see _CXRBertFn.backward)
         self.lazy_logits, self.recognise_masks, self.grad_views = False, True, True
         self.n_masks_seen = self.n_masks_recognised = 0
+        self._lazy_rows = None
         self._register()
         self.reset_parameters()
 
@@ -486,16 +501,30 @@ class CXRBERT(nn.Module):
         self.n_masks_recognised += 1
         return MaskDesc(desc, Lq, host=host[:-1].view(B, 3).clone())
 
-    def _run(self, want_heads, cls_tok, input_txt, attn_mask, segment, input_img, sep_tok):
+    def _run(self, want_heads, cls_tok, input_txt, attn_mask, segment, input_img, sep_tok, txt_labels=None):
         if attn_mask.dim() not in (2, 3):
             raise NotImplementedError            # cxrbert_origin.py:80-81
         feats, pos = self._regions(input_img)
+        self.__dict__.pop("_fwd_labels", None)
         if want_heads == 3 and self.recognise_masks and torch.is_tensor(attn_mask) and attn_mask.is_cuda and self.engine.is16:
             # lazy logits: nothing downstream needs a row per position, so a batch whose masks are the Dataset's closed forms runs on
             # its valid rows (packed), like the fused training step does for the trainer
             self.engine.sync_shadow()            # (enqueued first: the device converts the weights while the host waits for the verdict)
             self.__dict__["_shadow_fresh"] = True
             attn_mask = self._mask_descriptors(attn_mask, input_txt, int(feats.shape[1])) or attn_mask
+        if want_heads == 3 and txt_labels is not None:
+            from .data import MaskDesc, label_index
+            dev = self.engine.device
+            rows, ids = label_index(txt_labels.to(dev))
+            if isinstance(attn_mask, MaskDesc) and self.engine.is16 and attn_mask.packable() and rows.numel() > 0:
+                # packed rows: a label past a sample's text [SEP] has no row (the Dataset never produces one, dataset_origin.py:105-135)
+                Lq = attn_mask.L
+                r64 = rows.to(torch.int64)
+                vl = attn_mask.desc.to(dev)[:, 2].to(torch.int64)
+                if bool((r64 % Lq >= vl.index_select(0, r64 // Lq)).any()):
+                    raise ValueError("txt_labels holds a label at a padded position (after the text [SEP]); the lazy forward runs on the "
+                                     "valid rows only.  Set model.recognise_masks = False (and pass the mask matrix) to run every row")
+            self.__dict__["_fwd_labels"] = (rows, ids, txt_labels)
         params = self._plist
         self._want_grad = torch.is_grad_enabled()        # (grad mode is always off inside autograd.Function.forward)
         return _CXRBertFn.apply(self, want_heads, cls_tok, input_txt, attn_mask, segment, feats, pos, sep_tok, *params)
@@ -504,10 +533,14 @@ class CXRBERT(nn.Module):
         hidden, pooled = self._run(False, cls_tok, input_txt, attn_mask, segment, input_img, sep_tok)
         return hidden, pooled, None
 
-    def forward(self, cls_tok, input_txt, attn_mask, segment, input_img, sep_tok):
+    def forward(self, cls_tok, input_txt, attn_mask, segment, input_img, sep_tok, txt_labels=None):
+        """cxrbert_origin.py:144-149.  txt_labels (optional, lazy logits only; not part of the reference's signature): the MLM labels the loss
+        will use -- with them the last encoder layer runs on the rows the heads consume only (what the fused training step does)."""
+        if txt_labels is not None and not getattr(self, "lazy_logits", False):
+            raise ValueError("forward(..., txt_labels=...) needs model.lazy_logits = True (the full logits need every row)")
         if getattr(self, "lazy_logits", False):
             # (mlm, itm) like the reference, with `mlm` a LazyLogits handle for medvill_amd.losses.mlm_itm_loss (see LazyLogits)
-            tok, itm = self._run(3, cls_tok, input_txt, attn_mask, segment, input_img, sep_tok)
+            tok, itm = self._run(3, cls_tok, input_txt, attn_mask, segment, input_img, sep_tok, txt_labels=txt_labels)
             return LazyLogits(self, tok, (itm.shape[0], self.engine.S["L"], self.cfg.vocab_size)), itm
         return self._run(True, cls_tok, input_txt, attn_mask, segment, input_img, sep_tok)
 

@@ -22,13 +22,17 @@ model.lazy_logits = True
 eng = model.engine
 for B in (64, 16):
     bl = mv.data.synthetic_batch(cfg.vocab_size, B, N, S, "full", seed=998, device=dev)
-    for rec, views, opt in ((False, False, "engine"), (True, False, "engine"), (False, True, "engine"), (True, True, "engine"), (True, True, "torch")):
+    for rec, views, opt in ((False, False, "engine"), (True, False, "engine"), (False, True, "engine"), (True, True, "engine"), (True, True, "torch"),
+                            (True, True, "engine+labels"), (True, True, "torch+labels")):
         model.recognise_masks, model.grad_views = rec, views
+        with_labels = opt.endswith("+labels")           # forward(..., txt_labels=labels): last layer on the consumed rows only
+        opt = opt.split("+")[0]
         model.zero_grad()
         topt = torch.optim.AdamW(model.parameters(), lr=1e-5, fused=True) if opt == "torch" else None
 
         def one(t):
-            mlm, itm = model(bl["cls_tok"], bl["input_txt"], bl["attn_mask"], bl["segment"], (bl["img_feats"], bl["img_pos"]), bl["sep_tok"])
+            mlm, itm = model(bl["cls_tok"], bl["input_txt"], bl["attn_mask"], bl["segment"], (bl["img_feats"], bl["img_pos"]), bl["sep_tok"],
+                             **({"txt_labels": bl["txt_labels"]} if with_labels else {}))
             model.zero_grad()             # optim.zero_grad() of train_origin.py:129 (.grad = None)
             mv.losses.mlm_itm_loss(mlm, itm, bl["txt_labels"], bl["is_aligned"]).backward()
             if topt is not None:
@@ -43,6 +47,6 @@ for B in (64, 16):
             one(t + 3)
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / n * 1e3
-        print(f"B={B:3d} recognise_masks={int(rec)} grad_views={int(views)} optimizer={opt:6s}: {ms:7.2f} ms per step "
+        print(f"B={B:3d} recognise_masks={int(rec)} grad_views={int(views)} optimizer={opt:6s} labels_in_forward={int(with_labels)}: {ms:7.2f} ms per step "
               f"({B / ms * 1e3:7.0f} pairs/s), packed={eng.S['cu'] is not None}", flush=True)
         del topt

@@ -213,6 +213,48 @@ def test_lazy_forward_proves_a_device_matrix_before_it_runs_on_descriptors(golde
     model.zero_grad()
 
 
+@pytest.mark.parametrize("dtype,rtol", [(torch.float32, 2e-4), (torch.bfloat16, 3e-2)])
+def test_lazy_forward_given_the_labels_runs_its_last_layer_on_the_consumed_rows(golden_dir, dtype, rtol):
+    """forward(..., txt_labels=labels) under lazy logits (an optional keyword beyond the reference's signature): the last layer's per-row work
+    runs on the labelled rows + first rows only, like the fused step; loss and every gradient equal the literal path's; the loss refuses other
+    labels than the forward's; without lazy logits the keyword is refused."""
+    z, meta, cfg, P, b = load_case(golden_dir, "c1v1k_full")
+    model = make_model(cfg, P, dtype)
+    labels, aligned = b["txt_labels"].to(DEV), b["is_aligned"].to(DEV)
+    args = (b["cls_tok"].to(DEV), b["input_txt"].to(DEV), b["attn_mask"].to(DEV), b["segment"].to(DEV),
+            (b["img_feats"].to(DEV), b["img_pos"].to(DEV)), b["sep_tok"].to(DEV))
+    with pytest.raises(ValueError, match="lazy_logits"):
+        model(*args, txt_labels=labels)
+    mlm, itm = model(*args)
+    ref = mv.losses.mlm_itm_loss(mlm, itm, labels, aligned)
+    ref.backward()
+    g_ref = {n: p.grad.clone() for n, p in model.named_parameters()}
+    gmax = max(float(g.abs().max()) for g in g_ref.values())
+    model.zero_grad()
+    model.lazy_logits = True
+    lz, itm2 = model(*args, txt_labels=labels)
+    S = model.engine.S
+    assert S["sel"] is not None and S["n_lab"] == int((labels != -100).sum()) and (S["cu"] is not None) == (dtype != torch.float32)
+    assert float((itm2 - itm.detach()).abs().max()) < (FP32_TOL if dtype == torch.float32 else BF16_TOL)
+    other = labels.clone()
+    other[other != -100] = 7
+    with pytest.raises(ValueError, match="differ"):
+        mv.losses.mlm_itm_loss(lz, itm2, other, aligned)
+    loss = mv.losses.mlm_itm_loss(lz, itm2, labels.clone(), aligned)          # (an equal tensor is accepted, not only the same object)
+    assert abs(float(loss) - float(ref)) < (1e-5 if dtype == torch.float32 else 5e-3)
+    loss.backward()
+    for n, p in model.named_parameters():
+        scale = max(float(g_ref[n].abs().max()), 1e-3 * gmax)
+        assert float((p.grad - g_ref[n]).abs().max()) <= rtol * scale, n
+    with pytest.raises(RuntimeError, match="labelled rows only"):
+        lz.materialize()
+    model.zero_grad()
+    lz, itm3 = model(*args)                                                    # the next forward without labels is an ordinary lazy one
+    assert model.engine.S["sel"] is None and model._lazy_rows is None
+    mv.losses.mlm_itm_loss(lz, itm3, labels, aligned).backward()
+    model.zero_grad()
+
+
 def test_drop_in_gradients_are_views_of_the_flat_buffer_with_autograds_semantics(golden_dir):
     """loss.backward() on the model API (train_origin.py:129-131): with .grad = None (after optimizer.zero_grad()) every Parameter's .grad
     becomes a VIEW of the engine's flat gradient buffer (no copy, nothing for autograd to accumulate); a second backward without zero_grad
