@@ -94,16 +94,19 @@ class _CXRBertFn(torch.autograd.Function):
     def _backward_once(ctx, g0, g1):
         model = ctx.model
         eng = model.engine
-        eng.zero_grad()
         if ctx.want_heads == 3:
             if model._lazy is None:
                 raise RuntimeError("lazy logits: backward() reached the model without a loss from medvill_amd.losses.mlm_itm_loss(mlm, itm, ...)")
-            rows, ids, aligned, mlm_on, itm_on = model._lazy
+            rows, ids, aligned, mlm_on, itm_on, pre = model._lazy
+            model._lazy = (rows, ids, aligned, mlm_on, itm_on, False)      # (a second pass -- loss-scale retry, retain_graph -- redoes the head)
             gv = float(g0) if g0 is not None else 0.0          # d(total) / d(loss), normally 1.0 (one host read on the drop-in path)
-            eng.heads_train(rows, ids, aligned, mlm_scale=(gv / max(int(rows.numel()), 1)) if mlm_on else 0.0,
-                            itm_scale=(gv / int(aligned.numel())) if itm_on else 0.0, compute_grad=True)
+            if not (pre and gv == 1.0):
+                eng.zero_grad()
+                eng.heads_train(rows, ids, aligned, mlm_scale=(gv / max(int(rows.numel()), 1)) if mlm_on else 0.0,
+                                itm_scale=(gv / int(aligned.numel())) if itm_on else 0.0, compute_grad=True)
             eng.encoder_backward()
             return
+        eng.zero_grad()
         if ctx.want_heads == 2:
             eng.heads_full_backward(None, g0)
         elif ctx.want_heads:
@@ -134,7 +137,10 @@ class _CXRBertFn(torch.autograd.Function):
         eng = model.engine
         # gradients a previous backward left in the flat buffer THROUGH the .grad views (no zero_grad in between, or
         # zero_grad(set_to_none=False)): keep them, this backward adds to them like autograd would
-        held = eng.flat_g.clone() if (model.grad_views and eng.flat_g is not None and _holds_views(model)) else None
+        if ctx.want_heads == 3 and model._lazy is not None and model._lazy[5]:
+            held = model.__dict__.pop("_held", None)             # set aside by the loss, which has already zeroed the buffer
+        else:
+            held = eng.flat_g.clone() if (model.grad_views and eng.flat_g is not None and _holds_views(model)) else None
         _CXRBertFn._backward_once(ctx, g0, g1)
         if eng.scaler is not None:
             # f16 gradient operands under a loss scale: this path hands gradients to torch (an external optimizer), so an
@@ -243,10 +249,18 @@ class _LazyLossFn(torch.autograd.Function):
         model = lazy.model
         eng = model.engine
         R, B = int(rows.numel()), int(aligned.numel())
-        stats = eng.heads_train(rows, ids, aligned, mlm_scale=1.0 / max(R, 1), itm_scale=1.0 / B, compute_grad=False)
+        # A backward is coming (the handle requires grad): the head runs ONCE, with its gradient for d loss = 1 -- the flat gradient buffer
+        # is zeroed here instead of in the backward (gradients held through .grad views are set aside first, see _CXRBertFn.backward).  The
+        # backward reuses that when it is indeed handed 1.0 and redoes the head otherwise (an upstream factor, a loss-scale retry).
+        pre = bool(ctx.needs_input_grad[0]) and model.grad_in_loss
+        if pre:
+            model._held = eng.flat_g.clone() if (model.grad_views and eng.flat_g is not None and _holds_views(model)) else None
+            eng.zero_grad()
+        stats = eng.heads_train(rows, ids, aligned, mlm_scale=(1.0 / max(R, 1)) if (mlm_on or not pre) else 0.0,
+                                itm_scale=(1.0 / B) if (itm_on or not pre) else 0.0, compute_grad=pre)
         lazy.stats = stats
-        model._lazy = (rows, ids, aligned, mlm_on, itm_on)       # _CXRBertFn.backward redoes the head WITH its gradient (and again per
-        loss = tok.new_zeros(())                                 # loss-scale retry): the labelled-rows head is ~2 % of a step
+        model._lazy = (rows, ids, aligned, mlm_on, itm_on, pre)
+        loss = tok.new_zeros(())
         if mlm_on:
             loss = loss + stats[0] / torch.clamp(stats[1], min=1.0)      # mean over the labelled positions (ignore_index=-100)
         if itm_on:
@@ -395,6 +409,7 @@ class CXRBERT(nn.Module):
         # drop-in switches: lazy MLM logits; recognition of the Dataset's materialised masks on the lazy path; gradients
         # handed to torch as views of the flat gradient buffer instead of copies (see _CXRBertFn.backward)
         self.lazy_logits, self.recognise_masks, self.grad_views = False, True, True
+        self.grad_in_loss = True          # lazy logits: the loss runs the head once, with its gradient (see _LazyLossFn)
         self.n_masks_seen = self.n_masks_recognised = 0
         self._lazy_rows = None
         self._register()

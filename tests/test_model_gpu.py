@@ -252,6 +252,21 @@ def test_lazy_forward_given_the_labels_runs_its_last_layer_on_the_consumed_rows(
     lz, itm3 = model(*args)                                                    # the next forward without labels is an ordinary lazy one
     assert model.engine.S["sel"] is None and model._lazy_rows is None
     mv.losses.mlm_itm_loss(lz, itm3, labels, aligned).backward()
+    # no zero_grad: the next lazy step adds to the gradients held through the .grad views (the loss zeroes the flat buffer for its head's
+    # gradients -- the held values are set aside first)
+    lz, itm3 = model(*args)
+    mv.losses.mlm_itm_loss(lz, itm3, labels, aligned).backward()
+    for n, p in model.named_parameters():
+        scale = max(float(g_ref[n].abs().max()), 1e-3 * gmax)
+        assert float((p.grad - 2.0 * g_ref[n]).abs().max()) <= 2.0 * rtol * scale, n
+    # grad_in_loss = False: the head runs for the value in the loss and again, with its gradient, in the backward -- same result
+    model.zero_grad()
+    model.grad_in_loss = False
+    lz, itm3 = model(*args)
+    mv.losses.mlm_itm_loss(lz, itm3, labels, aligned).backward()
+    for n, p in model.named_parameters():
+        scale = max(float(g_ref[n].abs().max()), 1e-3 * gmax)
+        assert float((p.grad - g_ref[n]).abs().max()) <= rtol * scale, n
     model.zero_grad()
 
 
