@@ -43,6 +43,6 @@ from .cxrbert import CXRBERT  # noqa: F401
 from .trainer import CXRBERT_Trainer, TrainStep  # noqa: F401
 from .retrieval import CXRBertForRetrieval  # noqa: F401
 from .image import ImageEncoder_cnn  # noqa: F401
-from . import checkpoint, data, dist, hip_ops, losses  # noqa: F401
+from . import checkpoint, data, dist, hip_ops, losses, optim  # noqa: F401
 
 __all__ = ["Engine", "ModelConfig", "param_layout", "CXRBERT", "CXRBERT_Trainer", "TrainStep", "CXRBertForRetrieval", "ImageEncoder_cnn", "data"]

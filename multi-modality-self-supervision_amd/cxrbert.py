@@ -19,6 +19,7 @@ import json
 import os
 from collections import OrderedDict
 from dataclasses import replace
+import weakref
 from types import SimpleNamespace
 
 import torch
@@ -61,9 +62,10 @@ class _CXRBertFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, want_heads, cls_tok, input_txt, attn_mask, segment, feats, pos, sep_tok, *params):
         eng = model.engine
-        # parameters may have been stepped by an external optimizer: the 16-bit copies are refreshed on every forward (unless _run has just
-        # done so, ahead of the mask recognition's read-back)
-        eng.shadow_dirty = not model.__dict__.pop("_shadow_fresh", False)
+        # parameters may have been stepped by an external optimizer: the 16-bit copies are refreshed on every forward -- unless _run has just
+        # done so (ahead of the mask recognition's read-back) or medvill_amd.optim.AdamW, whose kernel writes them, was the last to touch them
+        if not model.__dict__.pop("_shadow_fresh", False):
+            eng.shadow_dirty = eng.shadow_dirty or model._params_dirty()
         eng.training = model.training           # dropout (p = 0.1 at every site of the reference) only in train mode
         eng.keep_acts = bool(model._want_grad)  # under torch.no_grad() nothing is saved for a backward
         from .data import MaskDesc
@@ -412,6 +414,7 @@ class CXRBERT(nn.Module):
         self.grad_in_loss = True          # lazy logits: the loss runs the head once, with its gradient (see _LazyLossFn)
         self.n_masks_seen = self.n_masks_recognised = 0
         self._lazy_rows = None
+        self._opt_versions = None
         self._register()
         self.reset_parameters()
 
@@ -425,6 +428,7 @@ class CXRBERT(nn.Module):
                     mod.add_module(p_, _Sub())
                 mod = mod._modules[p_]
             par = nn.Parameter(self.engine.p[name], requires_grad=True)
+            par._medvill_model = weakref.ref(self)           # medvill_amd.optim.AdamW(model.parameters()) finds the flat buffers through it
             mod._parameters[parts[-1]] = par
         # the Parameter objects in layout order (the same objects for the model's lifetime: _rebind only re-points their .data).  Looking
         # 200 names up with get_parameter costs ~1 ms of host time per use, and the drop-in step does it with the device idle
@@ -490,6 +494,13 @@ class CXRBERT(nn.Module):
         raise TypeError("input_img must be (region_feats[B,N,2048], region_pos[B,N]); for pixels construct the model with "
                         "img_encoder='resnet50' (medvill_amd.image.ImageEncoder_cnn) or pass your own callable")
 
+    def _params_dirty(self):
+        """True unless medvill_amd.optim.AdamW (whose kernel also writes the 16-bit copies) was the last to modify the Parameters: it records
+        the sum of their version counters, which every in-place operation of a torch optimizer, `load_state_dict`, `p.add_(...)` advances.
+        (Writes through `p.data` leave no trace -- after such an edit set `model.engine.shadow_dirty = True`.)"""
+        v = self._opt_versions
+        return v is None or v != sum(p._version for p in self._plist)
+
     def _mask_descriptors(self, mask, input_txt, N):
         """A materialised reference mask on the device -> MaskDesc when it IS one of the closed-form families, entry by entry: the
         hypothesis of data.descriptors_from_dense is confirmed by comparing the mask words the kernels would run on (mv_mask_pack of
@@ -524,7 +535,8 @@ class CXRBERT(nn.Module):
         if want_heads == 3 and self.recognise_masks and torch.is_tensor(attn_mask) and attn_mask.is_cuda and self.engine.is16:
             # lazy logits: nothing downstream needs a row per position, so a batch whose masks are the Dataset's closed forms runs on
             # its valid rows (packed), like the fused training step does for the trainer
-            self.engine.sync_shadow()            # (enqueued first: the device converts the weights while the host waits for the verdict)
+            if self.engine.shadow_dirty or self._params_dirty():
+                self.engine.sync_shadow()        # (enqueued first: the device converts the weights while the host waits for the verdict)
             self.__dict__["_shadow_fresh"] = True
             attn_mask = self._mask_descriptors(attn_mask, input_txt, int(feats.shape[1])) or attn_mask
         if want_heads == 3 and txt_labels is not None:

@@ -23,12 +23,15 @@ eng = model.engine
 for B in (64, 16):
     bl = mv.data.synthetic_batch(cfg.vocab_size, B, N, S, "full", seed=998, device=dev)
     for rec, views, opt in ((False, False, "engine"), (True, False, "engine"), (False, True, "engine"), (True, True, "engine"), (True, True, "torch"),
-                            (True, True, "engine+labels"), (True, True, "torch+labels")):
+                            (True, True, "engine+labels"), (True, True, "torch+labels"), (True, True, "mvopt"), (True, True, "mvopt+labels"),
+                            (True, True, "mvovl"), (True, True, "mvovl+labels")):
         model.recognise_masks, model.grad_views = rec, views
         with_labels = opt.endswith("+labels")           # forward(..., txt_labels=labels): last layer on the consumed rows only
         opt = opt.split("+")[0]
         model.zero_grad()
         topt = torch.optim.AdamW(model.parameters(), lr=1e-5, fused=True) if opt == "torch" else None
+        if opt in ("mvopt", "mvovl"):       # medvill_amd.optim.AdamW (the engine's kernel behind the torch optimizer protocol; mvovl: overlap=True)
+            topt = mv.optim.AdamW(model.parameters(), lr=1e-5, overlap=(opt == "mvovl"))
 
         def one(t):
             mlm, itm = model(bl["cls_tok"], bl["input_txt"], bl["attn_mask"], bl["segment"], (bl["img_feats"], bl["img_pos"]), bl["sep_tok"],

@@ -320,6 +320,64 @@ def test_drop_in_gradients_are_views_of_the_flat_buffer_with_autograds_semantics
     model.zero_grad()
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_engine_adamw_behind_the_torch_optimizer_protocol(golden_dir, dtype):
+    """medvill_amd.optim.AdamW(model.parameters(), lr) -- the reference's optimizer line (train_origin.py:60) on the flat buffers: the loop
+    zero_grad / backward / step moves the parameters exactly like the engine's own step, schedulers act through param_groups, the 16-bit weight
+    copies are the optimizer's (no refresh in the next forward until somebody else modifies a Parameter), state round-trips, and anything but
+    the whole parameter set of one CXRBERT is refused."""
+    z, meta, cfg, P, b = load_case(golden_dir, "c1v1k_full")
+    labels, aligned = b["txt_labels"].to(DEV), b["is_aligned"].to(DEV)
+    lrs = [3e-4, 3e-4, 1.5e-4]
+
+    def loss_of(model):
+        mlm, itm = fwd(model, b)
+        return mv.losses.mlm_itm_loss(mlm, itm, labels, aligned)
+    ref = make_model(cfg, P, dtype)
+    ref.lazy_logits = True
+    ref_losses = []
+    for t, lr in enumerate(lrs):
+        ref.zero_grad()
+        loss = loss_of(ref)
+        loss.backward()
+        ref.engine.adamw_step(t + 1, lr=lr, weight_decay=0.01)
+        ref_losses.append(float(loss))
+    model = make_model(cfg, P, dtype)
+    model.lazy_logits = True
+    opt = mv.optim.AdamW(model.parameters(), lr=lrs[0], weight_decay=0.01)
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda e: 1.0 if e < 2 else 0.5)
+    assert model._params_dirty()
+    casts = []
+    sync = model.engine.sync_shadow
+    model.engine.sync_shadow = lambda: (casts.append(1), sync())[1]
+    for t in range(len(lrs)):
+        opt.zero_grad()
+        loss = loss_of(model)
+        assert abs(float(loss) - ref_losses[t]) < (1e-6 if dtype == torch.float32 else 2e-3), t
+        loss.backward()
+        opt.step()
+        sched.step()
+        assert not model._params_dirty() and not model.engine.shadow_dirty
+    assert len(casts) <= 1                                  # only the first forward converted the weights (16-bit path)
+    for (n, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
+        assert float((p - q).abs().max()) <= (1e-7 if dtype == torch.float32 else 2e-5) + 1e-3 * lrs[0], n
+    opt.zero_grad()
+    before = model.engine.flat_p.clone()
+    opt.step()                                              # nothing back-propagated: no update
+    assert torch.equal(before, model.engine.flat_p)
+    with torch.no_grad():
+        next(iter(model.parameters())).add_(0.0)            # somebody else touches a Parameter in place: the copies are stale again
+    assert model._params_dirty()
+    sd = opt.state_dict()
+    opt2 = mv.optim.AdamW(model.parameters(), lr=1.0)
+    opt2.load_state_dict(sd)
+    assert opt2._t == len(lrs) and opt2.param_groups[0]["weight_decay"] == 0.01 and torch.equal(opt2.state_dict()["flat_m"], sd["flat_m"])
+    with pytest.raises(ValueError, match="whole flat parameter buffer"):
+        mv.optim.AdamW(list(model.parameters())[:5], lr=1e-3)
+    with pytest.raises(ValueError, match="not the Parameters"):
+        mv.optim.AdamW(torch.nn.Linear(2, 2).parameters(), lr=1e-3)
+
+
 @pytest.mark.parametrize("dtype,gop", [(torch.float32, None), (torch.bfloat16, "f16"), (torch.bfloat16, "bf16")])
 def test_fused_train_step_equals_dropin_path(golden_dir, dtype, gop):
     """TrainStep (labelled rows only, fused CE) must give the same losses and gradients as
