@@ -312,7 +312,15 @@ __global__ void splitk_reduce_kernel(GemmArgs p) {
       f32x4 s = {0.f, 0.f, 0.f, 0.f};
       for (int k = 0; k < p.splitk; ++k) s += *(const f32x4*)(p.ws + k * mn + e);
       const int m = (int)(e / p.N), n = (int)(e - (size_t)m * p.N);
-      epilogue4_slow(p, m, n, s);
+      if (p.epi == MV_EPI_NONE && p.c_dtype == MV_F32 && !p.C3 && p.vec_ok && (p.ldc & 3) == 0) {
+        // the weight gradients (51 of these launches per step): one 16-byte load / store of C instead of four scalar ones
+        float* c = (float*)p.C + (size_t)m * p.ldc + n;
+        if (p.alpha) s *= *p.alpha;
+        if (p.accumulate) s += *(const f32x4*)c;
+        *(f32x4*)c = s;
+      } else {
+        epilogue4_slow(p, m, n, s);
+      }
     } else {
       for (int j = 0; j < 4 && e + j < mn; ++j) {
         float s = 0.f;
