@@ -413,3 +413,31 @@ def test_torch_mask_recogniser_agrees_with_the_trainers_host_recogniser():
     assert bool(mv.data.descriptors_from_dense(inner, b["input_txt"], N)[1])
     assert mv.data.descriptors_from_dense(b["attn_mask"], b["input_txt"][:, :-1], N) is None          # shapes rule it out
     assert mv.data.descriptors_from_dense(b["attn_mask"].to(torch.int32), b["input_txt"], N) is None
+
+
+def test_flat_adamw_takes_the_whole_parameter_set_of_one_model_and_tracks_foreign_writes():
+    """medvill_amd.optim.AdamW (train_origin.py:60's optimizer line on the flat buffers), host logic only: anything but ALL parameters of ONE
+    CXRBERT is refused; the version-counter bookkeeping that lets a forward skip the 16-bit weight refresh notices in-place writes by others."""
+    cfg = mv.ModelConfig(vocab_size=64, hidden=64, layers=1, heads=2, intermediate=64, max_pos=32, img_hidden=8)
+    model = mv.CXRBERT(cfg, None, dtype=torch.float32, device="cpu")
+    params = list(model.parameters())
+    with pytest.raises(ValueError, match="whole flat parameter buffer"):
+        mv.optim.AdamW(params[:-1], lr=1e-3)
+    with pytest.raises(ValueError, match="not the Parameters"):
+        mv.optim.AdamW(torch.nn.Linear(2, 2).parameters(), lr=1e-3)
+    with pytest.raises(ValueError, match="single parameter group"):
+        mv.optim.AdamW([{"params": params}], lr=1e-3)
+    with pytest.raises(ValueError, match="do not belong"):
+        mv.optim.AdamW(params + list(torch.nn.Linear(2, 2).parameters()), lr=1e-3)
+    opt = mv.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=0.01)
+    assert len(opt.param_groups) == 1 and len(opt.param_groups[0]["params"]) == len(params) and opt.param_groups[0]["eps"] == 1e-6
+    assert opt.step() is None and opt._t == 0                     # no gradients anywhere: nothing happens (and no kernel is needed)
+    assert model._params_dirty()                                  # nobody has vouched for the 16-bit copies yet
+    model._opt_versions = sum(p._version for p in model._plist)   # (what step() records after its kernel has written them)
+    assert not model._params_dirty()
+    with torch.no_grad():
+        params[3].mul_(1.0)
+    assert model._params_dirty()
+    params[0].grad = torch.zeros_like(params[0])
+    with pytest.raises(RuntimeError, match="some Parameters have a gradient"):
+        opt.step()
