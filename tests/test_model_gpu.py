@@ -353,7 +353,7 @@ def test_engine_adamw_behind_the_torch_optimizer_protocol(golden_dir, dtype):
     for t in range(len(lrs)):
         opt.zero_grad()
         loss = loss_of(model)
-        assert abs(float(loss) - ref_losses[t]) < (1e-6 if dtype == torch.float32 else 2e-3), t
+        assert abs(float(loss) - ref_losses[t]) < (1e-5 if dtype == torch.float32 else 2e-3), t       # (atomic sums: not bit-reproducible)
         loss.backward()
         opt.step()
         sched.step()
