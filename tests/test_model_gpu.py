@@ -270,6 +270,41 @@ def test_lazy_forward_given_the_labels_runs_its_last_layer_on_the_consumed_rows(
     model.zero_grad()
 
 
+@pytest.mark.parametrize("family", ["full", "s2s", "mixed", "bar", "noncross", "1d"])
+@pytest.mark.parametrize("labels_in_forward", [False, True])
+def test_model_api_loop_on_every_mask_family_of_the_dataset(family, labels_in_forward):
+    """The reference's loop (train_origin.py:95-131) with the model swapped and lazy logits, over every mask family the Dataset builds
+    (dataset_origin.py:138-176), ragged lengths incl. a full-length and a one-token sample: the device matrix is recognised in all of them
+    (a full-length BAR sample is not mistaken for a full one), the padding-invisible families run on packed rows, and loss + gradients equal
+    those of the same loop with the recognition switched off (every row, the matrix as shipped)."""
+    cfg = mv.ModelConfig(hidden=128, heads=2, intermediate=512, layers=2, vocab_size=1024, max_pos=512, dropout=0.0)
+    B, N, S = 5, 6, 120
+    lens = [1, S, S] + [None] * (B - 3)
+    drawn = mv.data.synthetic_batch(cfg.vocab_size, B, N, S, family, seed=41, device="cpu")["n_ids"] - 1
+    lens = [int(drawn[i]) if v is None else v for i, v in enumerate(lens)]
+    b = mv.data.synthetic_batch(cfg.vocab_size, B, N, S, family, seed=41, device=DEV, lengths=lens)
+    model = mv.CXRBERT(cfg, None, dtype=torch.bfloat16, device=DEV)
+    model.reset_parameters(seed=6)
+    model.train()                                           # (dropout 0.0 in the config: deterministic)
+    model.lazy_logits = True
+    out = []
+    for rec in (False, True):
+        model.zero_grad()
+        model.recognise_masks = rec
+        kw = {"txt_labels": b["txt_labels"]} if labels_in_forward else {}
+        mlm, itm = model(b["cls_tok"], b["input_txt"], b["attn_mask"], b["segment"], (b["img_feats"], b["img_pos"]), b["sep_tok"], **kw)
+        packed = model.engine.S["cu"] is not None
+        loss = mv.losses.mlm_itm_loss(mlm, itm, b["txt_labels"], b["is_aligned"])
+        loss.backward()
+        out.append((packed, float(loss.detach()), model.engine.flat_g.clone(), mlm.stats.clone()))
+    (p0, l0, g0, s0), (p1, l1, g1, s1) = out
+    assert model.n_masks_seen == 1 and model.n_masks_recognised == 1
+    assert not p0 and p1 == (family in ("full", "s2s", "mixed", "1d"))
+    assert torch.equal(s0[[1, 2, 4, 5]], s1[[1, 2, 4, 5]])                  # label / sample counts, correct predictions
+    assert abs(l0 - l1) < 2e-3 and float((g0 - g1).norm() / g0.norm()) < 3e-3
+    model.zero_grad()
+
+
 def test_drop_in_gradients_are_views_of_the_flat_buffer_with_autograds_semantics(golden_dir):
     """loss.backward() on the model API (train_origin.py:129-131): with .grad = None (after optimizer.zero_grad()) every Parameter's .grad
     becomes a VIEW of the engine's flat gradient buffer (no copy, nothing for autograd to accumulate); a second backward without zero_grad
