@@ -142,7 +142,7 @@ class _CXRBertFn(torch.autograd.Function):
         if ctx.want_heads == 3 and model._lazy is not None and model._lazy[5]:
             held = model.__dict__.pop("_held", None)             # set aside by the loss, which has already zeroed the buffer
         else:
-            held = eng.flat_g.clone() if (model.grad_views and eng.flat_g is not None and _holds_views(model)) else None
+            held = eng.flat_g.clone() if (_use_views(model) and eng.flat_g is not None and _holds_views(model)) else None
         _CXRBertFn._backward_once(ctx, g0, g1)
         if eng.scaler is not None:
             # f16 gradient operands under a loss scale: this path hands gradients to torch (an external optimizer), so an
@@ -160,6 +160,16 @@ class _CXRBertFn(torch.autograd.Function):
         if held is not None:
             eng.flat_g.add_(held)
         return (None,) * 9 + _hand_over_grads(model)
+
+
+def _use_views(model):
+    gv = model.grad_views
+    if gv is not None:
+        return bool(gv)
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        return False
+    return not any(p._backward_hooks for p in model._plist)
 
 
 def _holds_views(model):
@@ -188,7 +198,7 @@ def _hand_over_grads(model):
     zero_grad(set_to_none=False)) already holds old + new (see `held` in backward); any other tensor found in .grad takes the copying path
     (autograd adds a clone to it)."""
     eng = model.engine
-    if not model.grad_views:
+    if not _use_views(model):
         return tuple(eng.g[n].clone() for n in model._param_names)
     out = []
     for n, p in zip(model._param_names, model._plist):
@@ -256,7 +266,7 @@ class _LazyLossFn(torch.autograd.Function):
         # backward reuses that when it is indeed handed 1.0 and redoes the head otherwise (an upstream factor, a loss-scale retry).
         pre = bool(ctx.needs_input_grad[0]) and model.grad_in_loss
         if pre:
-            model._held = eng.flat_g.clone() if (model.grad_views and eng.flat_g is not None and _holds_views(model)) else None
+            model._held = eng.flat_g.clone() if (_use_views(model) and eng.flat_g is not None and _holds_views(model)) else None
             eng.zero_grad()
         stats = eng.heads_train(rows, ids, aligned, mlm_scale=(1.0 / max(R, 1)) if (mlm_on or not pre) else 0.0,
                                 itm_scale=(1.0 / B) if (itm_on or not pre) else 0.0, compute_grad=pre)
@@ -361,7 +371,7 @@ class _HeadFn(torch.autograd.Function):
             return None, None, dx.view(*g.shape[:-1], H).to(ctx.in_dtype), gW, gb
 
         Vp = (V + 7) // 8 * 8
-        if model.grad_views:
+        if _use_views(model):
             _own_grads(model)        # this backward uses ranges of the flat gradient buffer as scratch: a .grad must not be a view of them
 
         def run():
@@ -410,7 +420,9 @@ class CXRBERT(nn.Module):
         self._param_names = list(self.engine.layout.keys())
         # drop-in switches: lazy MLM logits; recognition of the Dataset's materialised masks on the lazy path; gradients
         # handed to torch as views of the flat gradient buffer instead of copies (see _CXRBertFn.backward)
-        self.lazy_logits, self.recognise_masks, self.grad_views = False, True, True
+        # grad_views: None = automatic -- views unless something hooks autograd's per-parameter accumulation (a process group of more than
+        # one rank is initialised: DistributedDataParallel's reducer; a Tensor.register_hook on a Parameter), True / False force it
+        self.lazy_logits, self.recognise_masks, self.grad_views = False, True, None
         self.grad_in_loss = True          # lazy logits: the loss runs the head once, with its gradient (see _LazyLossFn)
         self.n_masks_seen = self.n_masks_recognised = 0
         self._lazy_rows = None

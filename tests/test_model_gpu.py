@@ -353,6 +353,18 @@ def test_drop_in_gradients_are_views_of_the_flat_buffer_with_autograds_semantics
     for n, p in model.named_parameters():
         assert float((p.detach() - (before[n] - 0.5 * ref[n])).abs().max()) <= 1e-6 + 1e-5 * float(ref[n].abs().max()), n
     model.zero_grad()
+    # the default (None) decides by itself: a hook on a Parameter must see its gradient arrive through autograd, so copies are handed over
+    model.grad_views = None
+    seen = []
+    some = dict(model.named_parameters())[name]
+    handle = some.register_hook(lambda g_: seen.append(tuple(g_.shape)))
+    backward()
+    assert seen == [tuple(some.shape)] and all(p.grad.data_ptr() != eng.g[n].data_ptr() for n, p in model.named_parameters())
+    handle.remove()
+    model.zero_grad()
+    backward()
+    assert all(p.grad.data_ptr() == eng.g[n].data_ptr() for n, p in model.named_parameters())
+    model.zero_grad()
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
